@@ -1,0 +1,292 @@
+/*
+ * reboundx_amd.h -- C ABI of librebxamd, an MI355X (gfx950) implementation of
+ * REBOUNDx's per-timestep additional-force path.
+ *
+ * Two groups of entry points:
+ *
+ *  A. The plugin API.  Same symbol names, argument meaning, struct layouts and
+ *     error behaviour as the reference library for this path, so REBOUND's
+ *     sim->additional_forces hook, C user programs and ctypes bindings written
+ *     for the reference bind to this library unchanged.  Each declaration cites
+ *     the reference declaration/definition it replaces (paths relative to the
+ *     reference tree).  Host particle arrays (array-of-structs) go in and out.
+ *
+ *  B. The device-resident API (rebxamd_*).  Plain device pointers and sizes;
+ *     particles and per-particle parameters live in HBM as fp64 columns and
+ *     never cross PCIe.  This is what group A calls underneath, and what a
+ *     device-resident integrator or a multi-GPU driver calls directly.
+ *
+ * No torch types, no C++ types, no HIP types appear in any signature
+ * (streams are passed as void*; pass NULL for the default stream).
+ */
+#ifndef REBOUNDX_AMD_H
+#define REBOUNDX_AMD_H
+
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef REBXAMD_WITH_REBOUND
+#include "rebound.h"
+#else
+#include "rebound_min.h"
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ======================================================================
+ * A. Plugin API (drop-in for the reference on this path)
+ * ==================================================================== */
+
+/* src/core.c:41-43 */
+extern const char* rebx_build_str;
+extern const char* rebx_version_str;
+extern const char* rebx_githash_str;
+
+/* src/reboundx.h:51-59 */
+enum rebx_param_type {
+    REBX_TYPE_NONE, REBX_TYPE_DOUBLE, REBX_TYPE_INT, REBX_TYPE_POINTER,
+    REBX_TYPE_FORCE, REBX_TYPE_UINT32, REBX_TYPE_ORBIT
+};
+/* src/reboundx.h:64-68 */
+enum REBX_COORDINATES {
+    REBX_COORDINATES_JACOBI, REBX_COORDINATES_BARYCENTRIC, REBX_COORDINATES_PARTICLE
+};
+/* src/reboundx.h:81-85 */
+enum rebx_force_type { REBX_FORCE_NONE, REBX_FORCE_POS, REBX_FORCE_VEL };
+
+/* src/reboundx.h:173-176 -- 16 bytes */
+struct rebx_node {
+    void* object;
+    struct rebx_node* next;
+};
+/* src/reboundx.h:182-186 -- 24 bytes */
+struct rebx_param {
+    char* name;
+    enum rebx_param_type type;
+    void* value;
+};
+/* src/reboundx.h:191-198 -- 40 bytes; mirrored field by field by ctypes users
+ * (reference reboundx/extras.py:284-288) */
+struct rebx_force {
+    char* name;
+    struct rebx_node* ap;
+    struct reb_simulation* sim;
+    enum rebx_force_type force_type;
+    void (*update_accelerations)(struct reb_simulation* const sim, struct rebx_force* const force,
+                                 struct reb_particle* const particles, const int N);
+};
+/* src/reboundx.h:233-243 -- 56 bytes; Python allocates this struct itself
+ * (reference reboundx/extras.py:39-45, :291-297), so the size and field order are frozen.
+ * Device state hangs off a side table keyed by the struct's address. */
+struct rebx_extras {
+    struct reb_simulation* sim;
+    struct rebx_node* additional_forces;
+    struct rebx_node* pre_timestep_modifications;
+    struct rebx_node* post_timestep_modifications;
+    struct rebx_node* registered_params;
+    struct rebx_node* allocated_forces;
+    struct rebx_node* allocated_operators;
+};
+
+/* src/reboundx.h:263, src/core.c:119-128 */
+struct rebx_extras* rebx_attach(struct reb_simulation* sim);
+/* src/reboundx.h:270, src/core.c:135-155 */
+void rebx_detach(struct reb_simulation* sim, struct rebx_extras* rebx);
+/* src/reboundx.h:271, src/core.c:130-133 */
+void rebx_extras_cleanup(struct reb_simulation* sim);
+/* src/reboundx.h:277, src/core.c:180-183 */
+void rebx_free(struct rebx_extras* rebx);
+/* src/core.h:45-46, src/core.c:158-178, :51-92 (called directly by the Python wrapper) */
+void rebx_initialize(struct reb_simulation* sim, struct rebx_extras* rebx);
+void rebx_register_default_params(struct rebx_extras* rebx);
+/* src/core.h:99, src/core.c:799-854 */
+void rebx_free_pointers(struct rebx_extras* rebx);
+/* src/core.h:95, src/core.c:764-766 (installed as sim->free_particle_ap) */
+void rebx_free_particle_ap(struct reb_particle* p);
+
+/* src/reboundx.h:332, src/core.c:189-225 */
+struct rebx_force* rebx_create_force(struct rebx_extras* const rebx, const char* name);
+/* src/reboundx.h:330, src/core.c:227-277 */
+struct rebx_force* rebx_load_force(struct rebx_extras* const rebx, const char* name);
+/* src/reboundx.h:328, src/core.c:371-409 */
+int rebx_add_force(struct rebx_extras* rebx, struct rebx_force* force);
+/* src/reboundx.h:279, src/core.c:654-662 */
+int rebx_remove_force(struct rebx_extras* rebx, struct rebx_force* force);
+/* src/reboundx.h:358, src/core.c:624-635 */
+struct rebx_force* rebx_get_force(struct rebx_extras* const rebx, const char* const name);
+
+/* src/reboundx.h:401-407, src/core.c:512-622, :94-117 */
+void* rebx_get_param(struct rebx_extras* rebx, struct rebx_node* ap, const char* const param_name);
+struct rebx_param* rebx_get_param_struct(struct rebx_extras* rebx, struct rebx_node* ap, const char* const param_name);
+void rebx_set_param_pointer(struct rebx_extras* const rebx, struct rebx_node** apptr, const char* const param_name, void* val);
+void rebx_set_param_double(struct rebx_extras* const rebx, struct rebx_node** apptr, const char* const param_name, double val);
+void rebx_set_param_int(struct rebx_extras* const rebx, struct rebx_node** apptr, const char* const param_name, int val);
+void rebx_set_param_uint32(struct rebx_extras* const rebx, struct rebx_node** apptr, const char* const param_name, uint32_t val);
+void rebx_register_param(struct rebx_extras* const rebx, const char* name, enum rebx_param_type type);
+/* src/core.h:102, src/core.c:958-966 */
+enum rebx_param_type rebx_get_type(struct rebx_extras* rebx, const char* name);
+/* src/reboundx.h:542, src/linkedlist.c:97-106 */
+int rebx_len(struct rebx_node* head);
+/* src/reboundx.h:590, src/core.c:1003-1010 */
+void rebx_error(struct rebx_extras* rebx, const char* const msg);
+
+/* src/core.h:52, src/core.c:868-880 -- the function installed in sim->additional_forces.
+ * Walks the added forces in list order (the reverse of rebx_add_force order), runs every
+ * maximal run of built-in forces as one fused device pass, and calls user-supplied
+ * callbacks on the host in between. */
+void rebx_additional_forces(struct reb_simulation* sim);
+/* src/core.h:61, src/core.c:860-866 */
+void rebx_reset_accelerations(struct reb_particle* const ps, const int N);
+
+/* src/core.h:66-74 -- the force callbacks.  Each adds its accelerations to the
+ * particle array it is given (which may be a scratch copy, src/integrator_rk4.c:58-83). */
+void rebx_gr(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N);
+void rebx_gr_full(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N);
+void rebx_gr_potential(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N);
+void rebx_radiation_forces(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N);
+void rebx_modify_orbits_forces(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N);
+void rebx_tides_precession(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N);
+void rebx_central_force(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N);
+void rebx_gravitational_harmonics(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N);
+
+/* src/reboundx.h:436,448, src/radiation_forces.c:119-124 */
+double rebx_rad_calc_beta(const double G, const double c, const double source_mass, const double source_luminosity, const double radius, const double density, const double Q_pr);
+double rebx_rad_calc_particle_radius(const double G, const double c, const double source_mass, const double source_luminosity, const double beta, const double density, const double Q_pr);
+
+/* Extensions to the plugin API (no counterpart in the reference). */
+
+/* The device copy of the per-particle parameters is rebuilt when a rebx_set_param_*,
+ * add/remove call or a change of the particle array is seen.  A value overwritten in place
+ * through a pointer obtained from rebx_get_param cannot be seen: call this afterwards. */
+void rebxamd_invalidate_params(struct rebx_extras* rebx);
+/* 0 = fast arithmetic (default), 1 = reference-order arithmetic, no FMA contraction. */
+void rebxamd_set_mode(struct rebx_extras* rebx, int mode);
+/* Milliseconds spent by the last rebx_additional_forces / callback in: [0] packing host
+ * AoS -> columns, [1] host->device, [2] kernels, [3] device->host + unpack. */
+void rebxamd_last_timings(struct rebx_extras* rebx, double out_ms[4]);
+
+/* ======================================================================
+ * B. Device-resident API
+ * ==================================================================== */
+
+typedef struct rebxamd_ctx rebxamd_ctx;
+
+enum rebxamd_status {
+    REBXAMD_OK = 0,
+    REBXAMD_ERR_ARG = 1,            /* NULL / negative size / bad index */
+    REBXAMD_ERR_HIP = 2,            /* a HIP runtime call failed; see rebxamd_last_error */
+    REBXAMD_ERR_UNSUPPORTED = 3,    /* valid request this build cannot run on the device */
+    REBXAMD_ERR_PARAM = 4           /* a required effect parameter is missing (reference: reb_error + return) */
+};
+
+enum rebxamd_mode {
+    REBXAMD_MODE_FAST = 0,          /* shared reciprocals, FMA contraction allowed; <=1e-12 relative */
+    REBXAMD_MODE_EXACT = 1          /* reference expression order, no contraction */
+};
+
+/* One elementary pass of a force.  A reference force expands to one op per source
+ * (e.g. gravitational_harmonics with one oblate body -> one J2 op then one J4 op). */
+enum rebxamd_op_kind {
+    REBXAMD_OP_RADIATION = 1,       /* src, a=c                      radiation_forces.c:69-98 */
+    REBXAMD_OP_J2 = 2,              /* src, a=J2, b=R_eq             gravitational_harmonics.c:61-85 */
+    REBXAMD_OP_J4 = 3,              /* src, a=J4, b=R_eq             gravitational_harmonics.c:99-123 */
+    REBXAMD_OP_GR = 4,              /* a=c, iarg=max_iterations      gr.c:73-171 (source is index 0) */
+    REBXAMD_OP_GR_POTENTIAL = 5,    /* a=c                           gr_potential.c:69-87 (source is index 0) */
+    REBXAMD_OP_CENTRAL = 6,         /* src, a=Acentral, b=gamma      central_force.c:63-83 */
+    REBXAMD_OP_TIDES = 7,           /* src                           tides_precession.c:65-116 */
+    REBXAMD_OP_MOF = 8,             /* iarg=coordinates, src=reference particle (PARTICLE only)
+                                       modify_orbits_forces.c:77-118 + rebxtools.c:45-126 */
+    REBXAMD_OP_GR_FULL = 9          /* a=c, iarg=gravity_ignore_10   gr_full.c:61-231 */
+};
+
+typedef struct rebxamd_op {
+    int32_t kind;
+    int32_t src;
+    int32_t iarg;
+    int32_t reserved;
+    double a;
+    double b;
+} rebxamd_op;
+
+#define REBXAMD_MAX_OPS 32
+#define REBXAMD_MAX_HEAD 64
+
+/* A set of particles resident in device memory, as fp64 columns of length n.
+ *
+ * Per-particle parameter columns use NaN for "not set on this particle"; a NULL
+ * column means not set on any particle.
+ *
+ * n_head / tail_massless describe the mass layout: if tail_massless != 0 the
+ * caller asserts that every particle with index >= n_head has m == 0 exactly
+ * (rebxamd_classify computes the smallest such n_head).  With n_head <=
+ * REBXAMD_MAX_HEAD and every op source inside the head, the library runs the
+ * head with the reference's sequential semantics in one wavefront and streams
+ * the tail with no reductions at all; otherwise it uses block reductions for
+ * the back-reactions on source particles. */
+typedef struct rebxamd_view {
+    int64_t n;
+    int64_t n_head;
+    int32_t tail_massless;
+    int32_t reserved;
+    double G;
+    const double *x, *y, *z;
+    const double *vx, *vy, *vz;
+    const double *m;
+    double *ax, *ay, *az;
+    const double *beta;
+    const double *R_tides, *k1;
+    const double *tau_a, *tau_e, *tau_inc;
+} rebxamd_view;
+
+int rebxamd_create(int device, rebxamd_ctx** out);
+void rebxamd_destroy(rebxamd_ctx* ctx);
+const char* rebxamd_last_error(rebxamd_ctx* ctx);
+
+/* Finds n_head = 1 + index of the last particle with m != 0 (at least 1).  Synchronises. */
+int rebxamd_classify(rebxamd_ctx* ctx, const double* m, int64_t n, int64_t* n_head, void* stream);
+
+/* Applies `ops` in order to the particles of `view`, adding to ax/ay/az, exactly as the
+ * reference would by calling the corresponding update_accelerations callbacks one after the
+ * other (src/core.c:868-880) -- but in as few passes over HBM as the ops allow.  Asynchronous
+ * on `stream`. */
+int rebxamd_apply(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, int mode, void* stream);
+
+/* src/core.c:860-866 on device columns. */
+int rebxamd_reset_accelerations(rebxamd_ctx* ctx, const rebxamd_view* view, void* stream);
+
+/* Bits raised by kernels since the last call (synchronises, then clears):
+ *  1 = a gr particle used 10 inner iterations (reference warns, gr.c:137-140)
+ *  2 = gr_full ran all 10 sweeps without meeting its stopping rule (gr_full.c:221-223) */
+int rebxamd_fetch_warnings(rebxamd_ctx* ctx, uint32_t* bits, void* stream);
+
+/* gr_full on one device (gr_full.c:61-231).  The three phases are also exposed on row
+ * ranges [row0,row1) so that a multi-GPU driver can shard rows and all-gather between
+ * phases.  Arrays are length-n device columns.
+ *   pot   : out pot[i] = sum_{k!=i} (1/c^2) G m_k / r_ik for rows in range (the reference's
+ *           a2 sum, gr_full.c:125-130; its a1 sum is exactly 4 pot[i])
+ *   const : out ac{x,y,z}[i] = the part that does not depend on the accelerations
+ *           (gr_full.c:104-170); needs pot of ALL bodies
+ *   sweep : out an{x,y,z}[i] = ac + terms linear in (a_newton + a_old) of ALL bodies
+ *           (gr_full.c:181-203); also sets *dev_flag (device uint32) to 1 if any row in range
+ *           fails the reference's stopping rule (gr_full.c:206-220)
+ */
+int rebxamd_grfull_pot(rebxamd_ctx* ctx, const rebxamd_view* view, double c, int64_t row0, int64_t row1, double* pot, int mode, void* stream);
+int rebxamd_grfull_const(rebxamd_ctx* ctx, const rebxamd_view* view, double c, int64_t row0, int64_t row1, const double* pot,
+                         double* acx, double* acy, double* acz, int mode, void* stream);
+int rebxamd_grfull_sweep(rebxamd_ctx* ctx, const rebxamd_view* view, double c, int64_t row0, int64_t row1,
+                         const double* anx, const double* any_, const double* anz,      /* a_newton, all bodies */
+                         const double* aox, const double* aoy, const double* aoz,       /* a_old, all bodies */
+                         const double* acx, const double* acy, const double* acz,       /* a_const, rows in range valid */
+                         double* outx, double* outy, double* outz,                      /* a_new, rows in range written */
+                         uint32_t* dev_flag, int mode, void* stream);
+/* Whole evaluation on one device, including the reference's stopping rule; adds the result
+ * to view->a{x,y,z}.  *sweeps receives the number of sweeps run.  Synchronises (it reads
+ * the stopping flag after every sweep). */
+int rebxamd_grfull(rebxamd_ctx* ctx, const rebxamd_view* view, double c, int gravity_ignore_10, int mode, int* sweeps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

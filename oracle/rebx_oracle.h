@@ -1,0 +1,91 @@
+/*
+ * rebx_oracle.h -- CPU restatement of the REBOUNDx additional-force path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the checker the HIP path is compared
+ * against; it is never linked into or called by the product library.  Only
+ * tests/, the smoke check and the CPU-baseline leg of the benchmark load it.
+ *
+ * Every routine is a plain-C, single-threaded, fp64 restatement of one
+ * reference function; the reference location is cited beside each one.
+ * Summation and evaluation order follow the reference expression by
+ * expression so that, compiled without FMA contraction, results are bitwise
+ * what the reference computes for the same inputs.
+ *
+ * Parity pinning: the reference sources cannot be built in this image
+ * (they need rebound.h / librebound from the REBOUND package, pinned as
+ * rebound>=3.10.0 in the reference setup.py:111, which is not vendored and not
+ * installed).  The oracle is therefore pinned by the reference's own recorded
+ * answers (see tests/test_oracle_kat.py) and by the potential/force
+ * consistency its conservation tests rely on.  The four REBOUND helpers
+ * (centre of mass, Jacobi transforms) are restated from REBOUND 3.x's
+ * published algorithm; for those, parity is unpinned at the instruction level.
+ *
+ * Conventions: particles are passed as SoA columns.  Per-particle double
+ * parameters are columns in which NaN means "parameter not set on this
+ * particle"; a NULL column means "not set on any particle".  Presence-only
+ * parameters (radiation_source, tides_primary, primary) are uint8 columns
+ * (non-zero = set) or NULL.
+ */
+#ifndef REBX_ORACLE_H
+#define REBX_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_sim {
+    int N;          /* real particles (N - N_var in the reference) */
+    double G;
+    double *x, *y, *z;
+    double *vx, *vy, *vz;
+    double *m;
+    double *ax, *ay, *az;   /* accumulated into (+=), as the callback contract demands */
+} orc_sim;
+
+enum { ORC_COORD_JACOBI = 0, ORC_COORD_BARYCENTRIC = 1, ORC_COORD_PARTICLE = 2 };
+
+/* src/radiation_forces.c:69-117 */
+int orc_radiation_forces(const orc_sim* s, double c, const double* beta, const uint8_t* radiation_source);
+/* src/gravitational_harmonics.c:61-140 */
+int orc_gravitational_harmonics(const orc_sim* s, const double* J2, const double* J4, const double* R_eq);
+/* src/gr.c:73-188; returns the largest inner-iteration count any particle used */
+int orc_gr(const orc_sim* s, double c, int max_iterations);
+/* same arithmetic with the reference's literal all-pairs double loop (small N only) */
+int orc_gr_literal(const orc_sim* s, double c, int max_iterations);
+/* src/gr_potential.c:69-98 */
+int orc_gr_potential(const orc_sim* s, double c);
+/* src/gr_full.c:61-249; returns the number of substitution sweeps executed (1..10) */
+int orc_gr_full(const orc_sim* s, double c, int gravity_ignore_10);
+/* src/central_force.c:63-95 */
+int orc_central_force(const orc_sim* s, const double* Acentral, const double* gammacentral);
+/* src/tides_precession.c:65-130 */
+int orc_tides_precession(const orc_sim* s, const double* R_tides, const double* k1, const uint8_t* tides_primary);
+/* src/modify_orbits_forces.c:77-129 + src/rebxtools.c:45-126; returns -1 when
+ * PARTICLE coordinates are requested and no particle carries `primary` */
+int orc_modify_orbits_forces(const orc_sim* s, int coordinates, const double* tau_a, const double* tau_e,
+                             const double* tau_inc, const uint8_t* primary);
+/* src/core.c:860-866 */
+void orc_reset_accelerations(const orc_sim* s);
+
+/* potentials used by the reference's conservation tests */
+double orc_gravitational_harmonics_potential(const orc_sim* s, const double* J2, const double* J4, const double* R_eq); /* gravitational_harmonics.c:142-231 */
+double orc_central_force_potential(const orc_sim* s, const double* Acentral, const double* gammacentral);               /* central_force.c:97-141 */
+double orc_tides_precession_potential(const orc_sim* s, const double* R_tides, const double* k1, const uint8_t* primary); /* tides_precession.c:132-202 */
+double orc_gr_potential_potential(const orc_sim* s, double c);                                                          /* gr_potential.c:100-132 */
+double orc_gr_hamiltonian(const orc_sim* s, double c);                                                                  /* gr.c:190-260 */
+double orc_newtonian_energy(const orc_sim* s);
+
+/* src/radiation_forces.c:119-124 */
+double orc_rad_calc_beta(double G, double c, double source_mass, double source_luminosity, double radius, double density, double Q_pr);
+double orc_rad_calc_particle_radius(double G, double c, double source_mass, double source_luminosity, double beta, double density, double Q_pr);
+
+/* plain Newtonian all-pairs gravity (what REBOUND adds before the hook runs); used to
+ * build realistic incoming accelerations in tests.  Only massive particles act as sources. */
+void orc_newtonian_gravity(const orc_sim* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,376 @@
+// device_api.hip -- host side of the device-resident C ABI (group B of reboundx_amd.h):
+// argument checks, translation of the op list into kernel programs, regime choice, scratch.
+#include "internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace rebxamd;
+
+struct rebxamd_ctx {
+    int device = 0;
+    std::string err;
+    HeadConsts* hc = nullptr;
+    unsigned* status = nullptr;         // warning bits raised by kernels
+    long long* ll = nullptr;            // 1 x int64 result slot
+    double* partials = nullptr;         // back-reaction partial sums
+    size_t partials_cap = 0;
+    double* gf = nullptr;               // gr_full workspace
+    size_t gf_cap = 0;
+    unsigned* gf_flag = nullptr;
+};
+
+static int fail(rebxamd_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess) {
+    if (ctx) {
+        ctx->err = what;
+        if (e != hipSuccess) { ctx->err += ": "; ctx->err += hipGetErrorString(e); }
+    }
+    return code;
+}
+
+#define HIP_TRY(call)                                                        \
+    do {                                                                     \
+        hipError_t _e = (call);                                              \
+        if (_e != hipSuccess) return fail(ctx, REBXAMD_ERR_HIP, #call, _e);  \
+    } while (0)
+
+extern "C" int rebxamd_create(int device, rebxamd_ctx** out) {
+    if (!out) return REBXAMD_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return REBXAMD_ERR_HIP;
+    rebxamd_ctx* ctx = new rebxamd_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipMalloc((void**)&ctx->hc, sizeof(HeadConsts)) != hipSuccess ||
+        hipMalloc((void**)&ctx->status, sizeof(unsigned)) != hipSuccess ||
+        hipMalloc((void**)&ctx->ll, sizeof(long long)) != hipSuccess ||
+        hipMalloc((void**)&ctx->gf_flag, sizeof(unsigned)) != hipSuccess ||
+        hipMemset(ctx->hc, 0, sizeof(HeadConsts)) != hipSuccess ||
+        hipMemset(ctx->status, 0, sizeof(unsigned)) != hipSuccess) {
+        rebxamd_destroy(ctx);
+        return REBXAMD_ERR_HIP;
+    }
+    *out = ctx;
+    return REBXAMD_OK;
+}
+
+extern "C" void rebxamd_destroy(rebxamd_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    if (ctx->hc) (void)hipFree(ctx->hc);
+    if (ctx->status) (void)hipFree(ctx->status);
+    if (ctx->ll) (void)hipFree(ctx->ll);
+    if (ctx->partials) (void)hipFree(ctx->partials);
+    if (ctx->gf) (void)hipFree(ctx->gf);
+    if (ctx->gf_flag) (void)hipFree(ctx->gf_flag);
+    delete ctx;
+}
+
+extern "C" const char* rebxamd_last_error(rebxamd_ctx* ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+
+static View make_view(const rebxamd_view* u) {
+    View v;
+    v.n = u->n;
+    v.n_head = u->n_head;
+    v.x = u->x; v.y = u->y; v.z = u->z; v.vx = u->vx; v.vy = u->vy; v.vz = u->vz; v.m = u->m;
+    v.ax = u->ax; v.ay = u->ay; v.az = u->az;
+    v.beta = u->beta; v.Rt = u->R_tides; v.k1 = u->k1; v.ta = u->tau_a; v.te = u->tau_e; v.ti = u->tau_inc;
+    return v;
+}
+
+static bool aligned16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static bool all_aligned(const View& v) {
+    return aligned16(v.x) && aligned16(v.y) && aligned16(v.z) && aligned16(v.vx) && aligned16(v.vy) && aligned16(v.vz) &&
+           aligned16(v.m) && aligned16(v.ax) && aligned16(v.ay) && aligned16(v.az) && aligned16(v.beta) && aligned16(v.Rt) &&
+           aligned16(v.k1) && aligned16(v.ta) && aligned16(v.te) && aligned16(v.ti);
+}
+
+static int ensure(rebxamd_ctx* ctx, double** buf, size_t* cap, size_t bytes, hipStream_t st) {
+    if (bytes <= *cap) return REBXAMD_OK;
+    if (*buf) {
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipFree(*buf));
+        *buf = nullptr; *cap = 0;
+    }
+    const size_t want = bytes + bytes / 4 + 4096;
+    HIP_TRY(hipMalloc((void**)buf, want));
+    *cap = want;
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_classify(rebxamd_ctx* ctx, const double* m, int64_t n, int64_t* n_head, void* stream) {
+    if (!ctx || !n_head || n < 0 || (n > 0 && !m)) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_classify: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(launch_last_massive(m, n, ctx->ll, st));
+    long long h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, ctx->ll, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *n_head = h < 1 ? 1 : h;
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_reset_accelerations(rebxamd_ctx* ctx, const rebxamd_view* view, void* stream) {
+    if (!ctx || !view || view->n < 0 || (view->n > 0 && (!view->ax || !view->ay || !view->az)))
+        return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_reset_accelerations: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(launch_reset(make_view(view), (hipStream_t)stream));
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_fetch_warnings(rebxamd_ctx* ctx, uint32_t* bits, void* stream) {
+    if (!ctx || !bits) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_fetch_warnings: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    unsigned h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, ctx->status, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemsetAsync(ctx->status, 0, sizeof(unsigned), st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *bits = h;
+    return REBXAMD_OK;
+}
+
+// ------------------------------------------------------------------ streaming ops
+
+static bool has_backreaction(const rebxamd_op& o) {
+    switch (o.kind) {
+    case REBXAMD_OP_J2: case REBXAMD_OP_J4: case REBXAMD_OP_GR_POTENTIAL: case REBXAMD_OP_CENTRAL: case REBXAMD_OP_TIDES:
+        return true;
+    case REBXAMD_OP_MOF:
+        return o.iarg == REBX_COORDINATES_PARTICLE;
+    default:
+        return false;
+    }
+}
+
+// Runs ops[lo,hi) (no gr_full inside, at most one gr and one centre-of-mass mof) as one program.
+static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_op* ops, int lo, int hi, int mode, hipStream_t st) {
+    const View v = make_view(u);
+    Program prog;
+    memset(&prog, 0, sizeof(prog));
+    prog.nops = hi - lo;
+    prog.G = u->G;
+    prog.gr_op = -1;
+    prog.mofcom_op = -1;
+    bool need_m = false;
+    int max_src = -1;
+    for (int k = lo; k < hi; k++) {
+        const rebxamd_op& o = ops[k];
+        DevOp& d = prog.ops[k - lo];
+        d.kind = o.kind; d.src = o.src; d.iarg = o.iarg; d.slot = -1; d.a = o.a; d.b = o.b; d.c = 0.; d.d = 0.;
+        switch (o.kind) {
+        case REBXAMD_OP_RADIATION:
+            d.c = 1. / o.a;
+            prog.need_vel = 1; prog.need_beta = 1; need_m = true;
+            break;
+        case REBXAMD_OP_J2: case REBXAMD_OP_J4: case REBXAMD_OP_CENTRAL:
+            need_m = true;
+            break;
+        case REBXAMD_OP_GR:
+            d.src = 0;
+            d.c = o.a * o.a; d.d = 1. / (o.a * o.a);
+            prog.need_vel = 1; need_m = true;
+            prog.gr_op = k - lo;
+            break;
+        case REBXAMD_OP_GR_POTENTIAL:
+            d.src = 0;
+            d.c = o.a * o.a; d.d = 1. / (o.a * o.a);
+            need_m = true;
+            break;
+        case REBXAMD_OP_TIDES:
+            prog.need_tides = 1; need_m = true;
+            break;
+        case REBXAMD_OP_MOF:
+            prog.need_vel = 1; prog.need_tau = 1; need_m = true;
+            if (o.iarg == REBX_COORDINATES_PARTICLE) { /* src = reference particle */ }
+            else if (o.iarg == REBX_COORDINATES_JACOBI || o.iarg == REBX_COORDINATES_BARYCENTRIC) { d.src = -1; prog.mofcom_op = k - lo; }
+            else return fail(ctx, REBXAMD_ERR_ARG, "modify_orbits_forces: unknown coordinates");
+            break;
+        default:
+            return fail(ctx, REBXAMD_ERR_ARG, "unknown op kind");
+        }
+        if (d.src >= 0) {
+            if (d.src >= v.n) return fail(ctx, REBXAMD_ERR_ARG, "op source index out of range");
+            if (d.src > max_src) max_src = d.src;
+        } else if (!(o.kind == REBXAMD_OP_MOF && o.iarg != REBX_COORDINATES_PARTICLE)) {
+            return fail(ctx, REBXAMD_ERR_ARG, "op needs a source index");
+        }
+    }
+    if (v.n <= 0) return REBXAMD_OK;
+    if (!v.x || !v.y || !v.z || !v.ax || !v.ay || !v.az) return fail(ctx, REBXAMD_ERR_ARG, "position/acceleration columns missing");
+    if (prog.need_vel && (!v.vx || !v.vy || !v.vz)) return fail(ctx, REBXAMD_ERR_ARG, "velocity columns missing");
+    if (need_m && !v.m) return fail(ctx, REBXAMD_ERR_ARG, "mass column missing");
+
+    const bool exact = (mode == REBXAMD_MODE_EXACT);
+    const bool vec2 = all_aligned(v);
+    const long long K = v.n_head < v.n ? v.n_head : v.n;
+    const bool sparse = (u->tail_massless != 0 || K == v.n) && K >= 1 && K <= REBXAMD_MAX_HEAD && max_src < K;
+
+    if (sparse) {
+        HIP_TRY(launch_head(v, prog, ctx->hc, ctx->status, exact, st));
+        if (v.n > K) HIP_TRY(launch_stream(v, prog, K, ctx->hc, nullptr, nullptr, false, exact, vec2, ctx->status, st));
+        return REBXAMD_OK;
+    }
+    // general regime
+    if (prog.gr_op >= 0)
+        return fail(ctx, REBXAMD_ERR_UNSUPPORTED, "gr needs the massive bodies to form a prefix of at most 64 particles followed by massless ones");
+    if (prog.mofcom_op >= 0)
+        return fail(ctx, REBXAMD_ERR_UNSUPPORTED, "modify_orbits_forces in Jacobi/barycentric coordinates needs the massive bodies to form a prefix of at most 64 particles; use REBX_COORDINATES_PARTICLE");
+    int nslots = 0;
+    for (int k = lo; k < hi; k++)
+        if (has_backreaction(ops[k])) prog.ops[k - lo].slot = nslots++;
+    prog.nslots = nslots;
+    const int nb = stream_block_count(0, v.n, vec2);
+    if (nslots > 0) {
+        const int rc = ensure(ctx, &ctx->partials, &ctx->partials_cap, (size_t)nslots * (size_t)nb * 3 * sizeof(double), st);
+        if (rc != REBXAMD_OK) return rc;
+    }
+    int nblocks = 0;
+    HIP_TRY(launch_stream(v, prog, 0, ctx->hc, ctx->partials, &nblocks, nslots > 0, exact, vec2, ctx->status, st));
+    if (nslots > 0) HIP_TRY(launch_finalize(v, prog, ctx->partials, nblocks, st));
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_apply(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, int mode, void* stream) {
+    if (!ctx) return REBXAMD_ERR_ARG;
+    if (!view || nops < 0 || (nops > 0 && !ops) || view->n < 0 || view->n_head < 0) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_apply: bad argument");
+    if (mode != REBXAMD_MODE_FAST && mode != REBXAMD_MODE_EXACT) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_apply: bad mode");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int lo = 0;
+    while (lo < nops) {
+        if (ops[lo].kind == REBXAMD_OP_GR_FULL) {
+            int sweeps = 0;
+            const int rc = rebxamd_grfull(ctx, view, ops[lo].a, ops[lo].iarg, mode, &sweeps, stream);
+            if (rc != REBXAMD_OK) return rc;
+            lo++;
+            continue;
+        }
+        int hi = lo, ngr = 0, ncom = 0;
+        while (hi < nops && hi - lo < REBXAMD_MAX_OPS && ops[hi].kind != REBXAMD_OP_GR_FULL) {
+            if (ops[hi].kind == REBXAMD_OP_GR && ++ngr > 1) break;
+            if (ops[hi].kind == REBXAMD_OP_MOF && ops[hi].iarg != REBX_COORDINATES_PARTICLE && ++ncom > 1) break;
+            hi++;
+        }
+        const int rc = run_streaming(ctx, view, ops, lo, hi, mode, st);
+        if (rc != REBXAMD_OK) return rc;
+        lo = hi;
+    }
+    return REBXAMD_OK;
+}
+
+// ------------------------------------------------------------------ gr_full
+
+static int grfull_check(rebxamd_ctx* ctx, const rebxamd_view* u, int64_t row0, int64_t row1) {
+    if (!ctx) return REBXAMD_ERR_ARG;
+    if (!u || u->n < 0 || row0 < 0 || row1 < row0 || row1 > u->n) return fail(ctx, REBXAMD_ERR_ARG, "gr_full: bad row range");
+    if (u->n > 0 && (!u->x || !u->y || !u->z || !u->vx || !u->vy || !u->vz || !u->m)) return fail(ctx, REBXAMD_ERR_ARG, "gr_full: missing column");
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_grfull_pot(rebxamd_ctx* ctx, const rebxamd_view* u, double c, int64_t row0, int64_t row1, double* pot, int mode, void* stream) {
+    int rc = grfull_check(ctx, u, row0, row1);
+    if (rc != REBXAMD_OK) return rc;
+    if (!pot) return fail(ctx, REBXAMD_ERR_ARG, "gr_full: NULL output");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const bool exact = mode == REBXAMD_MODE_EXACT;
+    if (!exact) {
+        rc = ensure(ctx, &ctx->partials, &ctx->partials_cap, grfull_partial_bytes(u->n, row1 - row0), st);
+        if (rc != REBXAMD_OK) return rc;
+    }
+    HIP_TRY(launch_grfull_pass(0, make_view(u), u->G, c, row0, row1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                               nullptr, nullptr, nullptr, pot, nullptr, nullptr, nullptr, ctx->partials, exact, st));
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_grfull_const(rebxamd_ctx* ctx, const rebxamd_view* u, double c, int64_t row0, int64_t row1, const double* pot,
+                                    double* acx, double* acy, double* acz, int mode, void* stream) {
+    int rc = grfull_check(ctx, u, row0, row1);
+    if (rc != REBXAMD_OK) return rc;
+    if (!pot || !acx || !acy || !acz) return fail(ctx, REBXAMD_ERR_ARG, "gr_full: NULL buffer");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const bool exact = mode == REBXAMD_MODE_EXACT;
+    if (!exact) {
+        rc = ensure(ctx, &ctx->partials, &ctx->partials_cap, grfull_partial_bytes(u->n, row1 - row0), st);
+        if (rc != REBXAMD_OK) return rc;
+    }
+    HIP_TRY(launch_grfull_pass(1, make_view(u), u->G, c, row0, row1, pot, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                               nullptr, nullptr, nullptr, acx, acy, acz, nullptr, ctx->partials, exact, st));
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_grfull_sweep(rebxamd_ctx* ctx, const rebxamd_view* u, double c, int64_t row0, int64_t row1,
+                                    const double* anx, const double* any_, const double* anz,
+                                    const double* aox, const double* aoy, const double* aoz,
+                                    const double* acx, const double* acy, const double* acz,
+                                    double* outx, double* outy, double* outz, uint32_t* dev_flag, int mode, void* stream) {
+    int rc = grfull_check(ctx, u, row0, row1);
+    if (rc != REBXAMD_OK) return rc;
+    if (!anx || !any_ || !anz || !aox || !aoy || !aoz || !acx || !acy || !acz || !outx || !outy || !outz || !dev_flag)
+        return fail(ctx, REBXAMD_ERR_ARG, "gr_full: NULL buffer");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const bool exact = mode == REBXAMD_MODE_EXACT;
+    if (!exact) {
+        rc = ensure(ctx, &ctx->partials, &ctx->partials_cap, grfull_partial_bytes(u->n, row1 - row0), st);
+        if (rc != REBXAMD_OK) return rc;
+    }
+    HIP_TRY(launch_grfull_pass(2, make_view(u), u->G, c, row0, row1, nullptr, anx, any_, anz, aox, aoy, aoz, acx, acy, acz,
+                               outx, outy, outz, dev_flag, ctx->partials, exact, st));
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_grfull(rebxamd_ctx* ctx, const rebxamd_view* u, double c, int gravity_ignore_10, int mode, int* sweeps, void* stream) {
+    int rc = grfull_check(ctx, u, 0, u ? u->n : 0);
+    if (rc != REBXAMD_OK) return rc;
+    if (sweeps) *sweeps = 0;
+    const long long n = u->n;
+    if (n <= 0) return REBXAMD_OK;
+    if (!u->ax || !u->ay || !u->az) return fail(ctx, REBXAMD_ERR_ARG, "gr_full: acceleration columns missing");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    // workspace: a_newton(3) pot(1) a_const(3) a_old(3) a_new(3) = 13 columns
+    rc = ensure(ctx, &ctx->gf, &ctx->gf_cap, (size_t)13 * (size_t)n * sizeof(double), st);
+    if (rc != REBXAMD_OK) return rc;
+    double* w = ctx->gf;
+    double *anx = w, *any_ = w + n, *anz = w + 2 * n, *pot = w + 3 * n;
+    double *acx = w + 4 * n, *acy = w + 5 * n, *acz = w + 6 * n;
+    double *aox = w + 7 * n, *aoy = w + 8 * n, *aoz = w + 9 * n;
+    double *nwx = w + 10 * n, *nwy = w + 11 * n, *nwz = w + 12 * n;
+    const View v = make_view(u);
+    HIP_TRY(launch_grfull_prepare(v, u->G, gravity_ignore_10, anx, any_, anz, aox, aoy, aoz, st));
+    rc = rebxamd_grfull_pot(ctx, u, c, 0, n, pot, mode, stream);
+    if (rc != REBXAMD_OK) return rc;
+    rc = rebxamd_grfull_const(ctx, u, c, 0, n, pot, acx, acy, acz, mode, stream);
+    if (rc != REBXAMD_OK) return rc;
+    int k = 0;
+    unsigned flag = 0;
+    for (k = 0; k < 10; k++) {          // reference gr_full.c:173: the bound is the literal 10
+        HIP_TRY(hipMemsetAsync(ctx->gf_flag, 0, sizeof(unsigned), st));
+        rc = rebxamd_grfull_sweep(ctx, u, c, 0, n, anx, any_, anz, aox, aoy, aoz, acx, acy, acz, nwx, nwy, nwz, ctx->gf_flag, mode, stream);
+        if (rc != REBXAMD_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(&flag, ctx->gf_flag, sizeof(flag), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        std::swap(aox, nwx); std::swap(aoy, nwy); std::swap(aoz, nwz);   // a_old now holds the newest iterate
+        if (!flag) { k++; break; }
+    }
+    if (flag) {                         // all ten sweeps ran without meeting the stopping rule
+        unsigned bit = WARN_GRFULL_SWEEPS, cur = 0;
+        HIP_TRY(hipMemcpyAsync(&cur, ctx->status, sizeof(cur), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        cur |= bit;
+        HIP_TRY(hipMemcpyAsync(ctx->status, &cur, sizeof(cur), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (sweeps) *sweeps = k;
+    HIP_TRY(launch_grfull_finish(v, aox, aoy, aoz, st));
+    return REBXAMD_OK;
+}

@@ -1,0 +1,327 @@
+// effects.h -- per-particle arithmetic of every streaming force, as device functions.
+//
+// Each force exists twice:
+//   *_exact : the reference's expressions in the reference's order with FMA contraction
+//             switched off, so that (with IEEE divide/sqrt) a particle's update carries the
+//             same bits the reference C code produces;
+//   *_fast  : the same mathematics with one reciprocal square root per (particle, source),
+//             reciprocals of loop invariants hoisted and contraction allowed.  Deviation from
+//             *_exact is a few ulp of the largest term of each component.
+//
+// All functions return the update for the particle itself in `d` (caller does acc += d) and,
+// where the reference also pushes on the source particle, the update for the source in `br`
+// (caller does acc[src] += br, i.e. br already carries the sign).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cmath>
+
+namespace rebxamd {
+
+struct V3 { double x, y, z; };
+
+// dynamic state of one particle plus its parameter columns (NaN = not set)
+struct Part {
+    double x, y, z, vx, vy, vz, m;
+    double beta, Rt, k1, ta, te, ti;
+};
+
+// snapshot of a source / reference body
+struct Src {
+    double x, y, z, vx, vy, vz, m;
+    double Rt, k1;      // tides only: source's own R_tides, k1 (0 when not set)
+};
+
+__device__ __forceinline__ bool is_set(double v) { return v == v; }
+
+// ---------------------------------------------------------------- radiation_forces
+// reference src/radiation_forces.c:69-98
+__device__ __forceinline__ void rad_exact(const Part& p, const Src& S, double G, double c, V3& d) {
+#pragma clang fp contract(off)
+    const double mu = G * S.m;
+    const double dx = p.x - S.x, dy = p.y - S.y, dz = p.z - S.z;
+    const double dr = sqrt(dx * dx + dy * dy + dz * dz);
+    const double dvx = p.vx - S.vx, dvy = p.vy - S.vy, dvz = p.vz - S.vz;
+    const double rdot = (dx * dvx + dy * dvy + dz * dvz) / dr;
+    const double a_rad = p.beta * mu / (dr * dr);
+    d.x = a_rad * ((1. - rdot / c) * dx / dr - dvx / c);
+    d.y = a_rad * ((1. - rdot / c) * dy / dr - dvy / c);
+    d.z = a_rad * ((1. - rdot / c) * dz / dr - dvz / c);
+}
+__device__ __forceinline__ void rad_fast(const Part& p, const Src& S, double G, double invc, V3& d) {
+    const double dx = p.x - S.x, dy = p.y - S.y, dz = p.z - S.z;
+    const double dvx = p.vx - S.vx, dvy = p.vy - S.vy, dvz = p.vz - S.vz;
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    const double ri = rsqrt(r2);
+    const double rdot = (dx * dvx + dy * dvy + dz * dvz) * ri;
+    const double a_rad = p.beta * (G * S.m) * (ri * ri);
+    const double k = (1. - rdot * invc) * ri;
+    d.x = a_rad * (k * dx - dvx * invc);
+    d.y = a_rad * (k * dy - dvy * invc);
+    d.z = a_rad * (k * dz - dvz * invc);
+}
+
+// ---------------------------------------------------------------- gravitational_harmonics
+// reference src/gravitational_harmonics.c:61-85
+__device__ __forceinline__ void j2_exact(const Part& p, const Src& S, double G, double J2, double R_eq, V3& d, V3& br) {
+#pragma clang fp contract(off)
+    const double dx = p.x - S.x, dy = p.y - S.y, dz = p.z - S.z;
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    const double r = sqrt(r2);
+    const double costheta2 = dz * dz / r2;
+    const double prefac = 3. * J2 * R_eq * R_eq / r2 / r2 / r / 2.;
+    const double fac = 5. * costheta2 - 1.;
+    d.x = G * S.m * prefac * fac * dx;
+    d.y = G * S.m * prefac * fac * dy;
+    d.z = G * S.m * prefac * (fac - 2.) * dz;
+    br.x = -(G * p.m * prefac * fac * dx);
+    br.y = -(G * p.m * prefac * fac * dy);
+    br.z = -(G * p.m * prefac * (fac - 2.) * dz);
+}
+__device__ __forceinline__ void j2_fast(const Part& p, const Src& S, double G, double J2, double R_eq, V3& d, V3& br) {
+    const double dx = p.x - S.x, dy = p.y - S.y, dz = p.z - S.z;
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    const double ri = rsqrt(r2);
+    const double ri2 = ri * ri;
+    const double costheta2 = dz * dz * ri2;
+    const double prefac = (1.5 * J2 * R_eq * R_eq) * (ri2 * ri2 * ri);
+    const double fac = 5. * costheta2 - 1.;
+    const double fx = prefac * fac * dx, fy = prefac * fac * dy, fz = prefac * (fac - 2.) * dz;
+    const double gs = G * S.m, gp = -(G * p.m);
+    d.x = gs * fx; d.y = gs * fy; d.z = gs * fz;
+    br.x = gp * fx; br.y = gp * fy; br.z = gp * fz;
+}
+// reference src/gravitational_harmonics.c:99-123
+__device__ __forceinline__ void j4_exact(const Part& p, const Src& S, double G, double J4, double R_eq, V3& d, V3& br) {
+#pragma clang fp contract(off)
+    const double dx = p.x - S.x, dy = p.y - S.y, dz = p.z - S.z;
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    const double r = sqrt(r2);
+    const double costheta2 = dz * dz / r2;
+    const double prefac = 5. * J4 * R_eq * R_eq * R_eq * R_eq / r2 / r2 / r2 / r / 8.;
+    const double fac = 63. * costheta2 * costheta2 - 42. * costheta2 + 3.;
+    d.x = G * S.m * prefac * fac * dx;
+    d.y = G * S.m * prefac * fac * dy;
+    d.z = G * S.m * prefac * (fac + 12. - 28. * costheta2) * dz;
+    br.x = -(G * p.m * prefac * fac * dx);
+    br.y = -(G * p.m * prefac * fac * dy);
+    br.z = -(G * p.m * prefac * (fac + 12. - 28. * costheta2) * dz);
+}
+__device__ __forceinline__ void j4_fast(const Part& p, const Src& S, double G, double J4, double R_eq, V3& d, V3& br) {
+    const double dx = p.x - S.x, dy = p.y - S.y, dz = p.z - S.z;
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    const double ri = rsqrt(r2);
+    const double ri2 = ri * ri;
+    const double costheta2 = dz * dz * ri2;
+    const double Re2 = R_eq * R_eq;
+    const double prefac = (0.625 * J4 * Re2 * Re2) * (ri2 * ri2 * ri2 * ri);
+    const double fac = 63. * costheta2 * costheta2 - 42. * costheta2 + 3.;
+    const double fx = prefac * fac * dx, fy = prefac * fac * dy, fz = prefac * (fac + 12. - 28. * costheta2) * dz;
+    const double gs = G * S.m, gp = -(G * p.m);
+    d.x = gs * fx; d.y = gs * fy; d.z = gs * fz;
+    br.x = gp * fx; br.y = gp * fy; br.z = gp * fz;
+}
+
+// ---------------------------------------------------------------- gr_potential
+// reference src/gr_potential.c:69-87 ; prefac1 = 6 (G m0)^2 / c^2
+__device__ __forceinline__ void grpot_exact(const Part& p, const Src& S, double prefac1, V3& d, V3& br) {
+#pragma clang fp contract(off)
+    const double dx = p.x - S.x, dy = p.y - S.y, dz = p.z - S.z;
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    const double prefac = prefac1 / (r2 * r2);
+    d.x = -(prefac * dx); d.y = -(prefac * dy); d.z = -(prefac * dz);
+    br.x = p.m / S.m * prefac * dx;
+    br.y = p.m / S.m * prefac * dy;
+    br.z = p.m / S.m * prefac * dz;
+}
+__device__ __forceinline__ void grpot_fast(const Part& p, const Src& S, double prefac1, double inv_ms, V3& d, V3& br) {
+    const double dx = p.x - S.x, dy = p.y - S.y, dz = p.z - S.z;
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    const double prefac = prefac1 / (r2 * r2);
+    const double fx = prefac * dx, fy = prefac * dy, fz = prefac * dz;
+    const double w = p.m * inv_ms;
+    d.x = -fx; d.y = -fy; d.z = -fz;
+    br.x = w * fx; br.y = w * fy; br.z = w * fz;
+}
+
+// ---------------------------------------------------------------- central_force
+// reference src/central_force.c:63-83
+__device__ __forceinline__ void central_exact(const Part& p, const Src& S, double A, double gamma, V3& d, V3& br) {
+#pragma clang fp contract(off)
+    const double dx = p.x - S.x, dy = p.y - S.y, dz = p.z - S.z;
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    const double prefac = A * pow(r2, (gamma - 1.) / 2.);
+    d.x = prefac * dx; d.y = prefac * dy; d.z = prefac * dz;
+    br.x = -(p.m / S.m * prefac * dx);
+    br.y = -(p.m / S.m * prefac * dy);
+    br.z = -(p.m / S.m * prefac * dz);
+}
+__device__ __forceinline__ void central_fast(const Part& p, const Src& S, double A, double gamma, V3& d, V3& br) {
+    const double dx = p.x - S.x, dy = p.y - S.y, dz = p.z - S.z;
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    const double prefac = A * pow(r2, 0.5 * (gamma - 1.));
+    d.x = prefac * dx; d.y = prefac * dy; d.z = prefac * dz;
+    const double w = -(p.m / S.m);
+    br.x = w * d.x; br.y = w * d.y; br.z = w * d.z;
+}
+
+// ---------------------------------------------------------------- tides_precession
+// reference src/tides_precession.c:65-116.  Returns false when the body is skipped
+// (mass ratio below DBL_MIN: massless bodies feel and exert nothing).
+__device__ __forceinline__ bool tides_exact(const Part& p, const Src& S, double G, V3& d, V3& br) {
+#pragma clang fp contract(off)
+    const double m0 = S.m;
+    const double fac0 = S.k1 * S.Rt * S.Rt * S.Rt * S.Rt * S.Rt;
+    const double mratio = p.m / m0;
+    if (mratio < DBL_MIN) return false;
+    double fac = 0.;
+    fac += fac0 * mratio;
+    const double Rp = is_set(p.Rt) ? p.Rt : 0.;
+    const double k1p = is_set(p.k1) ? p.k1 : 0.;
+    fac += k1p * Rp * Rp * Rp * Rp * Rp / mratio;
+    const double dx = p.x - S.x, dy = p.y - S.y, dz = p.z - S.z;
+    const double dr2 = dx * dx + dy * dy + dz * dz;
+    const double prefac = -3 * G * (m0 + p.m) / (dr2 * dr2 * dr2 * dr2) * fac;
+    d.x = prefac * dx; d.y = prefac * dy; d.z = prefac * dz;
+    br.x = -(mratio * prefac * dx);
+    br.y = -(mratio * prefac * dy);
+    br.z = -(mratio * prefac * dz);
+    return true;
+}
+__device__ __forceinline__ bool tides_fast(const Part& p, const Src& S, double G, V3& d, V3& br) {
+    const double m0 = S.m;
+    const double R02 = S.Rt * S.Rt;
+    const double fac0 = S.k1 * R02 * R02 * S.Rt;
+    const double mratio = p.m / m0;
+    if (mratio < DBL_MIN) return false;
+    const double Rp = is_set(p.Rt) ? p.Rt : 0.;
+    const double k1p = is_set(p.k1) ? p.k1 : 0.;
+    const double Rp2 = Rp * Rp;
+    const double fac = fac0 * mratio + (k1p * Rp2 * Rp2 * Rp) * (m0 / p.m);
+    const double dx = p.x - S.x, dy = p.y - S.y, dz = p.z - S.z;
+    const double dr2 = dx * dx + dy * dy + dz * dz;
+    const double dr4 = dr2 * dr2;
+    const double prefac = -3. * G * (m0 + p.m) * fac / (dr4 * dr4);
+    d.x = prefac * dx; d.y = prefac * dy; d.z = prefac * dz;
+    br.x = -(mratio * d.x); br.y = -(mratio * d.y); br.z = -(mratio * d.z);
+    return true;
+}
+
+// ---------------------------------------------------------------- modify_orbits_forces
+// reference src/modify_orbits_forces.c:77-118 ; force on p relative to `ref` (a particle or a
+// centre of mass).  Unset timescales act as +infinity.
+__device__ __forceinline__ void mof_exact(const Part& p, const Src& ref, V3& a) {
+#pragma clang fp contract(off)
+    const double tau_a = is_set(p.ta) ? p.ta : INFINITY;
+    const double tau_e = is_set(p.te) ? p.te : INFINITY;
+    const double tau_inc = is_set(p.ti) ? p.ti : INFINITY;
+    const double dvx = p.vx - ref.vx, dvy = p.vy - ref.vy, dvz = p.vz - ref.vz;
+    const double dx = p.x - ref.x, dy = p.y - ref.y, dz = p.z - ref.z;
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    a.x = dvx / (2. * tau_a);
+    a.y = dvy / (2. * tau_a);
+    a.z = dvz / (2. * tau_a);
+    if (tau_e < INFINITY || tau_inc < INFINITY) {
+        const double vdotr = dx * dvx + dy * dvy + dz * dvz;
+        const double prefac = 2 * vdotr / r2 / tau_e;
+        a.x += prefac * dx;
+        a.y += prefac * dy;
+        a.z += prefac * dz + 2. * dvz / tau_inc;
+    }
+}
+// The damping terms routinely cancel against each other (da/dt term vs. the radial term), so
+// a reciprocal-multiply version loses digits on exactly the components that matter; the five
+// divisions are cheap next to the memory traffic, so both modes use the same arithmetic.
+__device__ __forceinline__ void mof_fast(const Part& p, const Src& ref, V3& a) { mof_exact(p, ref, a); }
+
+// ---------------------------------------------------------------- gr (1PN, single dominant mass)
+// Jacobi-coordinate state of one body: position, velocity, Newtonian acceleration.
+struct Jac { double x, y, z, vx, vy, vz, ax, ay, az; };
+
+// reference src/gr.c:110-156.  out = post-Newtonian acceleration in Jacobi coordinates;
+// returns the number of inner iterations used.
+__device__ __forceinline__ int gr_term_exact(const Jac& p, double mu, double C2, int max_iterations, V3& out) {
+#pragma clang fp contract(off)
+    double vix = p.vx, viy = p.vy, viz = p.vz;
+    double vi2 = vix * vix + viy * viy + viz * viz;
+    const double ri = sqrt(p.x * p.x + p.y * p.y + p.z * p.z);
+    int q = 0;
+    double A = (0.5 * vi2 + 3. * mu / ri) / C2;
+    for (q = 0; q < max_iterations; q++) {
+        const double ox = vix, oy = viy, oz = viz;
+        vix = p.vx / (1. - A);
+        viy = p.vy / (1. - A);
+        viz = p.vz / (1. - A);
+        vi2 = vix * vix + viy * viy + viz * viz;
+        A = (0.5 * vi2 + 3. * mu / ri) / C2;
+        const double dvx = vix - ox, dvy = viy - oy, dvz = viz - oz;
+        if ((dvx * dvx + dvy * dvy + dvz * dvz) / vi2 < DBL_EPSILON * DBL_EPSILON) break;
+    }
+    const double B = (mu / ri - 1.5 * vi2) * mu / (ri * ri * ri) / C2;
+    const double rdotrdot = p.x * p.vx + p.y * p.vy + p.z * p.vz;
+    const double vdx = p.ax + B * p.x, vdy = p.ay + B * p.y, vdz = p.az + B * p.z;
+    const double vdotvdot = vix * vdx + viy * vdy + viz * vdz;
+    const double D = (vdotvdot - 3. * mu / (ri * ri * ri) * rdotrdot) / C2;
+    out.x = B * (1. - A) * p.x - A * p.ax - D * vix;
+    out.y = B * (1. - A) * p.y - A * p.ay - D * viy;
+    out.z = B * (1. - A) * p.z - A * p.az - D * viz;
+    return q;
+}
+__device__ __forceinline__ int gr_term_fast(const Jac& p, double mu, double invC2, int max_iterations, V3& out) {
+    double vix = p.vx, viy = p.vy, viz = p.vz;
+    double vi2 = vix * vix + viy * viy + viz * viz;
+    const double rinv = rsqrt(p.x * p.x + p.y * p.y + p.z * p.z);
+    const double mur = mu * rinv;
+    int q = 0;
+    double A = (0.5 * vi2 + 3. * mur) * invC2;
+    for (q = 0; q < max_iterations; q++) {
+        const double ox = vix, oy = viy, oz = viz;
+        const double s = 1. / (1. - A);
+        vix = p.vx * s; viy = p.vy * s; viz = p.vz * s;
+        vi2 = vix * vix + viy * viy + viz * viz;
+        A = (0.5 * vi2 + 3. * mur) * invC2;
+        const double dvx = vix - ox, dvy = viy - oy, dvz = viz - oz;
+        if ((dvx * dvx + dvy * dvy + dvz * dvz) < (DBL_EPSILON * DBL_EPSILON) * vi2) break;
+    }
+    const double mur3 = mur * rinv * rinv;         // mu / r^3
+    const double B = (mur - 1.5 * vi2) * mur3 * invC2;
+    const double rdotrdot = p.x * p.vx + p.y * p.vy + p.z * p.vz;
+    const double vdx = p.ax + B * p.x, vdy = p.ay + B * p.y, vdz = p.az + B * p.z;
+    const double vdotvdot = vix * vdx + viy * vdy + viz * vdz;
+    const double D = (vdotvdot - 3. * mur3 * rdotrdot) * invC2;
+    const double BA = B * (1. - A);
+    out.x = BA * p.x - A * p.ax - D * vix;
+    out.y = BA * p.y - A * p.ay - D * viy;
+    out.z = BA * p.z - A * p.az - D * viz;
+    return q;
+}
+
+// Newtonian pull of massive body u on body t, in the orientation the reference's pair loop
+// (src/gr.c:86-103) gives it: u<t -> d = p_u - p_t and += ; u>t -> d = p_t - p_u and -= .
+__device__ __forceinline__ void newton_pair_exact(double tx, double ty, double tz, double ux, double uy, double uz, double um,
+                                                  bool u_before_t, double G, double& ax, double& ay, double& az) {
+#pragma clang fp contract(off)
+    if (u_before_t) {
+        const double dx = ux - tx, dy = uy - ty, dz = uz - tz;
+        const double r2 = dx * dx + dy * dy + dz * dz;
+        const double r = sqrt(r2);
+        const double prefac = G / (r2 * r);
+        ax += prefac * um * dx; ay += prefac * um * dy; az += prefac * um * dz;
+    } else {
+        const double dx = tx - ux, dy = ty - uy, dz = tz - uz;
+        const double r2 = dx * dx + dy * dy + dz * dz;
+        const double r = sqrt(r2);
+        const double prefac = G / (r2 * r);
+        ax -= prefac * um * dx; ay -= prefac * um * dy; az -= prefac * um * dz;
+    }
+}
+__device__ __forceinline__ void newton_pair_fast(double tx, double ty, double tz, double ux, double uy, double uz, double um,
+                                                 double G, double& ax, double& ay, double& az) {
+    const double dx = ux - tx, dy = uy - ty, dz = uz - tz;
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    const double ri = rsqrt(r2);
+    const double w = (G * um) * (ri * ri * ri);
+    ax += w * dx; ay += w * dy; az += w * dz;
+}
+
+}  // namespace rebxamd

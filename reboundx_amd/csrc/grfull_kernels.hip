@@ -1,0 +1,340 @@
+// grfull_kernels.hip -- gr_full (1PN Einstein-Infeld-Hoffmann, all pairs) for gfx950.
+//
+// Reference: src/gr_full.c:61-231.  The reference recomputes two potential sums inside its
+// pair loop (O(N^3)) and keeps N x N separations on the stack; here every pass is one
+// O(N^2) all-pairs sweep over fp64 columns:
+//   pot   : pot_i   = sum_{k!=i} (1/c^2) G m_k / r_ik          (a2 of the reference; a1 = 4 pot_i)
+//   const : ac_i    = sum_{j!=i} [ G m_j d_ij/r^3 (a1+..+a6) + G m_j (d_ij.(4v_i-3v_j)) (v_i-v_j)/r^3/c^2 ]
+//   sweep : anew_i  = ac_i + sum_{j!=i} [ G m_j d_ij/r^3 (d_ij.t_j)/(2c^2) + 7/(2c^2) G m_j t_j / r ],
+//           t_j = a_newton_j + a_old_j
+// Not a dense contraction (every pair needs its own reciprocal square root), so this is fp64
+// vector-ALU work, tiled through LDS: a workgroup owns 256 rows i (one per thread), stages
+// 256-body tiles of j in LDS and every lane reads the same j by broadcast.  The j range is
+// split over blockIdx.y so that small row shards still fill 256 CUs; the split partial sums are
+// combined in fixed order by a second tiny kernel (deterministic, no atomics), which also
+// applies the reference's stopping rule with a wavefront ballot.
+//
+// The *exact* variants walk j sequentially in one workgroup column with the reference's
+// expression order and no FMA contraction; they exist for bit-level parity checks at small N.
+#include "internal.h"
+#include <cfloat>
+
+namespace rebxamd {
+
+static constexpr int GB = 256;      // rows per workgroup == bodies per LDS tile
+
+enum { PASS_POT = 0, PASS_CONST = 1, PASS_SWEEP = 2 };
+
+struct GrFullArgs {
+    long long n, row0, row1;
+    long long jchunk;                   // bodies per blockIdx.y
+    double G, C2, invC2;
+    const double *x, *y, *z, *vx, *vy, *vz, *m;
+    const double *pot;                  // const pass
+    const double *anx, *any_, *anz, *aox, *aoy, *aoz;   // sweep pass
+    double* part;                       // [nchunks][nrows][ncomp]
+};
+
+// ------------------------------------------------------------------ fast passes
+template <int PASS>
+__global__ __launch_bounds__(GB) void grfull_fast_kernel(GrFullArgs a) {
+    __shared__ double tj[8][GB];        // column-major tile: tj[c][jj]
+    const int tid = threadIdx.x;
+    const long long nrows = a.row1 - a.row0;
+    const long long r = (long long)blockIdx.x * GB + tid;
+    const long long i = a.row0 + r;
+    const bool live = r < nrows;
+    const long long j0 = (long long)blockIdx.y * a.jchunk;
+    long long j1 = j0 + a.jchunk; if (j1 > a.n) j1 = a.n;
+
+    double xi = 0., yi = 0., zi = 0., vxi = 0., vyi = 0., vzi = 0., vi2 = 0., p4 = 0.;
+    if (live) {
+        xi = a.x[i]; yi = a.y[i]; zi = a.z[i];
+        if (PASS == PASS_CONST) {
+            vxi = a.vx[i]; vyi = a.vy[i]; vzi = a.vz[i];
+            vi2 = vxi * vxi + vyi * vyi + vzi * vzi;
+            p4 = 4. * a.pot[i] * a.C2;          // work in units where 1/c^2 is applied once at the end
+        }
+    }
+    double s0 = 0., s1 = 0., s2 = 0.;
+
+    for (long long jt = j0; jt < j1; jt += GB) {
+        const long long j = jt + tid;
+        __syncthreads();
+        if (j < j1) {
+            tj[0][tid] = a.x[j]; tj[1][tid] = a.y[j]; tj[2][tid] = a.z[j]; tj[3][tid] = a.G * a.m[j];
+            if (PASS == PASS_CONST) {
+                tj[4][tid] = a.vx[j]; tj[5][tid] = a.vy[j]; tj[6][tid] = a.vz[j]; tj[7][tid] = a.pot[j] * a.C2;
+            }
+            if (PASS == PASS_SWEEP) {
+                tj[4][tid] = a.anx[j] + a.aox[j]; tj[5][tid] = a.any_[j] + a.aoy[j]; tj[6][tid] = a.anz[j] + a.aoz[j];
+            }
+        } else {
+            // padding bodies: zero mass far away contributes exactly nothing
+            tj[0][tid] = 1.e100; tj[1][tid] = 1.e100; tj[2][tid] = 1.e100; tj[3][tid] = 0.;
+            tj[4][tid] = 0.; tj[5][tid] = 0.; tj[6][tid] = 0.; tj[7][tid] = 0.;
+        }
+        __syncthreads();
+        const int self = (live && i >= jt && i < jt + GB) ? (int)(i - jt) : -1;
+#pragma unroll 4
+        for (int jj = 0; jj < GB; jj++) {
+            const double dx = xi - tj[0][jj], dy = yi - tj[1][jj], dz = zi - tj[2][jj];
+            const double r2 = dx * dx + dy * dy + dz * dz;
+            double gm = tj[3][jj];
+            if (jj == self) gm = 0.;                    // no self term (r2 == 0 handled below)
+            const double ri = (jj == self) ? 0. : rsqrt(r2);
+            if (PASS == PASS_POT) {
+                s0 += gm * ri;
+            } else if (PASS == PASS_CONST) {
+                const double vxj = tj[4][jj], vyj = tj[5][jj], vzj = tj[6][jj];
+                const double ri2 = ri * ri;
+                const double g3 = gm * ri2 * ri;
+                const double vj2 = vxj * vxj + vyj * vyj + vzj * vzj;
+                const double vivj = vxi * vxj + vyi * vyj + vzi * vzj;
+                const double dvj = dx * vxj + dy * vyj + dz * vzj;
+                const double dvi = dx * vxi + dy * vyi + dz * vzi;
+                const double f1 = p4 + tj[7][jj] - vi2 - 2. * vj2 + 4. * vivj + 1.5 * dvj * dvj * ri2;
+                const double f2 = 4. * dvi - 3. * dvj;
+                s0 += g3 * (f1 * dx + f2 * (vxi - vxj));
+                s1 += g3 * (f1 * dy + f2 * (vyi - vyj));
+                s2 += g3 * (f1 * dz + f2 * (vzi - vzj));
+            } else {
+                const double tx = tj[4][jj], ty = tj[5][jj], tz = tj[6][jj];
+                const double g1 = gm * ri;
+                const double h = 0.5 * (ri * ri) * (dx * tx + dy * ty + dz * tz);
+                s0 += g1 * (h * dx + 3.5 * tx);
+                s1 += g1 * (h * dy + 3.5 * ty);
+                s2 += g1 * (h * dz + 3.5 * tz);
+            }
+        }
+    }
+    if (live) {
+        if (PASS == PASS_POT) {
+            a.part[(long long)blockIdx.y * nrows + r] = s0 * a.invC2;
+        } else {
+            double* q = a.part + ((long long)blockIdx.y * nrows + r) * 3;
+            q[0] = s0 * a.invC2; q[1] = s1 * a.invC2; q[2] = s2 * a.invC2;
+        }
+    }
+}
+
+// combine the j-chunk partial sums (fixed order); sweep: add a_const and test the stopping rule
+template <int PASS>
+__global__ __launch_bounds__(256) void grfull_combine_kernel(const double* part, int nchunks, long long row0, long long row1,
+                                                             const double* acx, const double* acy, const double* acz,
+                                                             const double* aox, const double* aoy, const double* aoz,
+                                                             double* o0, double* o1, double* o2, unsigned* flag) {
+    const long long nrows = row1 - row0;
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    bool unconverged = false;
+    if (r < nrows) {
+        const long long i = row0 + r;
+        if (PASS == PASS_POT) {
+            double s = 0.;
+            for (int c = 0; c < nchunks; c++) s += part[(long long)c * nrows + r];
+            o0[i] = s;
+        } else {
+            double s0 = 0., s1 = 0., s2 = 0.;
+            for (int c = 0; c < nchunks; c++) {
+                const double* q = part + ((long long)c * nrows + r) * 3;
+                s0 += q[0]; s1 += q[1]; s2 += q[2];
+            }
+            if (PASS == PASS_SWEEP) {
+                s0 += acx[i]; s1 += acy[i]; s2 += acz[i];
+                // reference gr_full.c:206-220: signed ratio, NaN never counts, threshold 1e-30
+                const double d0 = (fabs(s0) < 1.e-30) ? 0. : fabs(s0 - aox[i]) / s0;
+                const double d1 = (fabs(s1) < 1.e-30) ? 0. : fabs(s1 - aoy[i]) / s1;
+                const double d2 = (fabs(s2) < 1.e-30) ? 0. : fabs(s2 - aoz[i]) / s2;
+                unconverged = (d0 >= 1.e-30) || (d1 >= 1.e-30) || (d2 >= 1.e-30);
+            }
+            o0[i] = s0; o1[i] = s1; o2[i] = s2;
+        }
+    }
+    if (PASS == PASS_SWEEP) {
+        const unsigned long long any = __ballot(unconverged);      // one vote per wavefront
+        if (any != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+    }
+}
+
+// ------------------------------------------------------------------ exact passes (sequential j)
+template <int PASS>
+__global__ __launch_bounds__(GB) void grfull_exact_kernel(GrFullArgs a, const double* acx, const double* acy, const double* acz,
+                                                          double* o0, double* o1, double* o2, unsigned* flag) {
+#pragma clang fp contract(off)
+    const long long r = (long long)blockIdx.x * GB + threadIdx.x;
+    const long long i = a.row0 + r;
+    bool unconverged = false;
+    if (i < a.row1) {
+        const double G = a.G, C2 = a.C2;
+        const double xi = a.x[i], yi = a.y[i], zi = a.z[i];
+        if (PASS == PASS_POT) {
+            double s2 = 0.;
+            for (long long k = 0; k < a.n; k++) {
+                if (k == i) continue;
+                const double dx = xi - a.x[k], dy = yi - a.y[k], dz = zi - a.z[k];
+                const double rr = sqrt(dx * dx + dy * dy + dz * dz);
+                s2 += (1. / (C2)) * G * a.m[k] / rr;
+            }
+            o0[i] = s2;
+        } else if (PASS == PASS_CONST) {
+            const double vxi = a.vx[i], vyi = a.vy[i], vzi = a.vz[i];
+            const double vi2 = vxi * vxi + vyi * vyi + vzi * vzi;
+            const double a1 = 4. * a.pot[i];        // exactly the reference's own 4/c^2 sum (power-of-two scaling)
+            double cx = 0., cy = 0., cz = 0.;
+            for (long long j = 0; j < a.n; j++) {
+                if (j == i) continue;
+                const double dx = xi - a.x[j], dy = yi - a.y[j], dz = zi - a.z[j];
+                const double rr = sqrt(dx * dx + dy * dy + dz * dz);
+                const double rij2 = rr * rr;
+                const double rij3 = rij2 * rr;
+                const double vxj = a.vx[j], vyj = a.vy[j], vzj = a.vz[j], mj = a.m[j];
+                const double a3 = -vi2 / (C2);
+                const double vj2 = vxj * vxj + vyj * vyj + vzj * vzj;
+                const double a4 = -2. * vj2 / (C2);
+                const double a5 = (4. / (C2)) * (vxi * vxj + vyi * vyj + vzi * vzj);
+                const double a6_0 = dx * vxj + dy * vyj + dz * vzj;
+                const double a6 = (3. / (2. * C2)) * a6_0 * a6_0 / rij2;
+                const double factor1 = a1 + a.pot[j] + a3 + a4 + a5 + a6;
+                cx += G * mj * dx * factor1 / rij3;
+                cy += G * mj * dy * factor1 / rij3;
+                cz += G * mj * dz * factor1 / rij3;
+                const double dvx = vxi - vxj, dvy = vyi - vyj, dvz = vzi - vzj;
+                const double factor2 = dx * (4. * vxi - 3. * vxj) + dy * (4. * vyi - 3. * vyj) + dz * (4. * vzi - 3. * vzj);
+                cx += G * mj * factor2 * dvx / rij3 / (C2);
+                cy += G * mj * factor2 * dvy / rij3 / (C2);
+                cz += G * mj * factor2 * dvz / rij3 / (C2);
+            }
+            o0[i] = cx; o1[i] = cy; o2[i] = cz;
+        } else {
+            double nx = 0., ny = 0., nz = 0.;
+            for (long long j = 0; j < a.n; j++) {
+                if (j == i) continue;
+                const double dx = xi - a.x[j], dy = yi - a.y[j], dz = zi - a.z[j];
+                const double rr = sqrt(dx * dx + dy * dy + dz * dz);
+                const double rij3 = rr * rr * rr;
+                const double mj = a.m[j];
+                const double tx = a.anx[j] + a.aox[j], ty = a.any_[j] + a.aoy[j], tz = a.anz[j] + a.aoz[j];
+                nx += (G * mj * dx / rij3) * (dx * tx + dy * ty + dz * tz) / (2. * C2) + (7. / (2. * C2)) * G * mj * tx / rr;
+                ny += (G * mj * dy / rij3) * (dx * tx + dy * ty + dz * tz) / (2. * C2) + (7. / (2. * C2)) * G * mj * ty / rr;
+                nz += (G * mj * dz / rij3) * (dx * tx + dy * ty + dz * tz) / (2. * C2) + (7. / (2. * C2)) * G * mj * tz / rr;
+            }
+            const double s0 = acx[i] + nx, s1 = acy[i] + ny, s2 = acz[i] + nz;
+            const double d0 = (fabs(s0) < 1.e-30) ? 0. : fabs(s0 - a.aox[i]) / s0;
+            const double d1 = (fabs(s1) < 1.e-30) ? 0. : fabs(s1 - a.aoy[i]) / s1;
+            const double d2 = (fabs(s2) < 1.e-30) ? 0. : fabs(s2 - a.aoz[i]) / s2;
+            unconverged = (d0 >= 1.e-30) || (d1 >= 1.e-30) || (d2 >= 1.e-30);
+            o0[i] = s0; o1[i] = s1; o2[i] = s2;
+        }
+    }
+    if (PASS == PASS_SWEEP) {
+        const unsigned long long any = __ballot(unconverged);
+        if (any != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+    }
+}
+
+// a_newton = incoming acceleration (+ the 0-1 pair when REBOUND's gravity left it out,
+// reference gr_full.c:92-102); a_old = 0
+__global__ __launch_bounds__(256) void grfull_prepare_kernel(View v, double G, int ignore10, double* anx, double* any_, double* anz,
+                                                             double* a0x, double* a0y, double* a0z) {
+#pragma clang fp contract(off)
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < v.n; i += (long long)gridDim.x * 256) {
+        double ax = v.ax[i], ay = v.ay[i], az = v.az[i];
+        if (ignore10 && i < 2 && v.n > 1) {
+            const double dx = v.x[0] - v.x[1], dy = v.y[0] - v.y[1], dz = v.z[0] - v.z[1];
+            const double rr = sqrt(dx * dx + dy * dy + dz * dz);
+            const double prefact = -G / (rr * rr * rr);
+            if (i == 0) { const double p1 = prefact * v.m[1]; ax += p1 * dx; ay += p1 * dy; az += p1 * dz; }
+            else        { const double p0 = prefact * v.m[0]; ax -= p0 * dx; ay -= p0 * dy; az -= p0 * dz; }
+        }
+        anx[i] = ax; any_[i] = ay; anz[i] = az;
+        a0x[i] = 0.; a0y[i] = 0.; a0z[i] = 0.;
+    }
+}
+
+__global__ __launch_bounds__(256) void grfull_finish_kernel(View v, const double* ax, const double* ay, const double* az) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < v.n; i += (long long)gridDim.x * 256) {
+        v.ax[i] += ax[i]; v.ay[i] += ay[i]; v.az[i] += az[i];
+    }
+}
+
+// ------------------------------------------------------------------ launchers
+// scratch for the j-chunk partials is owned by device_api.hip and handed in through `part`
+struct GrFullPlan { int rowblocks; int nchunks; long long jchunk; };
+
+static GrFullPlan plan(long long n, long long nrows) {
+    GrFullPlan p;
+    p.rowblocks = (int)((nrows + GB - 1) / GB);
+    long long want = (2048 + p.rowblocks - 1) / p.rowblocks;     // aim at >= 2048 workgroups (8 per CU)
+    const long long tiles = (n + GB - 1) / GB;
+    if (want > tiles) want = tiles;
+    if (want > 64) want = 64;
+    if (want < 1) want = 1;
+    const long long tiles_per_chunk = (tiles + want - 1) / want;
+    p.jchunk = tiles_per_chunk * GB;
+    p.nchunks = (int)((n + p.jchunk - 1) / p.jchunk);
+    return p;
+}
+
+size_t grfull_partial_bytes(long long n, long long nrows) {
+    const GrFullPlan p = plan(n, nrows);
+    return (size_t)p.nchunks * (size_t)nrows * 3 * sizeof(double);
+}
+
+static GrFullArgs base_args(const View& v, double G, double c, long long row0, long long row1) {
+    GrFullArgs a;
+    a.n = v.n; a.row0 = row0; a.row1 = row1; a.jchunk = v.n;
+    a.G = G; a.C2 = c * c; a.invC2 = 1. / (c * c);
+    a.x = v.x; a.y = v.y; a.z = v.z; a.vx = v.vx; a.vy = v.vy; a.vz = v.vz; a.m = v.m;
+    a.pot = nullptr; a.anx = a.any_ = a.anz = a.aox = a.aoy = a.aoz = nullptr; a.part = nullptr;
+    return a;
+}
+
+hipError_t launch_grfull_pass(int pass, const View& v, double G, double c, long long row0, long long row1, const double* pot,
+                              const double* anx, const double* any_, const double* anz,
+                              const double* aox, const double* aoy, const double* aoz,
+                              const double* acx, const double* acy, const double* acz,
+                              double* o0, double* o1, double* o2, unsigned* flag, double* part, bool exact, hipStream_t st) {
+    const long long nrows = row1 - row0;
+    if (nrows <= 0) return hipSuccess;
+    GrFullArgs a = base_args(v, G, c, row0, row1);
+    a.pot = pot; a.anx = anx; a.any_ = any_; a.anz = anz; a.aox = aox; a.aoy = aoy; a.aoz = aoz;
+    if (exact) {
+        const dim3 g((unsigned)((nrows + GB - 1) / GB)), b(GB);
+        if (pass == PASS_POT) hipLaunchKernelGGL(grfull_exact_kernel<PASS_POT>, g, b, 0, st, a, acx, acy, acz, o0, o1, o2, flag);
+        else if (pass == PASS_CONST) hipLaunchKernelGGL(grfull_exact_kernel<PASS_CONST>, g, b, 0, st, a, acx, acy, acz, o0, o1, o2, flag);
+        else hipLaunchKernelGGL(grfull_exact_kernel<PASS_SWEEP>, g, b, 0, st, a, acx, acy, acz, o0, o1, o2, flag);
+        return hipGetLastError();
+    }
+    const GrFullPlan p = plan(v.n, nrows);
+    a.jchunk = p.jchunk; a.part = part;
+    const dim3 g((unsigned)p.rowblocks, (unsigned)p.nchunks), b(GB);
+    const dim3 g2((unsigned)((nrows + 255) / 256)), b2(256);
+    if (pass == PASS_POT) {
+        hipLaunchKernelGGL(grfull_fast_kernel<PASS_POT>, g, b, 0, st, a);
+        hipLaunchKernelGGL(grfull_combine_kernel<PASS_POT>, g2, b2, 0, st, part, p.nchunks, row0, row1, acx, acy, acz, aox, aoy, aoz, o0, o1, o2, flag);
+    } else if (pass == PASS_CONST) {
+        hipLaunchKernelGGL(grfull_fast_kernel<PASS_CONST>, g, b, 0, st, a);
+        hipLaunchKernelGGL(grfull_combine_kernel<PASS_CONST>, g2, b2, 0, st, part, p.nchunks, row0, row1, acx, acy, acz, aox, aoy, aoz, o0, o1, o2, flag);
+    } else {
+        hipLaunchKernelGGL(grfull_fast_kernel<PASS_SWEEP>, g, b, 0, st, a);
+        hipLaunchKernelGGL(grfull_combine_kernel<PASS_SWEEP>, g2, b2, 0, st, part, p.nchunks, row0, row1, acx, acy, acz, aox, aoy, aoz, o0, o1, o2, flag);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_grfull_prepare(const View& v, double G, int gravity_ignore_10, double* anx, double* any_, double* anz,
+                                 double* a0x, double* a0y, double* a0z, hipStream_t st) {
+    if (v.n <= 0) return hipSuccess;
+    long long nb = (v.n + 255) / 256; if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(grfull_prepare_kernel, dim3((unsigned)nb), dim3(256), 0, st, v, G, gravity_ignore_10, anx, any_, anz, a0x, a0y, a0z);
+    return hipGetLastError();
+}
+
+hipError_t launch_grfull_finish(const View& v, const double* ax, const double* ay, const double* az, hipStream_t st) {
+    if (v.n <= 0) return hipSuccess;
+    long long nb = (v.n + 255) / 256; if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(grfull_finish_kernel, dim3((unsigned)nb), dim3(256), 0, st, v, ax, ay, az);
+    return hipGetLastError();
+}
+
+}  // namespace rebxamd

@@ -1,0 +1,75 @@
+// internal.h -- structures shared by the host side of the device API and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/reboundx_amd.h"
+
+namespace rebxamd {
+
+// One elementary pass, with everything that does not depend on the particle precomputed
+// on the host (in the same fp64 arithmetic the reference uses for these scalars).
+struct DevOp {
+    int kind;       // rebxamd_op_kind; REBXAMD_OP_MOF is refined by `iarg` (coordinates)
+    int src;        // source / reference particle index (-1: none)
+    int iarg;       // max_iterations (gr) or coordinates (mof)
+    int slot;       // index of this op's back-reaction partial sums, -1 if it has none
+    double a, b;    // as in rebxamd_op
+    double c, d;    // derived: radiation 1/c; gr c^2, 1/c^2; gr_potential 6(G m0)^2/c^2 is formed on device
+};
+
+struct Program {
+    int nops;
+    int nslots;
+    int need_vel, need_beta, need_tides, need_tau;
+    int gr_op;          // index of the (single) gr op in this run, or -1
+    int mofcom_op;      // index of the (single) Jacobi/barycentric mof op, or -1
+    double G;
+    DevOp ops[REBXAMD_MAX_OPS];
+};
+
+// Plain copy of rebxamd_view for kernels.
+struct View {
+    long long n;
+    long long n_head;
+    const double *x, *y, *z, *vx, *vy, *vz, *m;
+    double *ax, *ay, *az;
+    const double *beta, *Rt, *k1, *ta, *te, *ti;
+};
+
+// What the head pass hands to the tail pass (lives in device memory).
+struct HeadConsts {
+    // gr: interior centre of mass seen by every body behind the head, i.e. (sum m*q) * (1/sum m)
+    // for q in {pos, vel, Newtonian acc}, plus mu = G*m0.
+    double gr_c[9];
+    double gr_mu;
+    // modify_orbits_forces in Jacobi/barycentric coordinates: centre of mass of the head
+    double com[7];          // x y z vx vy vz m
+    int nbary;              // barycentric: number of head back-reaction terms that follow
+    int pad;
+    double bary[REBXAMD_MAX_HEAD][3];   // massratio_i * a_i for i = nbary-1 .. 0 (application order)
+};
+
+enum { WARN_GR_ITER = 1u, WARN_GRFULL_SWEEPS = 2u };
+
+// launchers implemented in stream_kernels.hip
+hipError_t launch_head(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, bool exact, hipStream_t st);
+hipError_t launch_stream(const View& v, const Program& prog, long long lo, const HeadConsts* hc, double* partials,
+                         int* nblocks_out, bool backreact, bool exact, bool vec2, unsigned* status, hipStream_t st);
+hipError_t launch_finalize(const View& v, const Program& prog, const double* partials, int nblocks, hipStream_t st);
+hipError_t launch_last_massive(const double* m, long long n, long long* out_dev, hipStream_t st);
+hipError_t launch_reset(const View& v, hipStream_t st);
+int stream_block_count(long long lo, long long n, bool vec2);
+
+// gr_full launchers implemented in grfull_kernels.hip
+// pass: 0 = potential sums, 1 = acceleration-independent part, 2 = one substitution sweep
+size_t grfull_partial_bytes(long long n, long long nrows);
+hipError_t launch_grfull_pass(int pass, const View& v, double G, double c, long long row0, long long row1, const double* pot,
+                              const double* anx, const double* any_, const double* anz,
+                              const double* aox, const double* aoy, const double* aoz,
+                              const double* acx, const double* acy, const double* acz,
+                              double* o0, double* o1, double* o2, unsigned* flag, double* part, bool exact, hipStream_t st);
+hipError_t launch_grfull_prepare(const View& v, double G, int gravity_ignore_10, double* anx, double* any_, double* anz,
+                                 double* a0x, double* a0y, double* a0z, hipStream_t st);
+hipError_t launch_grfull_finish(const View& v, const double* ax, const double* ay, const double* az, hipStream_t st);
+
+}  // namespace rebxamd

@@ -1,0 +1,138 @@
+"""Device-resident particles and the thin wrapper over the device C ABI.
+
+PyTorch is used only for HBM allocations and streams; every computation goes through
+``librebxamd.so``.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Op, View, lib
+from .program import build_ops
+
+DYN = ("x", "y", "z", "vx", "vy", "vz", "m", "ax", "ay", "az")
+PARAM_COLS = ("beta", "R_tides", "k1", "tau_a", "tau_e", "tau_inc")
+
+
+class RebxAmdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("librebxamd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Context:
+    """One per process and GPU (struct rebxamd_ctx)."""
+
+    def __init__(self, device=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("reboundx_amd.device needs a GPU; there is no CPU fallback")
+        self.device = int(device)
+        h = ctypes.c_void_p()
+        rc = lib.rebxamd_create(self.device, ctypes.byref(h))
+        if rc != _lib.OK:
+            raise RebxAmdError(rc, "rebxamd_create failed")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.rebxamd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != _lib.OK:
+            raise RebxAmdError(rc, lib.rebxamd_last_error(self._h).decode())
+
+    @staticmethod
+    def _stream():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def classify(self, m):
+        out = ctypes.c_int64(0)
+        self._check(lib.rebxamd_classify(self._h, ctypes.c_void_p(m.data_ptr()), m.numel(), ctypes.byref(out), self._stream()))
+        return out.value
+
+    def apply(self, view, ops, mode=_lib.MODE_FAST):
+        arr = (Op * max(len(ops), 1))(*ops)
+        self._check(lib.rebxamd_apply(self._h, ctypes.byref(view), arr, len(ops), mode, self._stream()))
+
+    def reset_accelerations(self, view):
+        self._check(lib.rebxamd_reset_accelerations(self._h, ctypes.byref(view), self._stream()))
+
+    def fetch_warnings(self):
+        bits = ctypes.c_uint32(0)
+        self._check(lib.rebxamd_fetch_warnings(self._h, ctypes.byref(bits), self._stream()))
+        return bits.value
+
+    def grfull(self, view, c, gravity_ignore_10=0, mode=_lib.MODE_FAST):
+        sweeps = ctypes.c_int(0)
+        self._check(lib.rebxamd_grfull(self._h, ctypes.byref(view), c, gravity_ignore_10, mode, ctypes.byref(sweeps), self._stream()))
+        return sweeps.value
+
+    def grfull_pot(self, view, c, row0, row1, pot, mode=_lib.MODE_FAST):
+        self._check(lib.rebxamd_grfull_pot(self._h, ctypes.byref(view), c, row0, row1, pot.data_ptr(), mode, self._stream()))
+
+    def grfull_const(self, view, c, row0, row1, pot, ac, mode=_lib.MODE_FAST):
+        self._check(lib.rebxamd_grfull_const(self._h, ctypes.byref(view), c, row0, row1, pot.data_ptr(),
+                                             ac[0].data_ptr(), ac[1].data_ptr(), ac[2].data_ptr(), mode, self._stream()))
+
+    def grfull_sweep(self, view, c, row0, row1, an, ao, ac, out, flag, mode=_lib.MODE_FAST):
+        ptrs = [t.data_ptr() for t in (an[0], an[1], an[2], ao[0], ao[1], ao[2], ac[0], ac[1], ac[2], out[0], out[1], out[2])]
+        self._check(lib.rebxamd_grfull_sweep(self._h, ctypes.byref(view), c, row0, row1, *ptrs, flag.data_ptr(), mode, self._stream()))
+
+
+class DeviceParticles:
+    """fp64 columns in HBM.  ``cols`` maps names to 1-D float64 tensors on one GPU;
+    parameter columns use NaN for 'not set' and may be absent."""
+
+    def __init__(self, cols, G=1.0, n_head=None, tail_massless=False):
+        self.cols = cols
+        self.G = float(G)
+        self.n = int(cols["x"].numel())
+        self.n_head = self.n if n_head is None else int(n_head)
+        self.tail_massless = bool(tail_massless)
+        for k, t in cols.items():
+            assert t.dtype == torch.float64 and t.is_contiguous() and t.numel() == self.n, k
+
+    @classmethod
+    def from_host(cls, host, device="cuda:0", G=1.0, n_head=None, tail_massless=None):
+        """host: dict of numpy columns (dynamic + any of PARAM_COLS)."""
+        cols = {}
+        for k in DYN + PARAM_COLS:
+            if k in host and host[k] is not None:
+                cols[k] = torch.from_numpy(np.ascontiguousarray(host[k], dtype=np.float64)).to(device)
+        m = np.asarray(host["m"])
+        if n_head is None:
+            nz = np.nonzero(m != 0.0)[0]
+            n_head = int(nz[-1]) + 1 if len(nz) else 1
+        if tail_massless is None:
+            tail_massless = bool(np.all(m[n_head:] == 0.0))
+        return cls(cols, G=G, n_head=n_head, tail_massless=tail_massless)
+
+    def view(self):
+        v = View()
+        v.n = self.n
+        v.n_head = self.n_head
+        v.tail_massless = 1 if self.tail_massless else 0
+        v.G = self.G
+        for k in DYN + PARAM_COLS:
+            t = self.cols.get(k)
+            setattr(v, k, t.data_ptr() if t is not None else None)
+        return v
+
+    def acc_host(self):
+        return tuple(self.cols[k].cpu().numpy() for k in ("ax", "ay", "az"))
+
+
+def apply_forces(ctx, dp, forces, pp_host, mode=_lib.MODE_FAST, gravity_ignore_terms=0):
+    """Runs a stack of reference forces (execution order) on device-resident particles."""
+    ops = build_ops(forces, pp_host, gravity_ignore_terms)
+    ctx.apply(dp.view(), ops, mode)
+    return ops

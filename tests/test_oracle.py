@@ -1,0 +1,272 @@
+"""Pins the CPU checker (oracle/) to what the reference itself records, and checks its
+internal consistency.  Runs without a GPU.
+
+What pins it:
+  * the pure-function answer stored in the reference notebook
+    ipython_examples/Radiation_Forces_Circumplanetary_Dust.ipynb (cell 11);
+  * the pericentre angles stored in ipython_examples/GeneralRelativity.ipynb (cell 9) and
+    ipython_examples/J2.ipynb (cell 6), reproduced by integrating Newtonian gravity plus the
+    checker's force with an 8th-order Runge-Kutta scheme (the notebooks used REBOUND's IAS15;
+    both integrate to ~1e-12, so the stored digits are reproduced to ~1e-9);
+  * force = -grad(potential) for every effect whose potential the reference's
+    test_conservation.py relies on (reboundx/test/test_conservation.py:38-96).
+"""
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+from reboundx_amd import synthetic
+
+
+def rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-300)
+
+
+def test_rad_calc_beta_notebook_value():
+    # Radiation_Forces_Circumplanetary_Dust.ipynb cell 11 output: 0.05767021830984005
+    beta = oracle.lib.orc_rad_calc_beta(6.674e-11, 3.e8, 1.99e30, 3.85e26, 1.e-5, 1000., 1.)
+    assert beta == pytest.approx(0.05767021830984005, rel=1e-15)
+    radius = oracle.lib.orc_rad_calc_particle_radius(6.674e-11, 3.e8, 1.99e30, 3.85e26, beta, 1000., 1.)
+    assert radius == pytest.approx(1.e-5, rel=1e-14)
+
+
+def random_system(n, seed, massless_from=None):
+    rng = np.random.default_rng(seed)
+    cols = {k: rng.normal(size=n) for k in ("x", "y", "z")}
+    cols.update({k: 0.3 * rng.normal(size=n) for k in ("vx", "vy", "vz")})
+    cols["m"] = 10.0 ** rng.uniform(-6, 0, size=n)
+    if massless_from is not None:
+        cols["m"][massless_from:] = 0.0
+    cols.update({k: 0.1 * rng.normal(size=n) for k in ("ax", "ay", "az")})
+    return cols
+
+
+@pytest.mark.parametrize("n,massless_from", [(2, None), (7, None), (40, 5), (33, 1)])
+def test_gr_massive_partner_loop_is_bitwise_the_pair_loop(n, massless_from):
+    cols = random_system(n, 11 + n, massless_from)
+    if massless_from is not None and n > 20:
+        cols["m"][10] = 0.0 if massless_from > 10 else cols["m"][10]
+    a = oracle.Sim(cols)
+    b = oracle.Sim(cols)
+    oracle.gr(a, 50.0)
+    oracle.gr(b, 50.0, literal=True)
+    for u, v in zip(a.acc, b.acc):
+        assert np.array_equal(u, v)
+
+
+def _numgrad(fun, cols, G, h=1e-6):
+    """-dH/dq / m for every particle and axis by central differences."""
+    n = len(cols["x"])
+    out = np.zeros((3, n))
+    for ax_i, key in enumerate(("x", "y", "z")):
+        for i in range(n):
+            c = {k: v.copy() for k, v in cols.items()}
+            c[key][i] += h
+            hp = fun(oracle.Sim(c, G))
+            c[key][i] -= 2 * h
+            hm = fun(oracle.Sim(c, G))
+            out[ax_i, i] = -(hp - hm) / (2 * h) / cols["m"][i]
+    return out
+
+
+def _force(fun, cols, G):
+    c = {k: v.copy() for k, v in cols.items()}
+    for k in ("ax", "ay", "az"):
+        c[k] = np.zeros_like(c[k])
+    s = oracle.Sim(c, G)
+    fun(s)
+    return np.array(s.acc)
+
+
+def _check_gradient(force_fun, pot_fun, cols, G=1.0, tol=2e-8):
+    f = _force(force_fun, cols, G)
+    g = _numgrad(pot_fun, cols, G)
+    scale = np.abs(f).max()
+    assert scale > 0
+    assert np.abs(f - g).max() <= tol * scale
+
+
+def _planetary(seed=5, n=4):
+    rng = np.random.default_rng(seed)
+    cols = {k: np.zeros(n) for k in ("x", "y", "z", "vx", "vy", "vz", "ax", "ay", "az")}
+    cols["m"] = np.array([1.0] + [10 ** rng.uniform(-5, -3) for _ in range(n - 1)])
+    for i in range(1, n):
+        cols["x"][i], cols["y"][i], cols["z"][i] = rng.normal(size=3) * (0.5 + i)
+        cols["vx"][i], cols["vy"][i], cols["vz"][i] = rng.normal(size=3) * 0.5
+    cols["x"][0], cols["y"][0], cols["z"][0] = 0.01, -0.02, 0.005
+    return cols
+
+
+def test_gravitational_harmonics_is_gradient_of_its_potential():
+    cols = _planetary()
+    n = len(cols["m"])
+    nan = np.full(n, np.nan)
+    J2, J4, Req = nan.copy(), nan.copy(), nan.copy()
+    J2[0], J4[0], Req[0] = 1e-3, 2e-3, 0.1
+    J2[2], Req[2] = 5e-2, 0.05          # second oblate body, J2 only
+    _check_gradient(lambda s: oracle.gravitational_harmonics(s, J2, J4, Req),
+                    lambda s: oracle.harmonics_potential(s, J2, J4, Req), cols, G=0.7)
+
+
+@pytest.mark.parametrize("gamma", [-1.0, -3.0, 0.5])
+def test_central_force_is_gradient_of_its_potential(gamma):
+    cols = _planetary()
+    n = len(cols["m"])
+    A, g = np.full(n, np.nan), np.full(n, np.nan)
+    A[0], g[0] = 1e-4, gamma
+    _check_gradient(lambda s: oracle.central_force(s, A, g), lambda s: oracle.central_force_potential(s, A, g), cols)
+
+
+def test_tides_precession_is_gradient_of_its_potential():
+    cols = _planetary()
+    n = len(cols["m"])
+    R, k1 = np.full(n, np.nan), np.full(n, np.nan)
+    R[0], k1[0] = 1e-1, 0.4
+    R[1], k1[1] = 2e-2, 0.3
+    _check_gradient(lambda s: oracle.tides_precession(s, R, k1, None), lambda s: oracle.tides_potential(s, R, k1, None), cols, G=1.3)
+
+
+def test_gr_potential_is_gradient_of_its_potential():
+    cols = _planetary()
+    _check_gradient(lambda s: oracle.gr_potential(s, 30.0), lambda s: oracle.gr_potential_potential(s, 30.0), cols)
+
+
+def test_tides_skip_massless_and_source_selection():
+    cols = _planetary(n=5)
+    cols["m"][3] = 0.0
+    n = 5
+    R, k1 = np.full(n, np.nan), np.full(n, np.nan)
+    R[0], k1[0] = 1e-1, 0.4
+    f = _force(lambda s: oracle.tides_precession(s, R, k1, None), cols, 1.0)
+    assert np.all(f[:, 3] == 0.0)                   # massless bodies feel nothing (tides_precession.c:84-87)
+    prim = np.zeros(n, dtype=np.uint8)
+    prim[0] = 1
+    f2 = _force(lambda s: oracle.tides_precession(s, R, k1, prim), cols, 1.0)
+    assert np.array_equal(f, f2)                    # no flag anywhere == flag on index 0
+
+
+def test_back_reactions_conserve_momentum():
+    cols = _planetary(n=6)
+    n = 6
+    m = cols["m"]
+    nan = np.full(n, np.nan)
+    J2, J4, Req = nan.copy(), nan.copy(), nan.copy()
+    J2[0], J4[0], Req[0] = 1e-3, 1e-3, 0.1
+    for fun in (lambda s: oracle.gravitational_harmonics(s, J2, J4, Req),
+                lambda s: oracle.gr_potential(s, 30.0),
+                lambda s: oracle.modify_orbits_forces(s, 2, np.full(n, -1e3), np.full(n, -1e2), None, np.eye(1, n, 0)[0]),
+                lambda s: oracle.modify_orbits_forces(s, 0, np.full(n, -1e3), np.full(n, -1e2), nan, None),
+                lambda s: oracle.modify_orbits_forces(s, 1, np.full(n, -1e3), np.full(n, -1e2), nan, None)):
+        f = _force(fun, cols, 1.0)
+        p = (f * m).sum(axis=1)
+        assert np.abs(p).max() <= 1e-13 * np.abs(f * m).max()
+
+
+def test_modify_orbits_forces_missing_primary_is_an_error():
+    s = oracle.Sim(_planetary())
+    assert oracle.modify_orbits_forces(s, 2, None, None, None, None) == -1
+
+
+def test_unset_parameters_mean_no_force():
+    cols = _planetary()
+    z = _force(lambda s: oracle.radiation_forces(s, 100.0, None, None), cols, 1.0)
+    assert np.all(z == 0.0)
+    z = _force(lambda s: oracle.gravitational_harmonics(s, None, None, None), cols, 1.0)
+    assert np.all(z == 0.0)
+    z = _force(lambda s: oracle.modify_orbits_forces(s, 0, None, None, None, None), cols, 1.0)
+    assert np.all(z == 0.0)
+
+
+def test_gr_full_two_body_matches_gr_to_post_newtonian_order():
+    """Different formulations of the same 1PN physics: for a test-mass-like planet the single
+    dominant-mass force (gr) and the full EIH force (gr_full) agree to O(m2/m1) and O(v^4/c^4)."""
+    cols = synthetic.twoplanets()
+    cols = {k: v[:2].copy() for k, v in cols.items()}
+    cols["m"][1] = 1e-9
+    c = 1.0e2
+    a = oracle.Sim(cols)
+    oracle.newtonian_gravity(a)
+    newt = np.array([q.copy() for q in a.acc])
+    sweeps = oracle.gr_full(a, c)
+    assert 1 <= sweeps <= 10
+    full = np.array(a.acc) - newt
+    b = oracle.Sim(cols)
+    oracle.gr(b, c)
+    single = np.array(b.acc)
+    assert np.abs(full[:, 1] - single[:, 1]).max() <= 2e-3 * np.abs(single[:, 1]).max()
+
+
+# --------------------------------------------------------------------- notebook known answers
+
+def _pomega(cols):
+    mu = cols["m"][0] + cols["m"][1]
+    r = np.array([cols[k][1] - cols[k][0] for k in ("x", "y", "z")])
+    v = np.array([cols[k][1] - cols[k][0] for k in ("vx", "vy", "vz")])
+    rn = np.linalg.norm(r)
+    e = ((v @ v - mu / rn) * r - (r @ v) * v) / mu
+    return math.atan2(e[1], e[0])
+
+
+def _integrate(cols, t0, t1, force_fun, rtol=1e-13):
+    from scipy.integrate import solve_ivp
+    n = len(cols["m"])
+    work = {k: np.array(v, dtype=np.float64) for k, v in cols.items()}
+    sim = oracle.Sim(work)
+
+    def rhs(t, y):
+        q = y.reshape(6, n)
+        for k, row in zip(("x", "y", "z", "vx", "vy", "vz"), q):
+            sim.cols[k][:] = row
+        for k in ("ax", "ay", "az"):
+            sim.cols[k][:] = 0.0
+        oracle.newtonian_gravity(sim)
+        if force_fun is not None:
+            force_fun(sim)
+        return np.concatenate([q[3], q[4], q[5], sim.cols["ax"], sim.cols["ay"], sim.cols["az"]])
+
+    y0 = np.concatenate([work[k] for k in ("x", "y", "z", "vx", "vy", "vz")])
+    sol = solve_ivp(rhs, (t0, t1), y0, method="DOP853", rtol=rtol, atol=1e-18)
+    assert sol.success
+    q = sol.y[:, -1].reshape(6, n)
+    out = {k: row.copy() for k, row in zip(("x", "y", "z", "vx", "vy", "vz"), q)}
+    out["m"] = work["m"].copy()
+    for k in ("ax", "ay", "az"):
+        out[k] = np.zeros(n)
+    return out
+
+
+def _two_body(m1, a, e):
+    m = np.array([1.0, m1])
+    x, y, z, vx, vy, vz = synthetic.kepler_to_cartesian(1.0 + m1, a, e, 0.0, 0.0, 0.0, 0.0)
+    cols = {"x": np.array([0.0, x]), "y": np.array([0.0, y]), "z": np.array([0.0, z]),
+            "vx": np.array([0.0, vx]), "vy": np.array([0.0, vy]), "vz": np.array([0.0, vz]), "m": m}
+    for k in ("x", "y", "z", "vx", "vy", "vz"):
+        cols[k] = cols[k] - (m * cols[k]).sum() / m.sum()
+    for k in ("ax", "ay", "az"):
+        cols[k] = np.zeros(2)
+    return cols
+
+
+def test_gr_reproduces_notebook_pericentre_advance():
+    # GeneralRelativity.ipynb: 10 time units of plain gravity, then 100 with gr, c = constants.C.
+    cols = _two_body(1.66013e-07, 0.387098, 0.205630)
+    cols = _integrate(cols, 0.0, 10.0, None)
+    assert abs(_pomega(cols)) < 1e-10
+    cols = _integrate(cols, 10.0, 110.0, lambda s: oracle.gr(s, synthetic.C_DEFAULT))
+    # stored cell output: "pomega = 0.0000332591781488"
+    assert _pomega(cols) == pytest.approx(0.0000332591781488, abs=2e-9)
+
+
+@pytest.mark.slow
+def test_harmonics_reproduce_notebook_pericentre_advance():
+    # J2.ipynb: star J2=0.1, J4=0.2, R_eq=1/200; planet m=1e-5, a=1, e=0.01; t = 1 .. 1e4
+    cols = _two_body(1.e-5, 1.0, 1.e-2)
+    cols = _integrate(cols, 0.0, 1.0, None)
+    nan = np.array([np.nan, np.nan])
+    J2, J4, Req = nan.copy(), nan.copy(), nan.copy()
+    J2[0], J4[0], Req[0] = 0.1, 0.2, 1 / 200.
+    cols = _integrate(cols, 1.0, 1.e4, lambda s: oracle.gravitational_harmonics(s, J2, J4, Req), rtol=1e-12)
+    # stored cell output: "pomega = 0.037037080331452"
+    assert _pomega(cols) == pytest.approx(0.037037080331452, abs=2e-7)
