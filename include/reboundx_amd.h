@@ -261,6 +261,13 @@ int rebxamd_reset_accelerations(rebxamd_ctx* ctx, const rebxamd_view* view, void
  *  2 = gr_full ran all 10 sweeps without meeting its stopping rule (gr_full.c:221-223) */
 int rebxamd_fetch_warnings(rebxamd_ctx* ctx, uint32_t* bits, void* stream);
 
+/* Timing aid (no counterpart in the reference).  While enabled, every streaming pass launched
+ * by rebxamd_apply is bracketed by a HIP event pair recorded on the stream it is launched on.
+ * rebxamd_timing_read waits for the recorded events, returns the summed kernel time and the
+ * number of launches since the last read, and starts over. */
+int rebxamd_timing_enable(rebxamd_ctx* ctx, int on);
+int rebxamd_timing_read(rebxamd_ctx* ctx, double* total_ms, int* launches);
+
 /* gr_full on one device (gr_full.c:61-231).  The three phases are also exposed on row
  * ranges [row0,row1) so that a multi-GPU driver can shard rows and all-gather between
  * phases.  Arrays are length-n device columns.

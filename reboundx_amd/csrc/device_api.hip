@@ -21,6 +21,30 @@ struct rebxamd_ctx {
     double* gf = nullptr;               // gr_full workspace
     size_t gf_cap = 0;
     unsigned* gf_flag = nullptr;
+    // optional timing of the dominant kernels with HIP events on the launch stream
+    bool timing = false;
+    std::vector<hipEvent_t> ev;         // pairs: start, stop
+    size_t ev_used = 0;
+};
+
+// Brackets one kernel launch with an event pair when timing is on.
+struct TimedLaunch {
+    rebxamd_ctx* ctx; hipStream_t st; bool on;
+    TimedLaunch(rebxamd_ctx* c, hipStream_t s) : ctx(c), st(s), on(c->timing) {
+        if (!on) return;
+        if (ctx->ev_used + 2 > ctx->ev.size()) {
+            if (ctx->ev.size() >= 16384) { on = false; return; }
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            ctx->ev.push_back(a); ctx->ev.push_back(b);
+        }
+        (void)hipEventRecord(ctx->ev[ctx->ev_used], st);
+    }
+    ~TimedLaunch() {
+        if (!on) return;
+        (void)hipEventRecord(ctx->ev[ctx->ev_used + 1], st);
+        ctx->ev_used += 2;
+    }
 };
 
 static int fail(rebxamd_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess) {
@@ -68,7 +92,31 @@ extern "C" void rebxamd_destroy(rebxamd_ctx* ctx) {
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->gf) (void)hipFree(ctx->gf);
     if (ctx->gf_flag) (void)hipFree(ctx->gf_flag);
+    for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     delete ctx;
+}
+
+extern "C" int rebxamd_timing_enable(rebxamd_ctx* ctx, int on) {
+    if (!ctx) return REBXAMD_ERR_ARG;
+    ctx->timing = on != 0;
+    ctx->ev_used = 0;
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_timing_read(rebxamd_ctx* ctx, double* total_ms, int* launches) {
+    if (!ctx || !total_ms || !launches) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_timing_read: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    double sum = 0.;
+    for (size_t k = 0; k + 1 < ctx->ev_used; k += 2) {
+        HIP_TRY(hipEventSynchronize(ctx->ev[k + 1]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[k], ctx->ev[k + 1]));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = (int)(ctx->ev_used / 2);
+    ctx->ev_used = 0;
+    return REBXAMD_OK;
 }
 
 extern "C" const char* rebxamd_last_error(rebxamd_ctx* ctx) { return ctx ? ctx->err.c_str() : "no context"; }
@@ -214,7 +262,10 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
 
     if (sparse) {
         HIP_TRY(launch_head(v, prog, ctx->hc, ctx->status, exact, st));
-        if (v.n > K) HIP_TRY(launch_stream(v, prog, K, ctx->hc, nullptr, nullptr, false, exact, vec2, ctx->status, st));
+        if (v.n > K) {
+            TimedLaunch tl(ctx, st);
+            HIP_TRY(launch_stream(v, prog, K, ctx->hc, nullptr, nullptr, false, exact, vec2, ctx->status, st));
+        }
         return REBXAMD_OK;
     }
     // general regime
@@ -232,7 +283,10 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
         if (rc != REBXAMD_OK) return rc;
     }
     int nblocks = 0;
-    HIP_TRY(launch_stream(v, prog, 0, ctx->hc, ctx->partials, &nblocks, nslots > 0, exact, vec2, ctx->status, st));
+    {
+        TimedLaunch tl(ctx, st);
+        HIP_TRY(launch_stream(v, prog, 0, ctx->hc, ctx->partials, &nblocks, nslots > 0, exact, vec2, ctx->status, st));
+    }
     if (nslots > 0) HIP_TRY(launch_finalize(v, prog, ctx->partials, nblocks, st));
     return REBXAMD_OK;
 }

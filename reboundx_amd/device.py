@@ -71,6 +71,14 @@ class Context:
         self._check(lib.rebxamd_fetch_warnings(self._h, ctypes.byref(bits), self._stream()))
         return bits.value
 
+    def timing_enable(self, on=True):
+        self._check(lib.rebxamd_timing_enable(self._h, 1 if on else 0))
+
+    def timing_read(self):
+        ms, cnt = ctypes.c_double(0), ctypes.c_int(0)
+        self._check(lib.rebxamd_timing_read(self._h, ctypes.byref(ms), ctypes.byref(cnt)))
+        return ms.value, cnt.value
+
     def grfull(self, view, c, gravity_ignore_10=0, mode=_lib.MODE_FAST):
         sweeps = ctypes.c_int(0)
         self._check(lib.rebxamd_grfull(self._h, ctypes.byref(view), c, gravity_ignore_10, mode, ctypes.byref(sweeps), self._stream()))

@@ -1,0 +1,368 @@
+"""Parity of the HIP path (through the C ABI of librebxamd.so) against the CPU checker.
+
+Bars (fp64 work; stated by the project's north star, restated here):
+  * per-particle forces: <= 1e-12 relative per acceleration component;
+  * gr_full after its sweep loop: <= 1e-10 relative per component.
+How "relative" is measured is defined in gpu_common.rel_err: against the component itself,
+floored at FLOOR x the largest component of the same particle's update.
+
+Two arithmetic modes are tested:
+  * MODE_EXACT (reference expression order, no FMA contraction): every row that is not the
+    target of a parallel reduction must carry the checker's bits (0 ulp); central_force is
+    the one exception (libm pow vs. the device pow differ by a few ulp);
+  * MODE_FAST (shared reciprocal square roots, FMA): the 1e-12 bar.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle
+from gpu_common import TOL, rel_err, run_device, run_oracle, ulp_diff
+from reboundx_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+C = synthetic.C_DEFAULT
+EXACT, FAST = 1, 0
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from reboundx_amd.device import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def zero_acc(cols):
+    c = dict(cols)
+    for k in ("ax", "ay", "az"):
+        c[k] = np.zeros_like(cols["x"])
+    return c
+
+
+def check(ctx, cols, pp, forces, mode, G=1.0, reduced_rows=(), pow_ulps=0, tol=TOL, **kw):
+    ref = run_oracle(cols, pp, forces, G)
+    got, _ = run_device(ctx, cols, pp, forces, G, mode, **kw)
+    assert np.isfinite(got).all()
+    if mode == EXACT:
+        u = ulp_diff(got, ref).max(axis=0)
+        mask = np.ones(u.shape, dtype=bool)
+        mask[list(reduced_rows)] = False
+        assert u[mask].max(initial=0) <= pow_ulps, "rows differ from the checker in exact mode: %s" % np.nonzero(u > pow_ulps)[0][:10]
+    e = rel_err(got, ref)
+    assert e.max(initial=0.0) <= tol, "max rel err %.3e at particle %d" % (e.max(), int(e.argmax()))
+    return got, ref
+
+
+C2_STACK = [("radiation_forces", {"c": C}), ("gravitational_harmonics", {}), ("gr", {"c": C})]
+
+
+@pytest.mark.parametrize("mode", [EXACT, FAST])
+@pytest.mark.parametrize("n,n_planets", [(2, 0), (3, 0), (1000, 0), (3001, 2), (4098, 5), (70001, 1)])
+def test_debris_disk_stack_head_plus_massless_tail(ctx, n, n_planets, mode):
+    """radiation_forces + gravitational_harmonics + gr on star(+planets) + massless dust."""
+    cols, pp, _ = synthetic.disk(n, n_planets)
+    check(ctx, zero_acc(cols), pp, C2_STACK, mode)
+    synthetic.add_newtonian(cols, n_head=1 + n_planets)
+    check(ctx, cols, pp, C2_STACK, mode)
+
+
+@pytest.mark.parametrize("mode", [EXACT, FAST])
+@pytest.mark.parametrize("force", [("radiation_forces", {"c": C}), ("gravitational_harmonics", {}), ("gr", {"c": C}),
+                                   ("gr", {"c": 50.0, "max_iterations": 3}), ("gr_potential", {"c": C}), ("tides_precession", {}),
+                                   ("modify_orbits_forces", {}), ("modify_orbits_forces", {"coordinates": 1}),
+                                   ("modify_orbits_forces", {"coordinates": 2})])
+def test_each_force_head_plus_massless_tail(ctx, force, mode):
+    n = 5003
+    cols, pp, _ = synthetic.disk(n, 3)
+    pp["primary"] = np.zeros(n, dtype=np.uint8)
+    pp["primary"][0] = 1
+    check(ctx, zero_acc(cols), pp, [force], mode)
+
+
+@pytest.mark.parametrize("mode", [EXACT, FAST])
+@pytest.mark.parametrize("gamma", [-1.0, -2.5, 1.0])
+def test_central_force(ctx, gamma, mode):
+    n = 2001
+    cols, pp, _ = synthetic.disk(n, 2)
+    pp["Acentral"] = np.full(n, np.nan)
+    pp["gammacentral"] = np.full(n, np.nan)
+    pp["Acentral"][0], pp["gammacentral"][0] = 1e-4, gamma
+    # pow() is the one libm call on the path; device and host libm agree to a few ulp only
+    check(ctx, zero_acc(cols), pp, [("central_force", {})], mode, pow_ulps=16)
+
+
+C3_STACK = [("tides_precession", {}), ("modify_orbits_forces", {"coordinates": 2}), ("gr_potential", {"c": C})]
+
+
+@pytest.mark.parametrize("mode", [EXACT, FAST])
+@pytest.mark.parametrize("n", [100, 20001, 65537])
+def test_massive_everywhere_stack_with_back_reactions(ctx, n, mode):
+    """tides + modify_orbits_forces(PARTICLE) + gr_potential where every particle has mass:
+    the push on the source is a parallel reduction, so row 0 is compared with the 1e-12 bar
+    relative to the size of the terms that were summed."""
+    cols, pp, _ = synthetic.disk(n, 1, dust_mass=1e-15)
+    pp["primary"] = np.zeros(n, dtype=np.uint8)
+    pp["primary"][0] = 1
+    cols = zero_acc(cols)
+    ref = run_oracle(cols, pp, C3_STACK)
+    got, _ = run_device(ctx, cols, pp, C3_STACK, 1.0, mode)
+    u = ulp_diff(got, ref).max(axis=0)
+    if mode == EXACT:
+        assert u[1:].max() == 0
+    assert rel_err(got[:, 1:], ref[:, 1:]).max() <= TOL
+    # source row: scale = sum of |terms| ~ n * typical push; bound it from the per-particle pushes
+    push_scale = np.abs(ref[:, 1:]).max() * 1e-15 * n          # m_dust/m_star * |a| summed
+    assert np.abs(got[:, 0] - ref[:, 0]).max() <= 1e-12 * max(push_scale, np.abs(ref[:, 0]).max())
+
+
+@pytest.mark.parametrize("mode", [EXACT, FAST])
+def test_each_back_reacting_force_massive_everywhere(ctx, mode):
+    n = 30011
+    cols, pp, _ = synthetic.disk(n, 1, dust_mass=1e-12)
+    pp["primary"] = np.zeros(n, dtype=np.uint8)
+    pp["primary"][0] = 1
+    pp["Acentral"] = np.full(n, np.nan); pp["gammacentral"] = np.full(n, np.nan)
+    pp["Acentral"][0], pp["gammacentral"][0] = 1e-4, -1.0
+    cols = zero_acc(cols)
+    for force in (("gravitational_harmonics", {}), ("gr_potential", {"c": C}), ("tides_precession", {}),
+                  ("central_force", {}), ("modify_orbits_forces", {"coordinates": 2}), ("radiation_forces", {"c": C})):
+        ref = run_oracle(cols, pp, [force])
+        got, _ = run_device(ctx, cols, pp, [force], 1.0, mode)
+        if mode == EXACT and force[0] != "central_force":
+            assert ulp_diff(got[:, 1:], ref[:, 1:]).max() == 0, force
+        assert rel_err(got[:, 1:], ref[:, 1:]).max() <= TOL, force
+        scale = max(np.abs(ref[:, 1:]).max() * 1e-12 * n, np.abs(ref[:, 0]).max())
+        assert np.abs(got[:, 0] - ref[:, 0]).max() <= 1e-12 * scale, force
+
+
+def test_unsupported_layouts_are_refused_not_faked(ctx):
+    """gr and Jacobi/barycentric modify_orbits_forces need the massive bodies to be a short
+    prefix; anything else must fail loudly (no silent fallback)."""
+    from reboundx_amd.device import RebxAmdError
+    n = 500
+    cols, pp, _ = synthetic.disk(n, 1, dust_mass=1e-9)
+    for force in (("gr", {"c": C}), ("modify_orbits_forces", {})):
+        with pytest.raises(RebxAmdError) as ei:
+            run_device(ctx, zero_acc(cols), pp, [force])
+        assert ei.value.code == 3
+
+
+# parameters of the reference's own tests (reboundx/test/test_machine_independent.py:39-42,135-136,
+# 159-160,183-184,207-209) on the reference's own three-body system (:25-31)
+TWOPLANETS_PP = {
+    "beta": np.array([np.nan, .5, .3]),
+    "J2": np.array([1e-3, np.nan, np.nan]), "J4": np.array([1e-3, np.nan, np.nan]), "R_eq": np.array([1e-3, np.nan, np.nan]),
+    "R_tides": np.array([1e-3, np.nan, np.nan]), "k1": np.array([.4, np.nan, np.nan]),
+    "tau_a": np.array([np.nan, -1e4, np.nan]), "tau_e": np.array([np.nan, -1e3, -1e3]), "tau_inc": np.array([np.nan, np.nan, -1e3]),
+    "Acentral": np.array([1e-3, np.nan, np.nan]), "gammacentral": np.array([-1., np.nan, np.nan]),
+}
+
+
+@pytest.mark.parametrize("mode", [EXACT, FAST])
+@pytest.mark.parametrize("force", [("radiation_forces", {"c": 1e4}), ("gravitational_harmonics", {}), ("gr", {"c": 1e4}),
+                                   ("gr_potential", {"c": 1e4}), ("tides_precession", {}), ("central_force", {}),
+                                   ("modify_orbits_forces", {}), ("modify_orbits_forces", {"coordinates": 1})])
+def test_reference_test_system_each_force(ctx, force, mode):
+    cols = synthetic.twoplanets()
+    s = oracle.Sim(cols)
+    oracle.newtonian_gravity(s)
+    cols["ax"], cols["ay"], cols["az"] = [a.copy() for a in s.acc]
+    check(ctx, cols, TWOPLANETS_PP, [force], mode, pow_ulps=16 if force[0] == "central_force" else 0)
+    check(ctx, zero_acc(cols), TWOPLANETS_PP, [force], mode, pow_ulps=16 if force[0] == "central_force" else 0)
+
+
+@pytest.mark.parametrize("mode", [EXACT, FAST])
+def test_all_seven_streaming_forces_stacked_in_reverse_add_order(ctx, mode):
+    """The reference runs forces in the reverse of the order they were added
+    (src/linkedlist.c:33-36); here the execution order is given explicitly."""
+    n = 8191
+    cols, pp, _ = synthetic.disk(n, 4)
+    pp["primary"] = np.zeros(n, dtype=np.uint8); pp["primary"][0] = 1
+    stack = [("modify_orbits_forces", {"coordinates": 0}), ("tides_precession", {}), ("gr", {"c": C}),
+             ("gr_potential", {"c": C}), ("gravitational_harmonics", {}), ("radiation_forces", {"c": C}),
+             ("modify_orbits_forces", {"coordinates": 2})]
+    synthetic.add_newtonian(cols, n_head=5)
+    check(ctx, cols, pp, stack, mode)
+
+
+@pytest.mark.parametrize("mode", [EXACT, FAST])
+def test_several_sources(ctx, mode):
+    """Two radiation sources, two oblate bodies, two tidal primaries: one pass per source, in
+    index order, J2 passes before J4 passes (gravitational_harmonics.c:137-140)."""
+    n = 4000
+    cols, pp, _ = synthetic.disk(n, 3)
+    pp["radiation_source"] = np.zeros(n, dtype=np.uint8); pp["radiation_source"][[0, 2]] = 1
+    pp["tides_primary"] = np.zeros(n, dtype=np.uint8); pp["tides_primary"][[0, 1]] = 1
+    pp["J2"][2], pp["J4"][2], pp["R_eq"][2] = 2e-2, 1e-3, 5e-3
+    pp["J2"][3] = 0.5          # J2 without R_eq: ignored (gravitational_harmonics.c:90-92)
+    stack = [("radiation_forces", {"c": C}), ("gravitational_harmonics", {}), ("tides_precession", {})]
+    check(ctx, zero_acc(cols), pp, stack, mode)
+
+
+def test_particles_without_beta_are_untouched(ctx):
+    n = 3000
+    cols, pp, _ = synthetic.disk(n, 0)
+    pp["beta"][100:200] = np.nan
+    synthetic.add_newtonian(cols, n_head=1)
+    got, ref = check(ctx, cols, pp, [("radiation_forces", {"c": C})], EXACT)
+    for k, name in enumerate(("ax", "ay", "az")):
+        assert np.array_equal(got[k, 100:200], cols[name][100:200])
+        assert np.array_equal(got[k, 0:1], cols[name][0:1])        # the source itself
+
+
+def test_unaligned_columns_take_the_scalar_path(ctx):
+    """Views that start 8 bytes into an allocation cannot use 16-byte accesses."""
+    import torch
+    from reboundx_amd.device import DeviceParticles, apply_forces
+    n = 3001
+    cols, pp, _ = synthetic.disk(n, 2)
+    host = dict(zero_acc(cols)); host["beta"] = pp["beta"]
+    ref = run_oracle(zero_acc(cols), pp, C2_STACK)
+    dev = {}
+    for k, v in host.items():
+        if isinstance(v, np.ndarray) and v.dtype == np.float64 and k in ("x", "y", "z", "vx", "vy", "vz", "m", "ax", "ay", "az", "beta"):
+            buf = torch.empty(n + 1, dtype=torch.float64, device="cuda:0")
+            buf[1:] = torch.from_numpy(v)
+            dev[k] = buf[1:]
+    dp = DeviceParticles(dev, G=1.0, n_head=3, tail_massless=True)
+    assert dp.cols["x"].data_ptr() % 16 == 8
+    apply_forces(ctx, dp, C2_STACK, pp, EXACT)
+    got = np.array(dp.acc_host())
+    assert ulp_diff(got, ref).max() == 0
+
+
+def test_classify_and_reset(ctx):
+    import torch
+    from reboundx_amd.device import DeviceParticles
+    m = np.zeros(100000); m[0] = 1.0; m[37] = 1e-30
+    t = torch.from_numpy(m).cuda()
+    assert ctx.classify(t) == 38
+    assert ctx.classify(torch.zeros(10, dtype=torch.float64, device="cuda")) == 1
+    cols, pp, _ = synthetic.disk(1000, 0)
+    synthetic.add_newtonian(cols, n_head=1)
+    dp = DeviceParticles.from_host(cols)
+    ctx.reset_accelerations(dp.view())
+    assert all((a == 0).all() for a in dp.acc_host())
+
+
+def test_gr_nonconvergence_raises_the_reference_warning_bit(ctx):
+    cols = synthetic.twoplanets()
+    ctx.fetch_warnings()
+    run_device(ctx, zero_acc(cols), {}, [("gr", {"c": 1.2})], 1.0, EXACT)     # absurdly slow light: iteration cannot settle
+    assert ctx.fetch_warnings() & 1
+    run_device(ctx, zero_acc(cols), {}, [("gr", {"c": 1e4})], 1.0, EXACT)
+    assert ctx.fetch_warnings() == 0
+
+
+# --------------------------------------------------------------------------- gr_full
+
+def cluster_with_gravity(n):
+    cl = synthetic.cluster(n)
+    s = oracle.Sim(cl)
+    oracle.newtonian_gravity(s)
+    cl["ax"], cl["ay"], cl["az"] = [a.copy() for a in s.acc]
+    return cl
+
+
+@pytest.mark.parametrize("mode", [EXACT, FAST])
+@pytest.mark.parametrize("ignore10", [0, 1])
+@pytest.mark.parametrize("n", [1, 2, 3, 16, 128, 257, 700])
+def test_gr_full_against_checker(ctx, n, ignore10, mode):
+    from reboundx_amd.device import DeviceParticles
+    cl = cluster_with_gravity(n)
+    ref = oracle.Sim(cl)
+    sweeps_ref = oracle.gr_full(ref, 1e2, ignore10)
+    dp = DeviceParticles.from_host(cl)
+    sweeps = ctx.grfull(dp.view(), 1e2, ignore10, mode)
+    got = np.array(dp.acc_host())
+    a0 = np.array([cl["ax"], cl["ay"], cl["az"]])
+    d_ref, d_got = np.array(ref.acc) - a0, got - a0
+    if mode == EXACT:
+        assert sweeps == sweeps_ref
+        assert ulp_diff(got, np.array(ref.acc)).max() == 0
+    else:
+        # the stopping rule asks for bitwise-repeating iterates, so a last-bit difference may
+        # cost or save one sweep; the iterates themselves agree far below the bar by then
+        assert abs(sweeps - sweeps_ref) <= 1
+        assert rel_err(d_got, d_ref).max(initial=0.0) <= 1e-10
+        assert rel_err(got, np.array(ref.acc)).max(initial=0.0) <= 1e-12
+
+
+def test_gr_full_reference_test_system(ctx):
+    """test_machine_independent.py:52-73: the three-body system, c = 1e4, after WHFast's
+    Jacobi gravity (gravity_ignore_terms = 1 adds the 0-1 pair back, gr_full.c:92-102)."""
+    from reboundx_amd.device import DeviceParticles
+    cols = synthetic.twoplanets()
+    s = oracle.Sim(cols); oracle.newtonian_gravity(s)
+    cols["ax"], cols["ay"], cols["az"] = [a.copy() for a in s.acc]
+    for ig in (0, 1):
+        ref = oracle.Sim(cols); oracle.gr_full(ref, 1e4, ig)
+        dp = DeviceParticles.from_host(cols)
+        ctx.grfull(dp.view(), 1e4, ig, EXACT)
+        assert ulp_diff(np.array(dp.acc_host()), np.array(ref.acc)).max() == 0
+
+
+@pytest.mark.parametrize("mode", [EXACT, FAST])
+def test_gr_full_row_ranges_compose(ctx, mode):
+    """The three phases on two row shards + concatenation == the phases on all rows
+    (what the multi-GPU driver relies on)."""
+    import torch
+    from reboundx_amd.device import DeviceParticles
+    n, c = 1000, 1e2
+    cl = cluster_with_gravity(n)
+    dp = DeviceParticles.from_host(cl)
+    v = dp.view()
+    z = lambda: torch.zeros(n, dtype=torch.float64, device="cuda")
+    an = [dp.cols[k].clone() for k in ("ax", "ay", "az")]
+    ao = [0.01 * a for a in an]
+    res = {}
+    for label, cuts in (("whole", [0, n]), ("split", [0, 389, n])):
+        pot, ac, out = z(), [z(), z(), z()], [z(), z(), z()]
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        for r0, r1 in zip(cuts[:-1], cuts[1:]):
+            ctx.grfull_pot(v, c, r0, r1, pot, mode)
+        for r0, r1 in zip(cuts[:-1], cuts[1:]):
+            ctx.grfull_const(v, c, r0, r1, pot, ac, mode)
+        for r0, r1 in zip(cuts[:-1], cuts[1:]):
+            ctx.grfull_sweep(v, c, r0, r1, an, ao, ac, out, flag, mode)
+        res[label] = [t.cpu().numpy() for t in [pot] + ac + out] + [int(flag.item())]
+    for a, b in zip(res["whole"][:-1], res["split"][:-1]):
+        if mode == EXACT:
+            assert np.array_equal(a, b)
+        else:
+            assert np.abs(a - b).max() <= 1e-13 * np.abs(a).max()
+    assert res["whole"][-1] == res["split"][-1] == 1
+
+
+# --------------------------------------------------------------------------- full size
+
+@pytest.mark.parametrize("mode", [FAST, EXACT])
+def test_ten_million_particle_disk_matches_checker_on_a_sample(ctx, mode):
+    """The headline configuration (star + 1e7 massless grains, radiation + J2/J4 + gr).
+    Behind the head every grain's update depends only on the head and on itself, so the
+    checker run on (head + a random sample of grains) must reproduce the sampled rows of the
+    full-size device result; plus: the run is deterministic (two launches, same bits)."""
+    from reboundx_amd.device import DeviceParticles, apply_forces
+    n = 10_000_000
+    cols, pp, _ = synthetic.disk(n, 0)
+    synthetic.add_newtonian(cols, n_head=1)
+    host = dict(cols); host["beta"] = pp["beta"]
+    outs = []
+    for _ in range(2):
+        dp = DeviceParticles.from_host(host, n_head=1, tail_massless=True)
+        apply_forces(ctx, dp, C2_STACK, {k: pp[k][:1] for k in ("J2", "J4", "R_eq")} | {"beta": pp["beta"][:1]}, mode)
+        outs.append(np.array(dp.acc_host()))
+        del dp
+    assert np.array_equal(outs[0], outs[1])
+    rng = np.random.default_rng(7)
+    pick = np.concatenate([[0], np.sort(rng.choice(np.arange(1, n), size=20000, replace=False)), [n - 1]])
+    sub = {k: v[pick].copy() for k, v in cols.items()}
+    subpp = {k: v[pick].copy() for k, v in pp.items()}
+    ref = run_oracle(sub, subpp, C2_STACK)
+    got = outs[0][:, pick]
+    if mode == EXACT:
+        assert ulp_diff(got, ref).max() == 0
+    assert rel_err(got, ref).max() <= TOL
