@@ -283,6 +283,7 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
         if (rc != REBXAMD_OK) return rc;
     }
     int nblocks = 0;
+    HIP_TRY(launch_stage(v, prog, ctx->hc, st));
     {
         TimedLaunch tl(ctx, st);
         HIP_TRY(launch_stream(v, prog, 0, ctx->hc, ctx->partials, &nblocks, nslots > 0, exact, vec2, ctx->status, st));

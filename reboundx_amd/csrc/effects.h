@@ -27,12 +27,32 @@ struct Part {
 };
 
 // snapshot of a source / reference body
-struct Src {
-    double x, y, z, vx, vy, vz, m;
-    double Rt, k1;      // tides only: source's own R_tides, k1 (0 when not set)
-};
+// (Rt, k1: the source's own R_tides and k1 for tides, 0 when not set; inv_m = 1/m)
+typedef SrcRec Src;
+
+// Separation of a particle from a source, shared by every fast-mode force that has the
+// same source: d = p - S, ri = 1/|d|.  `src` remembers which source it was computed for.
+struct Geo { double dx, dy, dz, ri; int src; };
 
 __device__ __forceinline__ bool is_set(double v) { return v == v; }
+
+// Reciprocal square root and reciprocal for the fast mode: the hardware estimate
+// (v_rsq_f64 / v_rcp_f64, good to about 2^-23) refined by one third-order step, so the
+// error term is the cube of the estimate's (~2^-69) and the result is rounded once or
+// twice.  No range scaling: arguments here are squared distances and 1 - O(v^2/c^2), far
+// from the subnormal and overflow ranges; a zero distance gives NaN, where the reference
+// gives inf/NaN as well.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-(x * y), y, 1.0);             // 1 - x y^2
+    const double p = fma(0.375, e, 0.5);                // 1/2 + 3/8 e
+    return fma(y * e, p, y);                            // y (1 + e/2 + 3/8 e^2)
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+    const double y = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, y, 1.0);                   // 1 - x y
+    return fma(y, fma(e, e, e), y);                     // y (1 + e + e^2)
+}
 
 // ---------------------------------------------------------------- radiation_forces
 // reference src/radiation_forces.c:69-98
@@ -48,17 +68,15 @@ __device__ __forceinline__ void rad_exact(const Part& p, const Src& S, double G,
     d.y = a_rad * ((1. - rdot / c) * dy / dr - dvy / c);
     d.z = a_rad * ((1. - rdot / c) * dz / dr - dvz / c);
 }
-__device__ __forceinline__ void rad_fast(const Part& p, const Src& S, double G, double invc, V3& d) {
-    const double dx = p.x - S.x, dy = p.y - S.y, dz = p.z - S.z;
+__device__ __forceinline__ void rad_fast(const Part& p, const Src& S, const Geo& g, double G, double invc, V3& d) {
     const double dvx = p.vx - S.vx, dvy = p.vy - S.vy, dvz = p.vz - S.vz;
-    const double r2 = dx * dx + dy * dy + dz * dz;
-    const double ri = rsqrt(r2);
-    const double rdot = (dx * dvx + dy * dvy + dz * dvz) * ri;
+    const double ri = g.ri;
+    const double rdot = (g.dx * dvx + g.dy * dvy + g.dz * dvz) * ri;
     const double a_rad = p.beta * (G * S.m) * (ri * ri);
     const double k = (1. - rdot * invc) * ri;
-    d.x = a_rad * (k * dx - dvx * invc);
-    d.y = a_rad * (k * dy - dvy * invc);
-    d.z = a_rad * (k * dz - dvz * invc);
+    d.x = a_rad * (k * g.dx - dvx * invc);
+    d.y = a_rad * (k * g.dy - dvy * invc);
+    d.z = a_rad * (k * g.dz - dvz * invc);
 }
 
 // ---------------------------------------------------------------- gravitational_harmonics
@@ -78,15 +96,12 @@ __device__ __forceinline__ void j2_exact(const Part& p, const Src& S, double G, 
     br.y = -(G * p.m * prefac * fac * dy);
     br.z = -(G * p.m * prefac * (fac - 2.) * dz);
 }
-__device__ __forceinline__ void j2_fast(const Part& p, const Src& S, double G, double J2, double R_eq, V3& d, V3& br) {
-    const double dx = p.x - S.x, dy = p.y - S.y, dz = p.z - S.z;
-    const double r2 = dx * dx + dy * dy + dz * dz;
-    const double ri = rsqrt(r2);
-    const double ri2 = ri * ri;
-    const double costheta2 = dz * dz * ri2;
+__device__ __forceinline__ void j2_fast(const Part& p, const Src& S, const Geo& g, double G, double J2, double R_eq, V3& d, V3& br) {
+    const double ri = g.ri, ri2 = ri * ri;
+    const double costheta2 = g.dz * g.dz * ri2;
     const double prefac = (1.5 * J2 * R_eq * R_eq) * (ri2 * ri2 * ri);
     const double fac = 5. * costheta2 - 1.;
-    const double fx = prefac * fac * dx, fy = prefac * fac * dy, fz = prefac * (fac - 2.) * dz;
+    const double fx = prefac * fac * g.dx, fy = prefac * fac * g.dy, fz = prefac * (fac - 2.) * g.dz;
     const double gs = G * S.m, gp = -(G * p.m);
     d.x = gs * fx; d.y = gs * fy; d.z = gs * fz;
     br.x = gp * fx; br.y = gp * fy; br.z = gp * fz;
@@ -107,16 +122,13 @@ __device__ __forceinline__ void j4_exact(const Part& p, const Src& S, double G, 
     br.y = -(G * p.m * prefac * fac * dy);
     br.z = -(G * p.m * prefac * (fac + 12. - 28. * costheta2) * dz);
 }
-__device__ __forceinline__ void j4_fast(const Part& p, const Src& S, double G, double J4, double R_eq, V3& d, V3& br) {
-    const double dx = p.x - S.x, dy = p.y - S.y, dz = p.z - S.z;
-    const double r2 = dx * dx + dy * dy + dz * dz;
-    const double ri = rsqrt(r2);
-    const double ri2 = ri * ri;
-    const double costheta2 = dz * dz * ri2;
+__device__ __forceinline__ void j4_fast(const Part& p, const Src& S, const Geo& g, double G, double J4, double R_eq, V3& d, V3& br) {
+    const double ri = g.ri, ri2 = ri * ri;
+    const double costheta2 = g.dz * g.dz * ri2;
     const double Re2 = R_eq * R_eq;
     const double prefac = (0.625 * J4 * Re2 * Re2) * (ri2 * ri2 * ri2 * ri);
     const double fac = 63. * costheta2 * costheta2 - 42. * costheta2 + 3.;
-    const double fx = prefac * fac * dx, fy = prefac * fac * dy, fz = prefac * (fac + 12. - 28. * costheta2) * dz;
+    const double fx = prefac * fac * g.dx, fy = prefac * fac * g.dy, fz = prefac * (fac + 12. - 28. * costheta2) * g.dz;
     const double gs = G * S.m, gp = -(G * p.m);
     d.x = gs * fx; d.y = gs * fy; d.z = gs * fz;
     br.x = gp * fx; br.y = gp * fy; br.z = gp * fz;
@@ -134,12 +146,11 @@ __device__ __forceinline__ void grpot_exact(const Part& p, const Src& S, double 
     br.y = p.m / S.m * prefac * dy;
     br.z = p.m / S.m * prefac * dz;
 }
-__device__ __forceinline__ void grpot_fast(const Part& p, const Src& S, double prefac1, double inv_ms, V3& d, V3& br) {
-    const double dx = p.x - S.x, dy = p.y - S.y, dz = p.z - S.z;
-    const double r2 = dx * dx + dy * dy + dz * dz;
-    const double prefac = prefac1 / (r2 * r2);
-    const double fx = prefac * dx, fy = prefac * dy, fz = prefac * dz;
-    const double w = p.m * inv_ms;
+__device__ __forceinline__ void grpot_fast(const Part& p, const Src& S, const Geo& g, double prefac1, V3& d, V3& br) {
+    const double ri2 = g.ri * g.ri;
+    const double prefac = prefac1 * (ri2 * ri2);
+    const double fx = prefac * g.dx, fy = prefac * g.dy, fz = prefac * g.dz;
+    const double w = p.m * S.inv_m;
     d.x = -fx; d.y = -fy; d.z = -fz;
     br.x = w * fx; br.y = w * fy; br.z = w * fz;
 }
@@ -156,12 +167,11 @@ __device__ __forceinline__ void central_exact(const Part& p, const Src& S, doubl
     br.y = -(p.m / S.m * prefac * dy);
     br.z = -(p.m / S.m * prefac * dz);
 }
-__device__ __forceinline__ void central_fast(const Part& p, const Src& S, double A, double gamma, V3& d, V3& br) {
-    const double dx = p.x - S.x, dy = p.y - S.y, dz = p.z - S.z;
-    const double r2 = dx * dx + dy * dy + dz * dz;
+__device__ __forceinline__ void central_fast(const Part& p, const Src& S, const Geo& g, double A, double gamma, V3& d, V3& br) {
+    const double r2 = g.dx * g.dx + g.dy * g.dy + g.dz * g.dz;
     const double prefac = A * pow(r2, 0.5 * (gamma - 1.));
-    d.x = prefac * dx; d.y = prefac * dy; d.z = prefac * dz;
-    const double w = -(p.m / S.m);
+    d.x = prefac * g.dx; d.y = prefac * g.dy; d.z = prefac * g.dz;
+    const double w = -(p.m * S.inv_m);
     br.x = w * d.x; br.y = w * d.y; br.z = w * d.z;
 }
 
@@ -188,21 +198,19 @@ __device__ __forceinline__ bool tides_exact(const Part& p, const Src& S, double 
     br.z = -(mratio * prefac * dz);
     return true;
 }
-__device__ __forceinline__ bool tides_fast(const Part& p, const Src& S, double G, V3& d, V3& br) {
+__device__ __forceinline__ bool tides_fast(const Part& p, const Src& S, const Geo& g, double G, V3& d, V3& br) {
     const double m0 = S.m;
     const double R02 = S.Rt * S.Rt;
     const double fac0 = S.k1 * R02 * R02 * S.Rt;
-    const double mratio = p.m / m0;
+    const double mratio = p.m * S.inv_m;
     if (mratio < DBL_MIN) return false;
     const double Rp = is_set(p.Rt) ? p.Rt : 0.;
     const double k1p = is_set(p.k1) ? p.k1 : 0.;
     const double Rp2 = Rp * Rp;
-    const double fac = fac0 * mratio + (k1p * Rp2 * Rp2 * Rp) * (m0 / p.m);
-    const double dx = p.x - S.x, dy = p.y - S.y, dz = p.z - S.z;
-    const double dr2 = dx * dx + dy * dy + dz * dz;
-    const double dr4 = dr2 * dr2;
-    const double prefac = -3. * G * (m0 + p.m) * fac / (dr4 * dr4);
-    d.x = prefac * dx; d.y = prefac * dy; d.z = prefac * dz;
+    const double fac = fac0 * mratio + (k1p * Rp2 * Rp2 * Rp) * (m0 * fast_rcp(p.m));
+    const double ri2 = g.ri * g.ri, ri4 = ri2 * ri2;
+    const double prefac = -3. * G * (m0 + p.m) * fac * (ri4 * ri4);
+    d.x = prefac * g.dx; d.y = prefac * g.dy; d.z = prefac * g.dz;
     br.x = -(mratio * d.x); br.y = -(mratio * d.y); br.z = -(mratio * d.z);
     return true;
 }
@@ -267,16 +275,15 @@ __device__ __forceinline__ int gr_term_exact(const Jac& p, double mu, double C2,
     out.z = B * (1. - A) * p.z - A * p.az - D * viz;
     return q;
 }
-__device__ __forceinline__ int gr_term_fast(const Jac& p, double mu, double invC2, int max_iterations, V3& out) {
+__device__ __forceinline__ int gr_term_fast(const Jac& p, double rinv, double mu, double invC2, int max_iterations, V3& out) {
     double vix = p.vx, viy = p.vy, viz = p.vz;
     double vi2 = vix * vix + viy * viy + viz * viz;
-    const double rinv = rsqrt(p.x * p.x + p.y * p.y + p.z * p.z);
     const double mur = mu * rinv;
     int q = 0;
     double A = (0.5 * vi2 + 3. * mur) * invC2;
     for (q = 0; q < max_iterations; q++) {
         const double ox = vix, oy = viy, oz = viz;
-        const double s = 1. / (1. - A);
+        const double s = fast_rcp(1. - A);
         vix = p.vx * s; viy = p.vy * s; viz = p.vz * s;
         vi2 = vix * vix + viy * viy + viz * viz;
         A = (0.5 * vi2 + 3. * mur) * invC2;
@@ -315,11 +322,17 @@ __device__ __forceinline__ void newton_pair_exact(double tx, double ty, double t
         ax -= prefac * um * dx; ay -= prefac * um * dy; az -= prefac * um * dz;
     }
 }
+__device__ __forceinline__ void geo_compute(const Part& p, const Src& S, int src, Geo& g) {
+    g.dx = p.x - S.x; g.dy = p.y - S.y; g.dz = p.z - S.z;
+    g.ri = fast_rsqrt(g.dx * g.dx + g.dy * g.dy + g.dz * g.dz);
+    g.src = src;
+}
+
 __device__ __forceinline__ void newton_pair_fast(double tx, double ty, double tz, double ux, double uy, double uz, double um,
                                                  double G, double& ax, double& ay, double& az) {
     const double dx = ux - tx, dy = uy - ty, dz = uz - tz;
     const double r2 = dx * dx + dy * dy + dz * dz;
-    const double ri = rsqrt(r2);
+    const double ri = fast_rsqrt(r2);
     const double w = (G * um) * (ri * ri * ri);
     ax += w * dx; ay += w * dy; az += w * dz;
 }

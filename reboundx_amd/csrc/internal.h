@@ -36,12 +36,23 @@ struct View {
     const double *beta, *Rt, *k1, *ta, *te, *ti;
 };
 
-// What the head pass hands to the tail pass (lives in device memory).
+// State of one source / reference body as the kernels consume it.
+struct SrcRec { double x, y, z, vx, vy, vz, m, Rt, k1, inv_m; };
+
+// Small tables in device memory, written by a one-wavefront kernel right before the streaming
+// pass and read by it through scalar loads (every lane wants the same entry):
+//  - the state of each op's source particle;
+//  - what the head pass hands to the tail pass.
 struct HeadConsts {
+    SrcRec src[REBXAMD_MAX_OPS];
     // gr: interior centre of mass seen by every body behind the head, i.e. (sum m*q) * (1/sum m)
     // for q in {pos, vel, Newtonian acc}, plus mu = G*m0.
     double gr_c[9];
     double gr_mu;
+    // massive head bodies (x y z m), in index order, for the Newtonian term of gr
+    double head[REBXAMD_MAX_HEAD][4];
+    int nheadm;
+    int head0;              // index of the first massive head body
     // modify_orbits_forces in Jacobi/barycentric coordinates: centre of mass of the head
     double com[7];          // x y z vx vy vz m
     int nbary;              // barycentric: number of head back-reaction terms that follow
@@ -55,6 +66,7 @@ enum { WARN_GR_ITER = 1u, WARN_GRFULL_SWEEPS = 2u };
 hipError_t launch_head(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, bool exact, hipStream_t st);
 hipError_t launch_stream(const View& v, const Program& prog, long long lo, const HeadConsts* hc, double* partials,
                          int* nblocks_out, bool backreact, bool exact, bool vec2, unsigned* status, hipStream_t st);
+hipError_t launch_stage(const View& v, const Program& prog, HeadConsts* hc, hipStream_t st);
 hipError_t launch_finalize(const View& v, const Program& prog, const double* partials, int nblocks, hipStream_t st);
 hipError_t launch_last_massive(const double* m, long long n, long long* out_dev, hipStream_t st);
 hipError_t launch_reset(const View& v, hipStream_t st);

@@ -39,6 +39,7 @@ __device__ __forceinline__ void load_src(const View& v, int idx, Src& S) {
     const double rt = ld_or_nan(v.Rt, idx), k1 = ld_or_nan(v.k1, idx);
     S.Rt = is_set(rt) ? rt : 0.;
     S.k1 = is_set(k1) ? k1 : 0.;
+    S.inv_m = 1. / S.m;
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -48,20 +49,25 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // One force on one particle.  Returns true when the particle was acted on; `d` is its own
-// update, `br` the push on the source (already signed).
+// update, `br` the push on the source (already signed).  Fast mode reuses the separation
+// from the source (`g`) when the previous force on this particle had the same source.
 template <bool EXACT>
-__device__ __forceinline__ bool sourced_effect(const DevOp& op, const Part& p, const Src& S, double G, V3& d, V3& br) {
+__device__ __forceinline__ bool sourced_effect(const DevOp& op, const Part& p, const Src& S, double G, Geo& g, V3& d, V3& br) {
     br.x = br.y = br.z = 0.;
+    if (!EXACT) {
+        if (op.kind == REBXAMD_OP_RADIATION && !is_set(p.beta)) return false;
+        if (g.src != op.src) geo_compute(p, S, op.src, g);
+    }
     switch (op.kind) {
     case REBXAMD_OP_RADIATION:
-        if (!is_set(p.beta)) return false;
-        if (EXACT) rad_exact(p, S, G, op.a, d); else rad_fast(p, S, G, op.c, d);
+        if (EXACT) { if (!is_set(p.beta)) return false; rad_exact(p, S, G, op.a, d); }
+        else rad_fast(p, S, g, G, op.c, d);
         return true;
     case REBXAMD_OP_J2:
-        if (EXACT) j2_exact(p, S, G, op.a, op.b, d, br); else j2_fast(p, S, G, op.a, op.b, d, br);
+        if (EXACT) j2_exact(p, S, G, op.a, op.b, d, br); else j2_fast(p, S, g, G, op.a, op.b, d, br);
         return true;
     case REBXAMD_OP_J4:
-        if (EXACT) j4_exact(p, S, G, op.a, op.b, d, br); else j4_fast(p, S, G, op.a, op.b, d, br);
+        if (EXACT) j4_exact(p, S, G, op.a, op.b, d, br); else j4_fast(p, S, g, G, op.a, op.b, d, br);
         return true;
     case REBXAMD_OP_GR_POTENTIAL: {
         if (EXACT) {
@@ -72,15 +78,15 @@ __device__ __forceinline__ bool sourced_effect(const DevOp& op, const Part& p, c
             grpot_exact(p, S, prefac1, d, br);
         } else {
             const double gm = G * S.m;
-            grpot_fast(p, S, 6. * gm * gm * op.d, 1. / S.m, d, br);   // op.d = 1/c^2
+            grpot_fast(p, S, g, 6. * gm * gm * op.d, d, br);      // op.d = 1/c^2
         }
         return true;
     }
     case REBXAMD_OP_CENTRAL:
-        if (EXACT) central_exact(p, S, op.a, op.b, d, br); else central_fast(p, S, op.a, op.b, d, br);
+        if (EXACT) central_exact(p, S, op.a, op.b, d, br); else central_fast(p, S, g, op.a, op.b, d, br);
         return true;
     case REBXAMD_OP_TIDES:
-        return EXACT ? tides_exact(p, S, G, d, br) : tides_fast(p, S, G, d, br);
+        return EXACT ? tides_exact(p, S, G, d, br) : tides_fast(p, S, g, G, d, br);
     default:
         return false;
     }
@@ -159,7 +165,23 @@ __global__ __launch_bounds__(64) void head_kernel(View v, Program prog, HeadCons
         load_src(v, t, sh.hp[t]);
     }
     __syncthreads();
+    // tables for the tail pass: every op's source (all inside the head) and the massive head bodies
+    if (t < prog.nops) {
+        int s = prog.ops[t].src;
+        if (prog.ops[t].kind == REBXAMD_OP_GR) s = 0;
+        if (s >= 0) hc->src[t] = sh.hp[s];
+    }
+    {
+        const double mt = valid ? p.m : 0.;
+        const unsigned long long mask = __ballot(mt != 0.);
+        if (mt != 0.) {
+            const int c = __popcll(mask & ((1ull << t) - 1ull));
+            hc->head[c][0] = p.x; hc->head[c][1] = p.y; hc->head[c][2] = p.z; hc->head[c][3] = mt;
+        }
+        if (t == 0) { hc->nheadm = __popcll(mask); hc->head0 = mask ? __ffsll((long long)mask) - 1 : -1; }
+    }
 
+    Geo geo; geo.src = -1; geo.dx = geo.dy = geo.dz = geo.ri = 0.;
     for (int o = 0; o < prog.nops; o++) {
         const DevOp op = prog.ops[o];
         if (op.kind == REBXAMD_OP_GR) {
@@ -209,7 +231,8 @@ __global__ __launch_bounds__(64) void head_kernel(View v, Program prog, HeadCons
                 j.ax = sh.pj[t][6]; j.ay = sh.pj[t][7]; j.az = sh.pj[t][8];
                 V3 corr;
                 const double mu = G * sh.hp[0].m;
-                const int q = EXACT ? gr_term_exact(j, mu, op.c, op.iarg, corr) : gr_term_fast(j, mu, op.d, op.iarg, corr);
+                const int q = EXACT ? gr_term_exact(j, mu, op.c, op.iarg, corr)
+                                    : gr_term_fast(j, fast_rsqrt(j.x * j.x + j.y * j.y + j.z * j.z), mu, op.d, op.iarg, corr);
                 if (q == 10) atomicOr(status, WARN_GR_ITER);
                 sh.pj[t][6] = corr.x; sh.pj[t][7] = corr.y; sh.pj[t][8] = corr.z;
             }
@@ -294,7 +317,7 @@ __global__ __launch_bounds__(64) void head_kernel(View v, Program prog, HeadCons
                     mof_particle<EXACT>(p, S, acc, br);
                     acted = true;
                 } else {
-                    acted = sourced_effect<EXACT>(op, p, S, G, d, br);
+                    acted = sourced_effect<EXACT>(op, p, S, G, geo, d, br);
                     if (acted) {
 #pragma clang fp contract(off)
                         acc.x += d.x; acc.y += d.y; acc.z += d.z;
@@ -322,177 +345,181 @@ __global__ __launch_bounds__(64) void head_kernel(View v, Program prog, HeadCons
 
 // ------------------------------------------------------------------ streaming kernel
 
-struct StreamShared {
-    Src src[REBXAMD_MAX_OPS];
-    double head[REBXAMD_MAX_HEAD][4];           // x y z m of massive head bodies (gr tail)
-    int nheadm;
-    HeadConsts hc;
-    double part[WAVES][REBXAMD_MAX_OPS][3];
-};
+typedef double d2v __attribute__((ext_vector_type(2)));
 
-template <bool VEC2>
-__device__ __forceinline__ void ld2(const double* col, long long i0, bool two, double& a, double& b) {
-    if (VEC2 && two) {
-        const double2 t = *reinterpret_cast<const double2*>(col + i0);
-        a = t.x; b = t.y;
-    } else {
-        a = col[i0];
-        b = two ? col[i0 + 1] : 0.;
-    }
+// Which optional columns a kernel instance reads.  Instances exist for the column sets of
+// the common force stacks; any other stack runs on the all-columns instance.
+enum { COL_VEL = 1, COL_BETA = 2, COL_TIDES = 4, COL_TAU = 8, COL_ALL = 15 };
+
+// Read-once columns (positions, velocities, parameters) are loaded with the nontemporal hint
+// so that they do not evict the accelerations, which are read and written every pass and (up
+// to ~1e7 particles) stay resident in the 256 MiB Infinity Cache between passes.
+__device__ __forceinline__ void ldpair(const double* col, long long i0, double& a, double& b) {
+    const d2v t = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(col + i0));
+    a = t.x; b = t.y;
+}
+__device__ __forceinline__ double ldone(const double* col, long long i) { return __builtin_nontemporal_load(col + i); }
+
+__device__ __forceinline__ void part_defaults(Part& p) {
+    const double nan = __builtin_nan("");
+    p.x = p.y = p.z = p.vx = p.vy = p.vz = p.m = 0.;
+    p.beta = p.Rt = p.k1 = p.ta = p.te = p.ti = nan;
 }
 
-template <bool EXACT, bool BACKREACT, bool VEC2>
-__global__ __launch_bounds__(BLOCK) void stream_kernel(View v, Program prog, long long lo, long long base,
-                                                       const HeadConsts* hcg, double* partials, unsigned* status) {
-    __shared__ StreamShared sh;
-    const int tid = threadIdx.x;
+// All forces of the program on one particle behind the head (massless by the caller's
+// assertion: it pushes on nothing and feels no tides).  `t` points at the device tables; every
+// lane reads the same entries, so these become scalar loads.
+template <bool EXACT>
+__device__ __forceinline__ void tail_particle(const Program& prog, const HeadConsts* __restrict__ t, const Part& p, V3& acc, unsigned* status) {
     const double G = prog.G;
-
-    // ---- stage sources (and, for the gr tail, the massive head bodies) in LDS
-    if (tid < prog.nops) {
-        const int s = prog.ops[tid].src;
-        if (s >= 0) load_src(v, s, sh.src[tid]);
-    }
-    const bool tail = !BACKREACT;
-    if (tail && (prog.gr_op >= 0 || prog.mofcom_op >= 0)) {
-        // HeadConsts is a few hundred doubles; copy cooperatively
-        const double* g = reinterpret_cast<const double*>(hcg);
-        double* l = reinterpret_cast<double*>(&sh.hc);
-        for (int k = tid; k < (int)(sizeof(HeadConsts) / sizeof(double)); k += BLOCK) l[k] = g[k];
-        if (prog.gr_op >= 0 && tid < 64) {      // wavefront 0 compacts the massive head bodies, keeping their order
-            const int K = (int)(v.n_head < v.n ? v.n_head : v.n);
-            const double mu = tid < K ? v.m[tid] : 0.;
-            const unsigned long long mask = __ballot(mu != 0.);
-            if (mu != 0.) {
-                const int c = __popcll(mask & ((1ull << tid) - 1ull));
-                sh.head[c][0] = v.x[tid]; sh.head[c][1] = v.y[tid]; sh.head[c][2] = v.z[tid]; sh.head[c][3] = mu;
-            }
-            if (tid == 0) sh.nheadm = __popcll(mask);
-        }
-    }
-    __syncthreads();
-
-    const long long i0 = base + 2 * ((long long)blockIdx.x * BLOCK + tid);
-    const bool in0 = i0 < v.n, in1 = i0 + 1 < v.n;
-    const bool act0 = in0 && i0 >= lo, act1 = in1 && i0 + 1 >= lo;
-
-    Part p[2];
-    V3 acc[2];
-    if (in0) {
-        ld2<VEC2>(v.x, i0, in1, p[0].x, p[1].x);
-        ld2<VEC2>(v.y, i0, in1, p[0].y, p[1].y);
-        ld2<VEC2>(v.z, i0, in1, p[0].z, p[1].z);
-        if (prog.need_vel) {
-            ld2<VEC2>(v.vx, i0, in1, p[0].vx, p[1].vx);
-            ld2<VEC2>(v.vy, i0, in1, p[0].vy, p[1].vy);
-            ld2<VEC2>(v.vz, i0, in1, p[0].vz, p[1].vz);
-        } else { p[0].vx = p[0].vy = p[0].vz = p[1].vx = p[1].vy = p[1].vz = 0.; }
-        // behind the head every body is massless by the caller's assertion: no need to read m
-        if (BACKREACT) ld2<VEC2>(v.m, i0, in1, p[0].m, p[1].m);
-        else { p[0].m = 0.; p[1].m = 0.; }
-        const double nan = __builtin_nan("");
-        if (prog.need_beta && v.beta) ld2<VEC2>(v.beta, i0, in1, p[0].beta, p[1].beta); else { p[0].beta = p[1].beta = nan; }
-        if (prog.need_tides && v.Rt) ld2<VEC2>(v.Rt, i0, in1, p[0].Rt, p[1].Rt); else { p[0].Rt = p[1].Rt = nan; }
-        if (prog.need_tides && v.k1) ld2<VEC2>(v.k1, i0, in1, p[0].k1, p[1].k1); else { p[0].k1 = p[1].k1 = nan; }
-        if (prog.need_tau && v.ta) ld2<VEC2>(v.ta, i0, in1, p[0].ta, p[1].ta); else { p[0].ta = p[1].ta = nan; }
-        if (prog.need_tau && v.te) ld2<VEC2>(v.te, i0, in1, p[0].te, p[1].te); else { p[0].te = p[1].te = nan; }
-        if (prog.need_tau && v.ti) ld2<VEC2>(v.ti, i0, in1, p[0].ti, p[1].ti); else { p[0].ti = p[1].ti = nan; }
-        ld2<VEC2>(v.ax, i0, in1, acc[0].x, acc[1].x);
-        ld2<VEC2>(v.ay, i0, in1, acc[0].y, acc[1].y);
-        ld2<VEC2>(v.az, i0, in1, acc[0].z, acc[1].z);
-    }
-    const bool act[2] = {act0, act1};
-    const int wave = tid >> 6, lane = tid & 63;
-
+    Geo g; g.src = -1; g.dx = g.dy = g.dz = g.ri = 0.;
     for (int o = 0; o < prog.nops; o++) {
         const DevOp op = prog.ops[o];
         if (op.kind == REBXAMD_OP_GR) {
-            if (tail) {
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    if (!act[k]) continue;
-                    // Newtonian pull of the massive head bodies (all of them precede this body)
-                    double nx = 0., ny = 0., nz = 0.;
-                    for (int u = 0; u < sh.nheadm; u++) {
-                        if (EXACT) newton_pair_exact(p[k].x, p[k].y, p[k].z, sh.head[u][0], sh.head[u][1], sh.head[u][2], sh.head[u][3], true, G, nx, ny, nz);
-                        else newton_pair_fast(p[k].x, p[k].y, p[k].z, sh.head[u][0], sh.head[u][1], sh.head[u][2], sh.head[u][3], G, nx, ny, nz);
-                    }
-                    Jac j;
-                    {
+            double nx = 0., ny = 0., nz = 0.;
+            Jac j;
+            V3 corr;
+            int q;
+            const int nheadm = t->nheadm;
+            if (!EXACT && nheadm == 1) {
+                // one massive body: its separation serves the Newtonian pull and (to an ulp of the
+                // body's own coordinates) the Jacobi position
+                const int h0 = t->head0;
+                if (g.src != h0) geo_compute(p, t->src[o], h0, g);
+                const double w = -(G * t->head[0][3]) * (g.ri * g.ri * g.ri);
+                j.x = g.dx; j.y = g.dy; j.z = g.dz;
+                j.vx = p.vx - t->gr_c[3]; j.vy = p.vy - t->gr_c[4]; j.vz = p.vz - t->gr_c[5];
+                j.ax = w * g.dx - t->gr_c[6]; j.ay = w * g.dy - t->gr_c[7]; j.az = w * g.dz - t->gr_c[8];
+                q = gr_term_fast(j, g.ri, t->gr_mu, op.d, op.iarg, corr);
+            } else {
+                // Newtonian pull of the massive head bodies (all of them precede this body)
+                for (int u = 0; u < nheadm; u++) {
+                    if (EXACT) newton_pair_exact(p.x, p.y, p.z, t->head[u][0], t->head[u][1], t->head[u][2], t->head[u][3], true, G, nx, ny, nz);
+                    else newton_pair_fast(p.x, p.y, p.z, t->head[u][0], t->head[u][1], t->head[u][2], t->head[u][3], G, nx, ny, nz);
+                }
+                {
 #pragma clang fp contract(off)
-                        j.x = p[k].x - sh.hc.gr_c[0]; j.y = p[k].y - sh.hc.gr_c[1]; j.z = p[k].z - sh.hc.gr_c[2];
-                        j.vx = p[k].vx - sh.hc.gr_c[3]; j.vy = p[k].vy - sh.hc.gr_c[4]; j.vz = p[k].vz - sh.hc.gr_c[5];
-                        j.ax = nx - sh.hc.gr_c[6]; j.ay = ny - sh.hc.gr_c[7]; j.az = nz - sh.hc.gr_c[8];
-                    }
-                    V3 corr;
-                    const int q = EXACT ? gr_term_exact(j, sh.hc.gr_mu, op.c, op.iarg, corr) : gr_term_fast(j, sh.hc.gr_mu, op.d, op.iarg, corr);
-                    if (q == 10) atomicOr(status, WARN_GR_ITER);
-                    // a massless body's inertial correction equals its Jacobi correction
-                    acc[k].x += corr.x; acc[k].y += corr.y; acc[k].z += corr.z;
+                    j.x = p.x - t->gr_c[0]; j.y = p.y - t->gr_c[1]; j.z = p.z - t->gr_c[2];
+                    j.vx = p.vx - t->gr_c[3]; j.vy = p.vy - t->gr_c[4]; j.vz = p.vz - t->gr_c[5];
+                    j.ax = nx - t->gr_c[6]; j.ay = ny - t->gr_c[7]; j.az = nz - t->gr_c[8];
+                }
+                q = EXACT ? gr_term_exact(j, t->gr_mu, op.c, op.iarg, corr)
+                          : gr_term_fast(j, fast_rsqrt(j.x * j.x + j.y * j.y + j.z * j.z), t->gr_mu, op.d, op.iarg, corr);
+            }
+            if (q == 10) atomicOr(status, WARN_GR_ITER);
+            // a massless body's inertial correction equals its Jacobi correction
+            acc.x += corr.x; acc.y += corr.y; acc.z += corr.z;
+        } else if (op.kind == REBXAMD_OP_MOF) {
+            Src ref;
+            if (op.iarg == REBX_COORDINATES_PARTICLE) {
+                ref = t->src[o];
+            } else {
+                ref.x = t->com[0]; ref.y = t->com[1]; ref.z = t->com[2];
+                ref.vx = t->com[3]; ref.vy = t->com[4]; ref.vz = t->com[5]; ref.m = t->com[6];
+            }
+            V3 a;
+            if (EXACT) mof_exact(p, ref, a); else mof_fast(p, ref, a);
+            acc.x += a.x; acc.y += a.y; acc.z += a.z;
+            if (op.iarg == REBX_COORDINATES_BARYCENTRIC) {
+                const int nb = t->nbary;
+                for (int i = 0; i < nb; i++) {
+                    acc.x -= t->bary[i][0]; acc.y -= t->bary[i][1]; acc.z -= t->bary[i][2];
                 }
             }
-            continue;
-        }
-        if (op.kind == REBXAMD_OP_MOF && op.iarg != REBX_COORDINATES_PARTICLE) {
-            if (tail) {
-                Src ref;
-                ref.x = sh.hc.com[0]; ref.y = sh.hc.com[1]; ref.z = sh.hc.com[2];
-                ref.vx = sh.hc.com[3]; ref.vy = sh.hc.com[4]; ref.vz = sh.hc.com[5]; ref.m = sh.hc.com[6];
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    if (!act[k]) continue;
-                    V3 a;
-                    if (EXACT) mof_exact(p[k], ref, a); else mof_fast(p[k], ref, a);
-                    acc[k].x += a.x; acc[k].y += a.y; acc[k].z += a.z;
-                    for (int i = 0; i < sh.hc.nbary; i++) {
-                        acc[k].x -= sh.hc.bary[i][0]; acc[k].y -= sh.hc.bary[i][1]; acc[k].z -= sh.hc.bary[i][2];
-                    }
-                }
+        } else if (op.kind != REBXAMD_OP_TIDES) {
+            V3 d, br;
+            if (sourced_effect<EXACT>(op, p, t->src[o], G, g, d, br)) {
+#pragma clang fp contract(off)
+                acc.x += d.x; acc.y += d.y; acc.z += d.z;
             }
-            continue;
         }
-        const Src S = sh.src[o];
-        double bx = 0., by = 0., bz = 0.;
+    }
+}
+
+// One op on one particle where every body may be massive: the push on the source is returned.
+template <bool EXACT>
+__device__ __forceinline__ void general_op(const DevOp& op, const Src& S, double G, const Part& p, Geo& g, V3& acc, double& bx, double& by, double& bz) {
+    V3 d, br;
+    if (op.kind == REBXAMD_OP_MOF) {
+        mof_particle<EXACT>(p, S, acc, br);
+        bx += br.x; by += br.y; bz += br.z;
+    } else if (sourced_effect<EXACT>(op, p, S, G, g, d, br)) {
+#pragma clang fp contract(off)
+        acc.x += d.x; acc.y += d.y; acc.z += d.z;
+        bx += br.x; by += br.y; bz += br.z;
+    }
+}
+
+struct StreamShared { double part[WAVES][REBXAMD_MAX_OPS][3]; };
+
+template <bool EXACT, bool BACKREACT, bool VEC2, int COLS>
+__global__ __launch_bounds__(BLOCK) void stream_kernel(View v, Program prog, long long lo, long long base,
+                                                       const HeadConsts* __restrict__ tab, double* partials, unsigned* status) {
+    const int tid = threadIdx.x;
+    const double G = prog.G;
+    const long long i0 = base + 2 * ((long long)blockIdx.x * BLOCK + tid);
+    const bool in0 = i0 < v.n, in1 = i0 + 1 < v.n;
+    const bool act0 = in0 && i0 >= lo, act1 = in1 && i0 + 1 >= lo;
+    const bool full = VEC2 && act0 && act1;      // the common case: both particles, 16-byte accesses
+
+    Part p[2];
+    V3 acc[2];
+    part_defaults(p[0]); part_defaults(p[1]);
+    acc[0].x = acc[0].y = acc[0].z = acc[1].x = acc[1].y = acc[1].z = 0.;
+    if (full) {
+        ldpair(v.x, i0, p[0].x, p[1].x); ldpair(v.y, i0, p[0].y, p[1].y); ldpair(v.z, i0, p[0].z, p[1].z);
+        if (COLS & COL_VEL) { ldpair(v.vx, i0, p[0].vx, p[1].vx); ldpair(v.vy, i0, p[0].vy, p[1].vy); ldpair(v.vz, i0, p[0].vz, p[1].vz); }
+        // behind the head every body is massless by the caller's assertion: no need to read m
+        if (BACKREACT) ldpair(v.m, i0, p[0].m, p[1].m);
+        if ((COLS & COL_BETA) && v.beta) ldpair(v.beta, i0, p[0].beta, p[1].beta);
+        if ((COLS & COL_TIDES) && v.Rt) ldpair(v.Rt, i0, p[0].Rt, p[1].Rt);
+        if ((COLS & COL_TIDES) && v.k1) ldpair(v.k1, i0, p[0].k1, p[1].k1);
+        if ((COLS & COL_TAU) && v.ta) ldpair(v.ta, i0, p[0].ta, p[1].ta);
+        if ((COLS & COL_TAU) && v.te) ldpair(v.te, i0, p[0].te, p[1].te);
+        if ((COLS & COL_TAU) && v.ti) ldpair(v.ti, i0, p[0].ti, p[1].ti);
+        const d2v ax = *reinterpret_cast<const d2v*>(v.ax + i0), ay = *reinterpret_cast<const d2v*>(v.ay + i0), az = *reinterpret_cast<const d2v*>(v.az + i0);
+        acc[0].x = ax.x; acc[1].x = ax.y; acc[0].y = ay.x; acc[1].y = ay.y; acc[0].z = az.x; acc[1].z = az.y;
+    } else {
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            if (!act[k] || i0 + k == op.src) continue;
-            V3 d, br;
-            if (op.kind == REBXAMD_OP_MOF) {
-                if (BACKREACT) {
-                    mof_particle<EXACT>(p[k], S, acc[k], br);
-                    bx += br.x; by += br.y; bz += br.z;
-                } else {
-                    V3 a;
-                    if (EXACT) mof_exact(p[k], S, a); else mof_fast(p[k], S, a);
-                    acc[k].x += a.x; acc[k].y += a.y; acc[k].z += a.z;
-                }
-            } else if (sourced_effect<EXACT>(op, p[k], S, G, d, br)) {
-#pragma clang fp contract(off)
-                acc[k].x += d.x; acc[k].y += d.y; acc[k].z += d.z;
-                if (BACKREACT) { bx += br.x; by += br.y; bz += br.z; }
+            if (!(k ? act1 : act0)) continue;
+            const long long i = i0 + k;
+            p[k].x = ldone(v.x, i); p[k].y = ldone(v.y, i); p[k].z = ldone(v.z, i);
+            if (COLS & COL_VEL) { p[k].vx = ldone(v.vx, i); p[k].vy = ldone(v.vy, i); p[k].vz = ldone(v.vz, i); }
+            if (BACKREACT) p[k].m = ldone(v.m, i);
+            if ((COLS & COL_BETA) && v.beta) p[k].beta = ldone(v.beta, i);
+            if ((COLS & COL_TIDES) && v.Rt) p[k].Rt = ldone(v.Rt, i);
+            if ((COLS & COL_TIDES) && v.k1) p[k].k1 = ldone(v.k1, i);
+            if ((COLS & COL_TAU) && v.ta) p[k].ta = ldone(v.ta, i);
+            if ((COLS & COL_TAU) && v.te) p[k].te = ldone(v.te, i);
+            if ((COLS & COL_TAU) && v.ti) p[k].ti = ldone(v.ti, i);
+            acc[k].x = v.ax[i]; acc[k].y = v.ay[i]; acc[k].z = v.az[i];
+        }
+    }
+
+    if (!BACKREACT) {
+        // one particle after the other keeps the live register set small
+        if (act0) tail_particle<EXACT>(prog, tab, p[0], acc[0], status);
+        if (act1) tail_particle<EXACT>(prog, tab, p[1], acc[1], status);
+    } else {
+        __shared__ StreamShared sh;
+        const int wave = tid >> 6, lane = tid & 63;
+        Geo g[2];
+        g[0].src = -1; g[0].dx = g[0].dy = g[0].dz = g[0].ri = 0.; g[1] = g[0];
+        const bool any_mass = __ballot((act0 && p[0].m != 0.) || (act1 && p[1].m != 0.)) != 0ull;
+        for (int o = 0; o < prog.nops; o++) {
+            const DevOp op = prog.ops[o];
+            const Src S = tab->src[o];
+            double bx = 0., by = 0., bz = 0.;
+            if (act0 && i0 != op.src) general_op<EXACT>(op, S, G, p[0], g[0], acc[0], bx, by, bz);
+            if (act1 && i0 + 1 != op.src) general_op<EXACT>(op, S, G, p[1], g[1], acc[1], bx, by, bz);
+            if (op.slot >= 0) {
+                // a wavefront whose bodies are all massless pushes on nothing
+                if (any_mass) { bx = wave_sum(bx); by = wave_sum(by); bz = wave_sum(bz); }
+                else { bx = by = bz = 0.; }
+                if (lane == 0) { sh.part[wave][op.slot][0] = bx; sh.part[wave][op.slot][1] = by; sh.part[wave][op.slot][2] = bz; }
             }
         }
-        if (BACKREACT && op.slot >= 0) {
-            // a wavefront whose bodies are all massless pushes on nothing
-            const bool any_mass = __ballot((act0 && p[0].m != 0.) || (act1 && p[1].m != 0.)) != 0ull;
-            if (any_mass) { bx = wave_sum(bx); by = wave_sum(by); bz = wave_sum(bz); }
-            else { bx = by = bz = 0.; }
-            if (lane == 0) { sh.part[wave][op.slot][0] = bx; sh.part[wave][op.slot][1] = by; sh.part[wave][op.slot][2] = bz; }
-        }
-    }
-
-    if (in0) {
-        if (VEC2 && act0 && act1) {
-            *reinterpret_cast<double2*>(v.ax + i0) = make_double2(acc[0].x, acc[1].x);
-            *reinterpret_cast<double2*>(v.ay + i0) = make_double2(acc[0].y, acc[1].y);
-            *reinterpret_cast<double2*>(v.az + i0) = make_double2(acc[0].z, acc[1].z);
-        } else {
-            if (act0) { v.ax[i0] = acc[0].x; v.ay[i0] = acc[0].y; v.az[i0] = acc[0].z; }
-            if (act1) { v.ax[i0 + 1] = acc[1].x; v.ay[i0 + 1] = acc[1].y; v.az[i0 + 1] = acc[1].z; }
-        }
-    }
-
-    if (BACKREACT && prog.nslots > 0) {
         __syncthreads();
         if (tid < prog.nslots * 3) {
             const int s = tid / 3, c = tid % 3;
@@ -501,6 +528,26 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(View v, Program prog, lon
             for (int w = 1; w < WAVES; w++) t += sh.part[w][s][c];
             partials[((long long)s * gridDim.x + blockIdx.x) * 3 + c] = t;
         }
+    }
+
+    if (full) {
+        d2v ax, ay, az;
+        ax.x = acc[0].x; ax.y = acc[1].x; ay.x = acc[0].y; ay.y = acc[1].y; az.x = acc[0].z; az.y = acc[1].z;
+        *reinterpret_cast<d2v*>(v.ax + i0) = ax;
+        *reinterpret_cast<d2v*>(v.ay + i0) = ay;
+        *reinterpret_cast<d2v*>(v.az + i0) = az;
+    } else {
+        if (act0) { v.ax[i0] = acc[0].x; v.ay[i0] = acc[0].y; v.az[i0] = acc[0].z; }
+        if (act1) { v.ax[i0 + 1] = acc[1].x; v.ay[i0 + 1] = acc[1].y; v.az[i0 + 1] = acc[1].z; }
+    }
+}
+
+// Fills the source table when no head pass runs (any mass layout).
+__global__ __launch_bounds__(64) void stage_kernel(View v, Program prog, HeadConsts* hc) {
+    const int t = threadIdx.x;
+    if (t < prog.nops) {
+        int s = prog.ops[t].src;
+        if (s >= 0) { Src S; load_src(v, s, S); hc->src[t] = S; }
     }
 }
 
@@ -561,6 +608,18 @@ hipError_t launch_head(const View& v, const Program& prog, HeadConsts* hc, unsig
     return hipGetLastError();
 }
 
+template <bool EXACT, bool BACKREACT>
+static void launch_stream_cols(dim3 g, dim3 b, hipStream_t st, bool vec2, int cols, const View& v, const Program& prog, long long lo,
+                               long long base, const HeadConsts* hc, double* partials, unsigned* status) {
+#define LAUNCH(V, C) hipLaunchKernelGGL((stream_kernel<EXACT, BACKREACT, V, C>), g, b, 0, st, v, prog, lo, base, hc, partials, status)
+    if (!vec2) { LAUNCH(false, COL_ALL); return; }
+    if (cols == 0) LAUNCH(true, 0);
+    else if ((cols & ~(COL_VEL | COL_BETA)) == 0) LAUNCH(true, COL_VEL | COL_BETA);
+    else if ((cols & ~(COL_VEL | COL_TIDES | COL_TAU)) == 0) LAUNCH(true, COL_VEL | COL_TIDES | COL_TAU);
+    else LAUNCH(true, COL_ALL);
+#undef LAUNCH
+}
+
 hipError_t launch_stream(const View& v, const Program& prog, long long lo, const HeadConsts* hc, double* partials,
                          int* nblocks_out, bool backreact, bool exact, bool vec2, unsigned* status, hipStream_t st) {
     const long long base = lo & ~1ll;
@@ -568,15 +627,19 @@ hipError_t launch_stream(const View& v, const Program& prog, long long lo, const
     if (nblocks_out) *nblocks_out = nb;
     if (nb <= 0) return hipSuccess;
     const dim3 g(nb), b(BLOCK);
-#define LAUNCH(E, B, V) hipLaunchKernelGGL((stream_kernel<E, B, V>), g, b, 0, st, v, prog, lo, base, hc, partials, status)
+    const int cols = (prog.need_vel ? COL_VEL : 0) | (prog.need_beta ? COL_BETA : 0) | (prog.need_tides ? COL_TIDES : 0) | (prog.need_tau ? COL_TAU : 0);
     if (exact) {
-        if (backreact) { if (vec2) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
-        else           { if (vec2) LAUNCH(true, false, true); else LAUNCH(true, false, false); }
+        if (backreact) launch_stream_cols<true, true>(g, b, st, vec2, cols, v, prog, lo, base, hc, partials, status);
+        else launch_stream_cols<true, false>(g, b, st, vec2, cols, v, prog, lo, base, hc, partials, status);
     } else {
-        if (backreact) { if (vec2) LAUNCH(false, true, true); else LAUNCH(false, true, false); }
-        else           { if (vec2) LAUNCH(false, false, true); else LAUNCH(false, false, false); }
+        if (backreact) launch_stream_cols<false, true>(g, b, st, vec2, cols, v, prog, lo, base, hc, partials, status);
+        else launch_stream_cols<false, false>(g, b, st, vec2, cols, v, prog, lo, base, hc, partials, status);
     }
-#undef LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_stage(const View& v, const Program& prog, HeadConsts* hc, hipStream_t st) {
+    hipLaunchKernelGGL(stage_kernel, dim3(1), dim3(64), 0, st, v, prog, hc);
     return hipGetLastError();
 }
 
