@@ -21,6 +21,7 @@ struct rebxamd_ctx {
     double* gf = nullptr;               // gr_full workspace
     size_t gf_cap = 0;
     unsigned* gf_flag = nullptr;
+    double* chunk_sums = nullptr;       // second-stage scratch of the back-reaction reduction
     // optional timing of the dominant kernels with HIP events on the launch stream
     bool timing = false;
     std::vector<hipEvent_t> ev;         // pairs: start, stop
@@ -73,6 +74,7 @@ extern "C" int rebxamd_create(int device, rebxamd_ctx** out) {
         hipMalloc((void**)&ctx->status, sizeof(unsigned)) != hipSuccess ||
         hipMalloc((void**)&ctx->ll, sizeof(long long)) != hipSuccess ||
         hipMalloc((void**)&ctx->gf_flag, sizeof(unsigned)) != hipSuccess ||
+        hipMalloc((void**)&ctx->chunk_sums, sizeof(double) * REBXAMD_MAX_OPS * 64 * 3) != hipSuccess ||
         hipMemset(ctx->hc, 0, sizeof(HeadConsts)) != hipSuccess ||
         hipMemset(ctx->status, 0, sizeof(unsigned)) != hipSuccess) {
         rebxamd_destroy(ctx);
@@ -92,6 +94,7 @@ extern "C" void rebxamd_destroy(rebxamd_ctx* ctx) {
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->gf) (void)hipFree(ctx->gf);
     if (ctx->gf_flag) (void)hipFree(ctx->gf_flag);
+    if (ctx->chunk_sums) (void)hipFree(ctx->chunk_sums);
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     delete ctx;
 }
@@ -288,7 +291,7 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
         TimedLaunch tl(ctx, st);
         HIP_TRY(launch_stream(v, prog, 0, ctx->hc, ctx->partials, &nblocks, nslots > 0, exact, vec2, ctx->status, st));
     }
-    if (nslots > 0) HIP_TRY(launch_finalize(v, prog, ctx->partials, nblocks, st));
+    if (nslots > 0) HIP_TRY(launch_finalize(v, prog, ctx->partials, nblocks, ctx->chunk_sums, st));
     return REBXAMD_OK;
 }
 

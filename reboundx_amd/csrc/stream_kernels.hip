@@ -25,6 +25,9 @@ namespace rebxamd {
 
 static constexpr int BLOCK = 256;
 static constexpr int WAVES = BLOCK / 64;
+#ifndef STREAM_WAVES_PER_SIMD
+#define STREAM_WAVES_PER_SIMD 4
+#endif
 
 // ------------------------------------------------------------------ small helpers
 
@@ -453,7 +456,7 @@ __device__ __forceinline__ void general_op(const DevOp& op, const Src& S, double
 struct StreamShared { double part[WAVES][REBXAMD_MAX_OPS][3]; };
 
 template <bool EXACT, bool BACKREACT, bool VEC2, int COLS>
-__global__ __launch_bounds__(BLOCK) void stream_kernel(View v, Program prog, long long lo, long long base,
+__global__ __launch_bounds__(BLOCK, (!EXACT && !BACKREACT && COLS != COL_ALL) ? 4 : 3) void stream_kernel(View v, Program prog, long long lo, long long base,
                                                        const HeadConsts* __restrict__ tab, double* partials, unsigned* status) {
     const int tid = threadIdx.x;
     const double G = prog.G;
@@ -552,27 +555,49 @@ __global__ __launch_bounds__(64) void stage_kernel(View v, Program prog, HeadCon
 }
 
 // ------------------------------------------------------------------ finalize: partials -> sources
-__global__ __launch_bounds__(BLOCK) void finalize_kernel(View v, Program prog, const double* partials, int nblocks) {
-    __shared__ double red[WAVES][3];
+// Two fixed-shape stages so that the result does not depend on timing: FIN_CHUNKS workgroups per
+// slot each fold a contiguous range of the per-workgroup partials, then one workgroup folds the
+// chunk sums slot by slot (in op order) and adds each total to its source particle.
+static constexpr int FIN_CHUNKS = 64;
+
+__device__ __forceinline__ void block_sum3(double& x, double& y, double& z, double (*red)[3]) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    x = wave_sum(x); y = wave_sum(y); z = wave_sum(z);
+    __syncthreads();
+    if (lane == 0) { red[wave][0] = x; red[wave][1] = y; red[wave][2] = z; }
+    __syncthreads();
+    x = red[0][0]; y = red[0][1]; z = red[0][2];
+    for (int w = 1; w < WAVES; w++) { x += red[w][0]; y += red[w][1]; z += red[w][2]; }
+}
+
+__global__ __launch_bounds__(BLOCK) void finalize_stage1(const double* partials, int nblocks, double* chunk_sums) {
+    __shared__ double red[WAVES][3];
+    const int s = blockIdx.y, c = blockIdx.x;
+    const int per = (nblocks + FIN_CHUNKS - 1) / FIN_CHUNKS;
+    const int b0 = c * per, b1 = (b0 + per < nblocks) ? b0 + per : nblocks;
+    double x = 0., y = 0., z = 0.;
+    for (int b = b0 + threadIdx.x; b < b1; b += BLOCK) {
+        const double* q = partials + ((long long)s * nblocks + b) * 3;
+        x += q[0]; y += q[1]; z += q[2];
+    }
+    block_sum3(x, y, z, red);
+    if (threadIdx.x == 0) {
+        double* o = chunk_sums + ((long long)s * FIN_CHUNKS + c) * 3;
+        o[0] = x; o[1] = y; o[2] = z;
+    }
+}
+
+__global__ __launch_bounds__(64) void finalize_stage2(View v, Program prog, const double* chunk_sums) {
+    const int lane = threadIdx.x;
     for (int o = 0; o < prog.nops; o++) {
         const int s = prog.ops[o].slot;
         if (s < 0) continue;
-        double x = 0., y = 0., z = 0.;
-        for (int b = tid; b < nblocks; b += BLOCK) {
-            const double* q = partials + ((long long)s * nblocks + b) * 3;
-            x += q[0]; y += q[1]; z += q[2];
-        }
-        x = wave_sum(x); y = wave_sum(y); z = wave_sum(z);
-        if (lane == 0) { red[wave][0] = x; red[wave][1] = y; red[wave][2] = z; }
-        __syncthreads();
-        if (tid == 0) {
-            double tx = red[0][0], ty = red[0][1], tz = red[0][2];
-            for (int w = 1; w < WAVES; w++) { tx += red[w][0]; ty += red[w][1]; tz += red[w][2]; }
+        const double* q = chunk_sums + ((long long)s * FIN_CHUNKS + lane) * 3;
+        const double x = wave_sum(q[0]), y = wave_sum(q[1]), z = wave_sum(q[2]);
+        if (lane == 0) {
             const int src = prog.ops[o].src;
-            v.ax[src] += tx; v.ay[src] += ty; v.az[src] += tz;
+            v.ax[src] += x; v.ay[src] += y; v.az[src] += z;
         }
-        __syncthreads();
     }
 }
 
@@ -643,8 +668,10 @@ hipError_t launch_stage(const View& v, const Program& prog, HeadConsts* hc, hipS
     return hipGetLastError();
 }
 
-hipError_t launch_finalize(const View& v, const Program& prog, const double* partials, int nblocks, hipStream_t st) {
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(BLOCK), 0, st, v, prog, partials, nblocks);
+hipError_t launch_finalize(const View& v, const Program& prog, const double* partials, int nblocks, double* chunk_sums, hipStream_t st) {
+    static_assert(FIN_CHUNKS == 64, "stage 2 folds the chunk sums with one wavefront");
+    hipLaunchKernelGGL(finalize_stage1, dim3(FIN_CHUNKS, prog.nslots), dim3(BLOCK), 0, st, partials, nblocks, chunk_sums);
+    hipLaunchKernelGGL(finalize_stage2, dim3(1), dim3(64), 0, st, v, prog, chunk_sums);
     return hipGetLastError();
 }
 
