@@ -1,0 +1,799 @@
+// host_api.hip -- the plugin API (group A of reboundx_amd.h): the reference's object model
+// (linked lists of named, typed parameters hanging off particles and forces), its force
+// factory, and the additional-force dispatch -- with the arithmetic handed to the device.
+//
+// The linked lists stay the single source of truth, exactly as laid out by the reference, so
+// C programs and ctypes bindings can keep walking them.  What changes is who reads them on
+// the hot path: instead of 1-5 strcmp walks per particle per force per call, the lists are
+// flattened once per parameter change into fp64 columns (NaN = not set) plus short lists of
+// source particles, which live on the GPU; every call then only moves positions, velocities,
+// masses and accelerations.
+#include "internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <chrono>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#define STRINGIFY2(s) #s
+#define STRINGIFY(s) STRINGIFY2(s)
+#ifndef REBXGITHASH
+#define REBXGITHASH rebxamd0000000000000000000000000000000001
+#endif
+
+extern "C" {
+const char* rebx_build_str = __DATE__ " " __TIME__;
+const char* rebx_version_str = "3.0.4";             // the reference version whose API this library speaks
+const char* rebx_githash_str = STRINGIFY(REBXGITHASH);
+}
+
+// ------------------------------------------------------------------ standalone message channel
+#ifndef REBXAMD_WITH_REBOUND
+static void push_message(struct reb_simulation* r, char kind, const char* msg) {
+    if (!r) { fprintf(stderr, "%s\n", msg); return; }
+    char** grown = (char**)realloc(r->messages, sizeof(char*) * (size_t)(r->n_messages + 1));
+    if (!grown) return;
+    r->messages = grown;
+    const size_t len = strlen(msg);
+    char* copy = (char*)malloc(len + 2);
+    if (!copy) return;
+    copy[0] = kind;
+    memcpy(copy + 1, msg, len + 1);
+    r->messages[r->n_messages++] = copy;
+}
+extern "C" void reb_error(struct reb_simulation* r, const char* msg) { push_message(r, 'e', msg); }
+extern "C" void reb_warning(struct reb_simulation* r, const char* msg) { push_message(r, 'w', msg); }
+extern "C" int rebxamd_pop_message(struct reb_simulation* r, char* buf, int len) {
+    if (!r || r->n_messages <= 0 || !buf || len <= 0) return 0;
+    char* m = r->messages[0];
+    const int kind = m[0] == 'e' ? 2 : 1;
+    strncpy(buf, m + 1, (size_t)len - 1);
+    buf[len - 1] = '\0';
+    free(m);
+    memmove(r->messages, r->messages + 1, sizeof(char*) * (size_t)(r->n_messages - 1));
+    r->n_messages--;
+    return kind;
+}
+extern "C" void rebxamd_clear_messages(struct reb_simulation* r) {
+    if (!r) return;
+    for (int i = 0; i < r->n_messages; i++) free(r->messages[i]);
+    free(r->messages);
+    r->messages = nullptr;
+    r->n_messages = 0;
+}
+#endif
+
+using rebxamd::WARN_GR_ITER;
+using rebxamd::WARN_GRFULL_SWEEPS;
+
+// ------------------------------------------------------------------ per-extras device state
+namespace {
+
+enum { H_X, H_Y, H_Z, H_VX, H_VY, H_VZ, H_M, H_AX, H_AY, H_AZ, H_NDYN };
+enum { P_BETA, P_RT, P_K1, P_TA, P_TE, P_TI, P_NPAR };
+static const char* const kParamName[P_NPAR] = {"beta", "R_tides", "k1", "tau_a", "tau_e", "tau_inc"};
+
+struct SourceJ { int idx; double J, Req; };
+struct SourceC { int idx; double A, gamma; };
+
+struct Bridge {
+    rebxamd_ctx* ctx = nullptr;
+    int mode = REBXAMD_MODE_FAST;
+    unsigned long long generation = 1;      // bumped by every API call that can change a parameter list
+    // staging
+    size_t cap = 0;
+    double* h_dyn[H_NDYN] = {};             // pinned host columns
+    double* d_dyn[H_NDYN] = {};
+    double* h_par[P_NPAR] = {};             // pageable host columns (rebuilt rarely)
+    double* d_par[P_NPAR] = {};
+    bool par_used[P_NPAR] = {};             // column has at least one value set
+    // validity of the flattened parameters
+    unsigned long long built_generation = 0;
+    int built_n = -1;
+    unsigned long long built_checksum = 0;
+    // sparse per-particle parameters (sources)
+    std::vector<int> radiation_sources, tides_primaries;
+    int first_primary = -1;
+    std::vector<SourceJ> j2, j4;
+    std::vector<SourceC> central;
+    double timings[4] = {0, 0, 0, 0};
+};
+
+std::mutex g_mu;
+std::unordered_map<const rebx_extras*, Bridge*> g_bridges;
+
+Bridge* bridge_of(const rebx_extras* rebx, bool create) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_bridges.find(rebx);
+    if (it != g_bridges.end()) return it->second;
+    if (!create) return nullptr;
+    Bridge* b = new Bridge();
+    g_bridges[rebx] = b;
+    return b;
+}
+
+void touch(const rebx_extras* rebx) {
+    if (Bridge* b = bridge_of(rebx, true)) b->generation++;
+}
+
+void release_buffers(Bridge* b) {
+    for (int k = 0; k < H_NDYN; k++) {
+        if (b->h_dyn[k]) (void)hipHostFree(b->h_dyn[k]);
+        if (b->d_dyn[k]) (void)hipFree(b->d_dyn[k]);
+        b->h_dyn[k] = b->d_dyn[k] = nullptr;
+    }
+    for (int k = 0; k < P_NPAR; k++) {
+        free(b->h_par[k]);
+        if (b->d_par[k]) (void)hipFree(b->d_par[k]);
+        b->h_par[k] = b->d_par[k] = nullptr;
+    }
+    b->cap = 0;
+    b->built_n = -1;
+}
+
+void drop_bridge(const rebx_extras* rebx) {
+    Bridge* b = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        auto it = g_bridges.find(rebx);
+        if (it == g_bridges.end()) return;
+        b = it->second;
+        g_bridges.erase(it);
+    }
+    if (b->ctx) {
+        release_buffers(b);
+        rebxamd_destroy(b->ctx);
+    }
+    delete b;
+}
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ lists (reference src/linkedlist.c)
+static void list_push_front(struct rebx_node** head, struct rebx_node* node) {      // :33-37
+    node->next = *head;
+    *head = node;
+}
+
+static int list_remove_object(struct rebx_node** head, void* object) {              // :71-95
+    for (struct rebx_node** link = head; *link; link = &(*link)->next) {
+        if ((*link)->object == object) {
+            struct rebx_node* dead = *link;
+            *link = dead->next;
+            free(dead);
+            return 1;
+        }
+    }
+    return 0;
+}
+
+extern "C" int rebx_len(struct rebx_node* head) {                                   // :97-106
+    int n = 0;
+    for (; head; head = head->next) n++;
+    return n;
+}
+
+// ------------------------------------------------------------------ errors, memory
+extern "C" void rebx_error(struct rebx_extras* rebx, const char* const msg) {       // src/core.c:1003-1010
+    if (!rebx || rebx->sim == NULL) {
+        fprintf(stderr, "REBOUNDx Error: A Simulation is no longer attached to this REBOUNDx extras instance. Most likely the Simulation has been freed.\n");
+        return;
+    }
+    reb_error(rebx->sim, msg);
+}
+
+static void* checked_malloc(struct rebx_extras* rebx, size_t bytes) {               // src/core.c:730-738
+    void* p = malloc(bytes);
+    if (!p && bytes > 0) rebx_error(rebx, "REBOUNDx Error: Could not allocate memory.\n");
+    return p;
+}
+
+static char* dup_name(struct rebx_extras* rebx, const char* name) {
+    char* c = (char*)checked_malloc(rebx, strlen(name) + 1);
+    if (c) strcpy(c, name);
+    return c;
+}
+
+static struct rebx_node* new_node(struct rebx_extras* rebx, void* object) {         // src/core.c:918-926
+    struct rebx_node* n = (struct rebx_node*)checked_malloc(rebx, sizeof(*n));
+    if (n) { n->object = object; n->next = NULL; }
+    return n;
+}
+
+static void free_param(struct rebx_param* p, bool owns_value) {                     // src/core.c:740-751, :792-797
+    free(p->name);
+    // numeric values were allocated by the setters; pointers and forces are borrowed
+    if (owns_value && (p->type == REBX_TYPE_INT || p->type == REBX_TYPE_DOUBLE || p->type == REBX_TYPE_UINT32)) free(p->value);
+    free(p);
+}
+
+static void free_param_list(struct rebx_node** ap) {                                // src/core.c:753-762
+    struct rebx_node* cur = *ap;
+    while (cur) {
+        struct rebx_node* next = cur->next;
+        free_param((struct rebx_param*)cur->object, true);
+        free(cur);
+        cur = next;
+    }
+    *ap = NULL;
+}
+
+extern "C" void rebx_free_particle_ap(struct reb_particle* p) {                     // src/core.c:764-766
+    struct rebx_node* head = (struct rebx_node*)p->ap;
+    free_param_list(&head);
+    p->ap = NULL;
+    if (p->sim && p->sim->extras) touch((const rebx_extras*)p->sim->extras);
+}
+
+// ------------------------------------------------------------------ parameter registry and access
+extern "C" struct rebx_param* rebx_get_param_struct(struct rebx_extras*, struct rebx_node* ap, const char* const param_name) {
+    for (; ap; ap = ap->next) {                                                     // src/core.c:601-612
+        struct rebx_param* p = (struct rebx_param*)ap->object;
+        if (strcmp(p->name, param_name) == 0) return p;
+    }
+    return NULL;
+}
+
+extern "C" void* rebx_get_param(struct rebx_extras* rebx, struct rebx_node* ap, const char* const param_name) {
+    struct rebx_param* p = rebx_get_param_struct(rebx, ap, param_name);             // src/core.c:614-622
+    return p ? p->value : NULL;
+}
+
+extern "C" enum rebx_param_type rebx_get_type(struct rebx_extras* rebx, const char* name) {
+    struct rebx_param* p = rebx_get_param_struct(rebx, rebx->registered_params, name);   // src/core.c:958-966
+    return p ? p->type : REBX_TYPE_NONE;
+}
+
+static struct rebx_param* new_param(struct rebx_extras* rebx, const char* name, enum rebx_param_type type) {
+    struct rebx_param* p = (struct rebx_param*)checked_malloc(rebx, sizeof(*p));    // src/core.c:928-945
+    if (!p) return NULL;
+    p->type = type;
+    p->value = NULL;
+    p->name = dup_name(rebx, name);
+    if (!p->name) { free(p); return NULL; }
+    return p;
+}
+
+extern "C" void rebx_register_param(struct rebx_extras* const rebx, const char* name, enum rebx_param_type type) {
+    if (rebx_get_type(rebx, name) != REBX_TYPE_NONE) {                              // src/core.c:94-117
+        char str[300];
+        snprintf(str, sizeof(str), "REBOUNDx Error: Parameter name '%s' already in registered list. Cannot add duplicates.\n", name);
+        rebx_error(rebx, str);
+        return;
+    }
+    struct rebx_param* p = new_param(rebx, name, type);
+    if (!p) return;
+    struct rebx_node* n = new_node(rebx, p);
+    if (!n) { free_param(p, false); return; }
+    list_push_front(&rebx->registered_params, n);
+}
+
+extern "C" void rebx_register_default_params(struct rebx_extras* rebx) {            // src/core.c:51-92
+    static const struct { const char* name; enum rebx_param_type type; } defaults[] = {
+        {"c", REBX_TYPE_DOUBLE}, {"gr_source", REBX_TYPE_INT}, {"tau_mass", REBX_TYPE_DOUBLE}, {"force", REBX_TYPE_FORCE},
+        {"particle", REBX_TYPE_POINTER}, {"Acentral", REBX_TYPE_DOUBLE}, {"gammacentral", REBX_TYPE_DOUBLE},
+        {"max_iterations", REBX_TYPE_INT}, {"J2", REBX_TYPE_DOUBLE}, {"J4", REBX_TYPE_DOUBLE}, {"R_eq", REBX_TYPE_DOUBLE},
+        {"coordinates", REBX_TYPE_INT}, {"p", REBX_TYPE_DOUBLE}, {"tau_a", REBX_TYPE_DOUBLE}, {"tau_e", REBX_TYPE_DOUBLE},
+        {"tau_inc", REBX_TYPE_DOUBLE}, {"tau_omega", REBX_TYPE_DOUBLE}, {"tau_Omega", REBX_TYPE_DOUBLE}, {"primary", REBX_TYPE_INT},
+        {"radiation_source", REBX_TYPE_INT}, {"beta", REBX_TYPE_DOUBLE}, {"tides_primary", REBX_TYPE_INT},
+        {"R_tides", REBX_TYPE_DOUBLE}, {"k1", REBX_TYPE_DOUBLE}, {"integrator", REBX_TYPE_INT}, {"free_arrays", REBX_TYPE_POINTER},
+        {"im_ps_final", REBX_TYPE_POINTER}, {"im_ps_prev", REBX_TYPE_POINTER}, {"im_ps_avg", REBX_TYPE_POINTER},
+        {"rk2_k2", REBX_TYPE_POINTER}, {"rk4_k2", REBX_TYPE_POINTER}, {"rk4_k3", REBX_TYPE_POINTER},
+        {"min_distance", REBX_TYPE_DOUBLE}, {"min_distance_from", REBX_TYPE_UINT32}, {"min_distance_orbit", REBX_TYPE_ORBIT},
+        {"N_ephem", REBX_TYPE_INT}, {"N_ast", REBX_TYPE_INT}, {"geocentric", REBX_TYPE_INT}, {"outstate", REBX_TYPE_POINTER},
+        {"n_out", REBX_TYPE_INT},
+    };
+    for (const auto& d : defaults) rebx_register_param(rebx, d.name, d.type);
+}
+
+// existing parameter of that name, or a fresh one pushed on the list (src/core.c:512-541)
+static struct rebx_param* find_or_add(struct rebx_extras* const rebx, struct rebx_node** apptr, const char* const name) {
+    if (apptr == NULL) {
+        rebx_error(rebx, "REBOUNDx Error: Passed NULL apptr to rebx_add_param. See examples.\n");
+        return NULL;
+    }
+    const enum rebx_param_type type = rebx_get_type(rebx, name);
+    if (type == REBX_TYPE_NONE) {
+        char str[300];
+        snprintf(str, sizeof(str), "REBOUNDx Error: Need to register parameter name '%s' before using it. See examples.\n", name);
+        rebx_error(rebx, str);
+        return NULL;
+    }
+    struct rebx_param* p = rebx_get_param_struct(rebx, *apptr, name);
+    if (p) return p;
+    p = new_param(rebx, name, type);
+    if (!p) return NULL;
+    struct rebx_node* n = new_node(rebx, p);
+    if (!n) { free_param(p, false); return NULL; }
+    list_push_front(apptr, n);
+    return p;
+}
+
+template <typename T>
+static void set_numeric(struct rebx_extras* const rebx, struct rebx_node** apptr, const char* const name, T val) {
+    struct rebx_param* p = find_or_add(rebx, apptr, name);                          // src/core.c:552-595
+    if (!p) return;
+    if (p->value == NULL) p->value = checked_malloc(rebx, sizeof(T));
+    if (p->value) *(T*)p->value = val;
+    touch(rebx);
+}
+
+extern "C" void rebx_set_param_double(struct rebx_extras* const rebx, struct rebx_node** apptr, const char* const name, double val) { set_numeric<double>(rebx, apptr, name, val); }
+extern "C" void rebx_set_param_int(struct rebx_extras* const rebx, struct rebx_node** apptr, const char* const name, int val) { set_numeric<int>(rebx, apptr, name, val); }
+extern "C" void rebx_set_param_uint32(struct rebx_extras* const rebx, struct rebx_node** apptr, const char* const name, uint32_t val) { set_numeric<uint32_t>(rebx, apptr, name, val); }
+extern "C" void rebx_set_param_pointer(struct rebx_extras* const rebx, struct rebx_node** apptr, const char* const name, void* val) {
+    struct rebx_param* p = find_or_add(rebx, apptr, name);                          // src/core.c:543-550
+    if (!p) return;
+    p->value = val;
+    touch(rebx);
+}
+
+// ------------------------------------------------------------------ attach / detach / free
+extern "C" void rebx_extras_cleanup(struct reb_simulation* sim) {                   // src/core.c:130-133
+    struct rebx_extras* rebx = (struct rebx_extras*)sim->extras;
+    if (rebx) rebx->sim = NULL;
+}
+
+extern "C" void rebx_initialize(struct reb_simulation* sim, struct rebx_extras* rebx) {   // src/core.c:158-178
+    rebx->sim = sim;
+    if (rebx->sim == NULL) { rebx_error(rebx, ""); return; }
+    sim->extras = rebx;
+    rebx->additional_forces = NULL;
+    rebx->pre_timestep_modifications = NULL;
+    rebx->post_timestep_modifications = NULL;
+    rebx->allocated_forces = NULL;
+    rebx->allocated_operators = NULL;
+    rebx->registered_params = NULL;
+    sim->free_particle_ap = rebx_free_particle_ap;
+    sim->extras_cleanup = rebx_extras_cleanup;
+    if (sim->additional_forces || sim->pre_timestep_modifications || sim->post_timestep_modifications) {
+        reb_warning(sim, "REBOUNDx overwrites sim->additional_forces, sim->pre_timestep_modifications and sim->post_timestep_modifications whenever forces or operators that use them get added.  If you want to use REBOUNDx together with your own custom functions that use these callbacks, you should add them through REBOUNDx.");
+    }
+}
+
+extern "C" struct rebx_extras* rebx_attach(struct reb_simulation* sim) {            // src/core.c:119-128
+    if (sim == NULL) {
+        fprintf(stderr, "REBOUNDx Error: Simulation pointer passed to rebx_attach was NULL.\n");
+        return NULL;
+    }
+    struct rebx_extras* rebx = (struct rebx_extras*)malloc(sizeof(*rebx));
+    if (!rebx) return NULL;
+    rebx_initialize(sim, rebx);
+    rebx_register_default_params(rebx);
+    return rebx;
+}
+
+extern "C" void rebx_detach(struct reb_simulation* sim, struct rebx_extras* rebx) { // src/core.c:135-155
+    if (sim == NULL) return;
+    rebx->sim = NULL;
+    if (sim->extras == rebx) {          // only un-hook what is still ours
+        if (sim->additional_forces == rebx_additional_forces) sim->additional_forces = NULL;
+        if (sim->free_particle_ap == rebx_free_particle_ap) sim->free_particle_ap = NULL;
+    }
+}
+
+static void free_force(struct rebx_extras* rebx, struct rebx_force* force) {        // src/core.c:768-778
+    typedef void (*destructor)(struct rebx_extras*, struct rebx_force*);
+    destructor free_arrays = (destructor)rebx_get_param(rebx, force->ap, "free_arrays");
+    if (free_arrays) free_arrays(rebx, force);
+    free(force->name);
+    free_param_list(&force->ap);
+    free(force);
+}
+
+extern "C" void rebx_free_pointers(struct rebx_extras* rebx) {                      // src/core.c:799-854
+    if (rebx == NULL) return;
+    rebx_detach(rebx->sim, rebx);
+    for (struct rebx_node* cur = rebx->allocated_forces; cur;) {
+        struct rebx_node* next = cur->next;
+        free_force(rebx, (struct rebx_force*)cur->object);
+        free(cur);
+        cur = next;
+    }
+    rebx->allocated_forces = NULL;
+    for (struct rebx_node* cur = rebx->additional_forces; cur;) {
+        struct rebx_node* next = cur->next;
+        free(cur);
+        cur = next;
+    }
+    rebx->additional_forces = NULL;
+    for (struct rebx_node* cur = rebx->registered_params; cur;) {
+        struct rebx_node* next = cur->next;
+        free_param((struct rebx_param*)cur->object, false);
+        free(cur);
+        cur = next;
+    }
+    rebx->registered_params = NULL;
+    drop_bridge(rebx);                  // device buffers and context
+}
+
+extern "C" void rebx_free(struct rebx_extras* rebx) {                               // src/core.c:180-183
+    rebx_free_pointers(rebx);
+    free(rebx);
+}
+
+// ------------------------------------------------------------------ forces
+extern "C" struct rebx_force* rebx_create_force(struct rebx_extras* const rebx, const char* name) {   // src/core.c:189-225
+    if (rebx->sim == NULL) { rebx_error(rebx, ""); return NULL; }
+    struct rebx_force* force = (struct rebx_force*)checked_malloc(rebx, sizeof(*force));
+    if (!force) return NULL;
+    force->ap = NULL;
+    force->sim = rebx->sim;
+    force->force_type = REBX_FORCE_NONE;
+    force->update_accelerations = NULL;
+    force->name = NULL;
+    if (name != NULL) {
+        force->name = dup_name(rebx, name);
+        if (!force->name) { free(force); return NULL; }
+    }
+    struct rebx_node* n = new_node(rebx, force);
+    if (!n) { free(force->name); free(force); return NULL; }
+    list_push_front(&rebx->allocated_forces, n);
+    return force;
+}
+
+namespace {
+struct Builtin {
+    const char* name;
+    void (*fn)(struct reb_simulation* const, struct rebx_force* const, struct reb_particle* const, const int);
+    enum rebx_force_type type;
+};
+const Builtin kBuiltins[] = {                                                       // src/core.c:232-263
+    {"gr", rebx_gr, REBX_FORCE_VEL},
+    {"central_force", rebx_central_force, REBX_FORCE_POS},
+    {"modify_orbits_forces", rebx_modify_orbits_forces, REBX_FORCE_VEL},
+    {"gr_full", rebx_gr_full, REBX_FORCE_VEL},
+    {"gravitational_harmonics", rebx_gravitational_harmonics, REBX_FORCE_POS},
+    {"gr_potential", rebx_gr_potential, REBX_FORCE_POS},
+    {"radiation_forces", rebx_radiation_forces, REBX_FORCE_VEL},
+    {"tides_precession", rebx_tides_precession, REBX_FORCE_POS},
+};
+const Builtin* builtin_of(const struct rebx_force* f) {
+    for (const Builtin& b : kBuiltins)
+        if (f->update_accelerations == b.fn) return &b;
+    return nullptr;
+}
+}  // namespace
+
+extern "C" int rebx_remove_force(struct rebx_extras* rebx, struct rebx_force* force) {      // src/core.c:654-662
+    const int allocated = list_remove_object(&rebx->allocated_forces, force);
+    const int success = list_remove_object(&rebx->additional_forces, force);
+    if (allocated) free_force(rebx, force);
+    touch(rebx);
+    return success;
+}
+
+extern "C" struct rebx_force* rebx_load_force(struct rebx_extras* const rebx, const char* name) {     // src/core.c:227-277
+    struct rebx_force* force = rebx_create_force(rebx, name);
+    if (!force) return NULL;
+    for (const Builtin& b : kBuiltins) {
+        if (strcmp(name, b.name) == 0) {
+            force->update_accelerations = b.fn;
+            force->force_type = b.type;
+            return force;
+        }
+    }
+    char str[300];
+    snprintf(str, sizeof(str), "REBOUNDx error: Force '%s' not found in REBOUNDx library.\n", name);
+    rebx_error(rebx, str);
+    rebx_remove_force(rebx, force);
+    return NULL;
+}
+
+extern "C" int rebx_add_force(struct rebx_extras* rebx, struct rebx_force* force) {         // src/core.c:371-409
+    if (rebx->sim == NULL) { rebx_error(rebx, ""); return 0; }
+    if (force == NULL) { rebx_error(rebx, "REBOUNDx error: Passed NULL pointer to rebx_add_force.\n"); return 0; }
+    if (force->update_accelerations == NULL) {
+        rebx_error(rebx, "REBOUNDx error: Need to set update_accelerations function pointer on force before calling rebx_add_force. See custom effects example.\n");
+        return 0;
+    }
+    if (force->force_type == REBX_FORCE_NONE) {
+        rebx_error(rebx, "REBOUNDx error: Need to set force_type field on force before calling rebx_add_force. See custom effects example.\n");
+        return 0;
+    }
+    if (force->force_type == REBX_FORCE_VEL) rebx->sim->force_is_velocity_dependent = 1;
+    struct rebx_node* n = new_node(rebx, force);
+    if (!n) return 0;
+    list_push_front(&rebx->additional_forces, n);       // head insertion: forces run in reverse order of addition
+    if (rebx->sim->additional_forces != NULL && rebx->sim->additional_forces != rebx_additional_forces) {
+        reb_warning(rebx->sim, "REBOUNDx Warning: additional_forces was set and is being overwritten by REBOUNDx. To incorporate both, you can add your own custom effects through REBOUNDx.\n");
+    }
+    rebx->sim->additional_forces = rebx_additional_forces;
+    touch(rebx);
+    return 1;
+}
+
+extern "C" struct rebx_force* rebx_get_force(struct rebx_extras* const rebx, const char* const name) {    // src/core.c:624-635
+    for (struct rebx_node* cur = rebx->allocated_forces; cur; cur = cur->next) {
+        struct rebx_force* f = (struct rebx_force*)cur->object;
+        if (f->name && strcmp(f->name, name) == 0) return f;
+    }
+    return NULL;
+}
+
+extern "C" void rebx_reset_accelerations(struct reb_particle* const ps, const int N) {      // src/core.c:860-866
+    for (int i = 0; i < N; i++) { ps[i].ax = 0.; ps[i].ay = 0.; ps[i].az = 0.; }
+}
+
+extern "C" double rebx_rad_calc_beta(const double G, const double c, const double source_mass, const double source_luminosity,
+                                     const double radius, const double density, const double Q_pr) {        // src/radiation_forces.c:119-121
+    return 3. * source_luminosity * Q_pr / (16. * 3.14159265358979323846 * G * source_mass * c * density * radius);
+}
+extern "C" double rebx_rad_calc_particle_radius(const double G, const double c, const double source_mass, const double source_luminosity,
+                                                const double beta, const double density, const double Q_pr) { // src/radiation_forces.c:122-124
+    return 3. * source_luminosity * Q_pr / (16. * 3.14159265358979323846 * G * source_mass * c * density * beta);
+}
+
+// ------------------------------------------------------------------ extensions
+extern "C" void rebxamd_invalidate_params(struct rebx_extras* rebx) { touch(rebx); }
+extern "C" void rebxamd_set_mode(struct rebx_extras* rebx, int mode) {
+    if (Bridge* b = bridge_of(rebx, true)) b->mode = mode ? REBXAMD_MODE_EXACT : REBXAMD_MODE_FAST;
+}
+extern "C" void rebxamd_last_timings(struct rebx_extras* rebx, double out_ms[4]) {
+    Bridge* b = bridge_of(rebx, false);
+    for (int k = 0; k < 4; k++) out_ms[k] = b ? b->timings[k] : 0.;
+}
+
+// ------------------------------------------------------------------ host AoS <-> device columns
+namespace {
+
+bool ensure_capacity(struct rebx_extras* rebx, Bridge* b, size_t n) {
+    if (!b->ctx) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (rebxamd_create(dev, &b->ctx) != REBXAMD_OK) {
+            rebx_error(rebx, "REBOUNDx (MI355X) Error: no usable GPU: the additional-force path has no CPU fallback.\n");
+            b->ctx = nullptr;
+            return false;
+        }
+    }
+    if (n <= b->cap) return true;
+    release_buffers(b);
+    const size_t cap = n + n / 8 + 64;
+    for (int k = 0; k < H_NDYN; k++) {
+        if (hipHostMalloc((void**)&b->h_dyn[k], cap * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+            hipMalloc((void**)&b->d_dyn[k], cap * sizeof(double)) != hipSuccess) {
+            rebx_error(rebx, "REBOUNDx (MI355X) Error: could not allocate staging buffers.\n");
+            release_buffers(b);
+            return false;
+        }
+    }
+    for (int k = 0; k < P_NPAR; k++) {
+        b->h_par[k] = (double*)malloc(cap * sizeof(double));
+        if (!b->h_par[k] || hipMalloc((void**)&b->d_par[k], cap * sizeof(double)) != hipSuccess) {
+            rebx_error(rebx, "REBOUNDx (MI355X) Error: could not allocate parameter columns.\n");
+            release_buffers(b);
+            return false;
+        }
+    }
+    b->cap = cap;
+    return true;
+}
+
+// Flattens every particle's parameter list: six dense columns (NaN = not set) and the short
+// lists of source-type parameters.  One walk per list, no matter how many forces are stacked.
+void flatten_params(struct rebx_extras* rebx, Bridge* b, const struct reb_particle* ps, int N) {
+    const double nan = std::nan("");
+    for (int k = 0; k < P_NPAR; k++) {
+        b->par_used[k] = false;
+        for (int i = 0; i < N; i++) b->h_par[k][i] = nan;
+    }
+    b->radiation_sources.clear(); b->tides_primaries.clear(); b->j2.clear(); b->j4.clear(); b->central.clear();
+    b->first_primary = -1;
+    for (int i = 0; i < N; i++) {
+        const double *J2 = nullptr, *J4 = nullptr, *Req = nullptr, *A = nullptr, *gam = nullptr;
+        for (const struct rebx_node* node = (const struct rebx_node*)ps[i].ap; node; node = node->next) {
+            const struct rebx_param* p = (const struct rebx_param*)node->object;
+            const char* name = p->name;
+            bool dense = false;
+            for (int k = 0; k < P_NPAR; k++) {
+                if (strcmp(name, kParamName[k]) == 0) {
+                    // the first match in list order wins, as a linear search would find it
+                    if (p->value && std::isnan(b->h_par[k][i])) { b->h_par[k][i] = *(const double*)p->value; b->par_used[k] = true; }
+                    dense = true;
+                    break;
+                }
+            }
+            if (dense) continue;
+            if (!strcmp(name, "J2")) { if (!J2) J2 = (const double*)p->value; }
+            else if (!strcmp(name, "J4")) { if (!J4) J4 = (const double*)p->value; }
+            else if (!strcmp(name, "R_eq")) { if (!Req) Req = (const double*)p->value; }
+            else if (!strcmp(name, "Acentral")) { if (!A) A = (const double*)p->value; }
+            else if (!strcmp(name, "gammacentral")) { if (!gam) gam = (const double*)p->value; }
+            else if (!strcmp(name, "radiation_source")) { if (p->value && (b->radiation_sources.empty() || b->radiation_sources.back() != i)) b->radiation_sources.push_back(i); }
+            else if (!strcmp(name, "tides_primary")) { if (p->value && (b->tides_primaries.empty() || b->tides_primaries.back() != i)) b->tides_primaries.push_back(i); }
+            else if (!strcmp(name, "primary")) { if (p->value && b->first_primary < 0) b->first_primary = i; }
+        }
+        if (J2 && Req) b->j2.push_back({i, *J2, *Req});
+        if (J4 && Req) b->j4.push_back({i, *J4, *Req});
+        if (A && gam) b->central.push_back({i, *A, *gam});
+    }
+}
+
+struct Pending { struct rebx_force* force; const Builtin* builtin; };
+
+// Translates one built-in force into elementary ops; false (after reporting through the
+// simulation's message channel) when a required parameter is missing.
+bool ops_of_force(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* b, const Pending& pf, std::vector<rebxamd_op>& ops) {
+    auto add = [&](int kind, int src, int iarg, double a, double bb) {
+        rebxamd_op o; o.kind = kind; o.src = src; o.iarg = iarg; o.reserved = 0; o.a = a; o.b = bb; ops.push_back(o);
+    };
+    struct rebx_force* f = pf.force;
+    const auto fn = pf.builtin->fn;
+    const double* c = (const double*)rebx_get_param(rebx, f->ap, "c");
+    if (fn == rebx_radiation_forces) {
+        if (!c) { reb_error(sim, "Need to set speed of light in radiation_forces effect.  See examples in documentation.\n"); return false; }
+        if (b->radiation_sources.empty()) add(REBXAMD_OP_RADIATION, 0, 0, *c, 0.);
+        for (int s : b->radiation_sources) add(REBXAMD_OP_RADIATION, s, 0, *c, 0.);
+    } else if (fn == rebx_gravitational_harmonics) {
+        for (const SourceJ& s : b->j2) add(REBXAMD_OP_J2, s.idx, 0, s.J, s.Req);
+        for (const SourceJ& s : b->j4) add(REBXAMD_OP_J4, s.idx, 0, s.J, s.Req);
+    } else if (fn == rebx_gr) {
+        if (!c) { reb_error(sim, "REBOUNDx Error: Need to set speed of light in gr effect.  See examples in documentation.\n"); return false; }
+        const int* it = (const int*)rebx_get_param(rebx, f->ap, "max_iterations");
+        add(REBXAMD_OP_GR, 0, it ? *it : 10, *c, 0.);
+    } else if (fn == rebx_gr_potential) {
+        if (!c) { reb_error(sim, "REBOUNDx Error: Need to set speed of light in gr effect.  See examples in documentation.\n"); return false; }
+        add(REBXAMD_OP_GR_POTENTIAL, 0, 0, *c, 0.);
+    } else if (fn == rebx_gr_full) {
+        if (!c) { reb_error(sim, "REBOUNDx Error: Need to set speed of light in gr effect.  See examples in documentation.\n"); return false; }
+        add(REBXAMD_OP_GR_FULL, -1, sim->gravity_ignore_terms == 1 ? 1 : 0, *c, 0.);
+    } else if (fn == rebx_central_force) {
+        for (const SourceC& s : b->central) add(REBXAMD_OP_CENTRAL, s.idx, 0, s.A, s.gamma);
+    } else if (fn == rebx_tides_precession) {
+        if (b->tides_primaries.empty()) add(REBXAMD_OP_TIDES, 0, 0, 0., 0.);
+        for (int s : b->tides_primaries) add(REBXAMD_OP_TIDES, s, 0, 0., 0.);
+    } else if (fn == rebx_modify_orbits_forces) {
+        const int* cp = (const int*)rebx_get_param(rebx, f->ap, "coordinates");
+        const int coords = cp ? *cp : REBX_COORDINATES_JACOBI;
+        if (coords == REBX_COORDINATES_PARTICLE) {
+            if (b->first_primary < 0) {
+                reb_error(sim, "Coordinates set to REBX_COORDINATES_PARTICLE, but primary param was not found in any particle.  Need to set parameter.\n");
+                return false;
+            }
+            add(REBXAMD_OP_MOF, b->first_primary, coords, 0., 0.);
+        } else if (coords == REBX_COORDINATES_JACOBI || coords == REBX_COORDINATES_BARYCENTRIC) {
+            add(REBXAMD_OP_MOF, -1, coords, 0., 0.);
+        } else {
+            reb_error(sim, "Coordinates not supported in REBOUNDx.\n");
+            return false;
+        }
+    }
+    return true;
+}
+
+// Runs a run of built-in forces on `particles` (host array-of-structs) in one device round trip.
+void run_builtin(struct reb_simulation* sim, struct rebx_extras* rebx, const std::vector<Pending>& batch,
+                 struct reb_particle* const particles, const int N) {
+    if (batch.empty() || N <= 0) return;
+    Bridge* b = bridge_of(rebx, true);
+    if (!ensure_capacity(rebx, b, (size_t)N)) return;
+
+    // ---- pack: array-of-structs -> columns; fold the parameter-list heads into a checksum
+    const double t0 = now_ms();
+    unsigned long long sum = 1469598103934665603ull;
+    long long last_massive = -1;
+    double* const* h = b->h_dyn;
+    for (int i = 0; i < N; i++) {
+        const struct reb_particle& p = particles[i];
+        h[H_X][i] = p.x; h[H_Y][i] = p.y; h[H_Z][i] = p.z;
+        h[H_VX][i] = p.vx; h[H_VY][i] = p.vy; h[H_VZ][i] = p.vz;
+        h[H_M][i] = p.m;
+        h[H_AX][i] = p.ax; h[H_AY][i] = p.ay; h[H_AZ][i] = p.az;
+        if (p.m != 0.) last_massive = i;
+        sum = (sum ^ (unsigned long long)(uintptr_t)p.ap) * 1099511628211ull;
+    }
+    const bool rebuild = b->built_generation != b->generation || b->built_n != N || b->built_checksum != sum;
+    if (rebuild) flatten_params(rebx, b, particles, N);
+    const double t1 = now_ms();
+
+    // ---- ops (effect parameters are read on every call: they are a handful of list walks)
+    std::vector<rebxamd_op> ops;
+    for (const Pending& pf : batch) ops_of_force(sim, rebx, b, pf, ops);
+    if (ops.empty()) { b->timings[0] = t1 - t0; b->timings[1] = b->timings[2] = b->timings[3] = 0.; return; }
+
+    // ---- host -> device
+    hipStream_t st = nullptr;
+    const size_t bytes = (size_t)N * sizeof(double);
+    bool ok = true;
+    for (int k = 0; k < H_NDYN && ok; k++) ok = hipMemcpyAsync(b->d_dyn[k], b->h_dyn[k], bytes, hipMemcpyHostToDevice, st) == hipSuccess;
+    if (rebuild) {
+        for (int k = 0; k < P_NPAR && ok; k++)
+            if (b->par_used[k]) ok = hipMemcpyAsync(b->d_par[k], b->h_par[k], bytes, hipMemcpyHostToDevice, st) == hipSuccess;
+        b->built_generation = b->generation; b->built_n = N; b->built_checksum = sum;
+    }
+    ok = ok && hipStreamSynchronize(st) == hipSuccess;
+    const double t2 = now_ms();
+    if (!ok) { rebx_error(rebx, "REBOUNDx (MI355X) Error: host to device copy failed.\n"); return; }
+
+    // ---- kernels
+    rebxamd_view v;
+    memset(&v, 0, sizeof(v));
+    v.n = N;
+    v.n_head = last_massive + 1 < 1 ? 1 : last_massive + 1;
+    v.tail_massless = 1;
+    v.G = sim->G;
+    v.x = b->d_dyn[H_X]; v.y = b->d_dyn[H_Y]; v.z = b->d_dyn[H_Z];
+    v.vx = b->d_dyn[H_VX]; v.vy = b->d_dyn[H_VY]; v.vz = b->d_dyn[H_VZ];
+    v.m = b->d_dyn[H_M];
+    v.ax = b->d_dyn[H_AX]; v.ay = b->d_dyn[H_AY]; v.az = b->d_dyn[H_AZ];
+    v.beta = b->par_used[P_BETA] ? b->d_par[P_BETA] : nullptr;
+    v.R_tides = b->par_used[P_RT] ? b->d_par[P_RT] : nullptr;
+    v.k1 = b->par_used[P_K1] ? b->d_par[P_K1] : nullptr;
+    v.tau_a = b->par_used[P_TA] ? b->d_par[P_TA] : nullptr;
+    v.tau_e = b->par_used[P_TE] ? b->d_par[P_TE] : nullptr;
+    v.tau_inc = b->par_used[P_TI] ? b->d_par[P_TI] : nullptr;
+    const int rc = rebxamd_apply(b->ctx, &v, ops.data(), (int)ops.size(), b->mode, st);
+    if (rc != REBXAMD_OK) {
+        char str[400];
+        snprintf(str, sizeof(str), "REBOUNDx (MI355X) Error: %s. Accelerations were not updated.\n", rebxamd_last_error(b->ctx));
+        (void)hipStreamSynchronize(st);
+        reb_error(sim, str);
+        return;
+    }
+    ok = hipStreamSynchronize(st) == hipSuccess;
+    const double t3 = now_ms();
+
+    // ---- device -> host, columns -> array-of-structs
+    for (int k = H_AX; k <= H_AZ && ok; k++) ok = hipMemcpyAsync(b->h_dyn[k], b->d_dyn[k], bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
+    uint32_t bits = 0;
+    ok = ok && rebxamd_fetch_warnings(b->ctx, &bits, st) == REBXAMD_OK;     // synchronises the stream
+    if (!ok) { rebx_error(rebx, "REBOUNDx (MI355X) Error: device to host copy failed.\n"); return; }
+    for (int i = 0; i < N; i++) {
+        particles[i].ax = h[H_AX][i]; particles[i].ay = h[H_AY][i]; particles[i].az = h[H_AZ][i];
+    }
+    const double t4 = now_ms();
+    if (bits & WARN_GR_ITER)
+        reb_warning(sim, "REBOUNDx Warning: 10 iterations in gr.c failed to converge. This is typically because the perturbation is too strong for the current implementation.");
+    if (bits & WARN_GRFULL_SWEEPS) reb_warning(sim, "10 loops in rebx_gr_full did not converge.\n");
+    b->timings[0] = t1 - t0; b->timings[1] = t2 - t1; b->timings[2] = t3 - t2; b->timings[3] = t4 - t3;
+}
+
+void run_single(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N) {
+    struct rebx_extras* rebx = (struct rebx_extras*)sim->extras;
+    const Builtin* bi = builtin_of(force);
+    if (!rebx || !bi) return;
+    std::vector<Pending> one{{force, bi}};
+    run_builtin(sim, rebx, one, particles, N);
+}
+
+}  // namespace
+
+// reference src/core.c:868-880.  List order is the reverse of the order of rebx_add_force calls.
+extern "C" void rebx_additional_forces(struct reb_simulation* sim) {
+    struct rebx_extras* rebx = (struct rebx_extras*)sim->extras;
+    if (!rebx) return;
+    const int N = sim->N - sim->N_var;
+    std::vector<Pending> batch;
+    for (struct rebx_node* cur = rebx->additional_forces; cur; cur = cur->next) {
+        struct rebx_force* force = (struct rebx_force*)cur->object;
+        if (const Builtin* bi = builtin_of(force)) {
+            batch.push_back({force, bi});
+        } else {
+            // a user-supplied callback: everything before it must be on the host when it runs
+            run_builtin(sim, rebx, batch, sim->particles, N);
+            batch.clear();
+            force->update_accelerations(sim, force, sim->particles, N);
+        }
+    }
+    run_builtin(sim, rebx, batch, sim->particles, N);
+}
+
+// The force callbacks (reference src/core.h:66-74): one force on the array they are handed.
+extern "C" void rebx_gr(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N) { run_single(sim, force, particles, N); }
+extern "C" void rebx_gr_full(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N) { run_single(sim, force, particles, N); }
+extern "C" void rebx_gr_potential(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N) { run_single(sim, force, particles, N); }
+extern "C" void rebx_radiation_forces(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N) { run_single(sim, force, particles, N); }
+extern "C" void rebx_modify_orbits_forces(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N) { run_single(sim, force, particles, N); }
+extern "C" void rebx_tides_precession(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N) { run_single(sim, force, particles, N); }
+extern "C" void rebx_central_force(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N) { run_single(sim, force, particles, N); }
+extern "C" void rebx_gravitational_harmonics(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N) { run_single(sim, force, particles, N); }

@@ -1,0 +1,374 @@
+"""ctypes mirror of the plugin API (group A of include/reboundx_amd.h).
+
+Plays the role the reference's ``reboundx/extras.py`` + ``reboundx/params.py`` play for its C
+library (same class and method names: ``Extras``, ``Force``, ``.params[...]``,
+``load_force``/``add_force``/...), so tests of this library read like the reference's
+own.  REBOUND itself is not available here, so ``Simulation``/``Particle`` mirror the minimal
+structs of ``include/rebound_min.h`` instead of ``rebound.Simulation``.
+"""
+import ctypes
+import warnings
+from collections.abc import MutableMapping
+from ctypes import (CFUNCTYPE, POINTER, Structure, byref, c_char_p, c_double, c_int, c_uint, c_uint32, c_void_p, cast)
+
+from ._lib import lib
+
+REBX_FORCE_TYPE = {"none": 0, "pos": 1, "vel": 2}
+COORDINATES = {"JACOBI": 0, "BARYCENTRIC": 1, "PARTICLE": 2}
+INTEGRATORS = {"ias15": 0, "whfast": 1, "mercurius": 9}
+
+
+class Simulation(Structure):
+    pass
+
+
+class Particle(Structure):
+    """struct reb_particle (128 bytes, REBOUND 3.x layout)"""
+    _fields_ = [("x", c_double), ("y", c_double), ("z", c_double),
+                ("vx", c_double), ("vy", c_double), ("vz", c_double),
+                ("ax", c_double), ("ay", c_double), ("az", c_double),
+                ("m", c_double), ("r", c_double), ("lastcollision", c_double),
+                ("c", c_void_p), ("hash", c_uint32), ("ap", c_void_p), ("_sim", POINTER(Simulation))]
+
+    @property
+    def params(self):
+        return Params(self)
+
+
+assert ctypes.sizeof(Particle) == 128
+
+SIMFUNC = CFUNCTYPE(None, POINTER(Simulation))
+PARTFUNC = CFUNCTYPE(None, POINTER(Particle))
+
+Simulation._fields_ = [("t", c_double), ("G", c_double), ("dt", c_double),
+                       ("N", c_int), ("N_var", c_int), ("N_active", c_int), ("integrator", c_int),
+                       ("gravity_ignore_terms", c_uint), ("force_is_velocity_dependent", c_int),
+                       ("_particles", POINTER(Particle)), ("extras", c_void_p),
+                       ("additional_forces", SIMFUNC), ("pre_timestep_modifications", SIMFUNC),
+                       ("post_timestep_modifications", SIMFUNC), ("free_particle_ap", PARTFUNC),
+                       ("extras_cleanup", SIMFUNC),
+                       ("n_messages", c_int), ("messages", POINTER(c_char_p))]
+
+
+def _sim_init(self, G=1.0, integrator="ias15"):
+    Structure.__init__(self)
+    self.G = G
+    self.N = 0
+    self.N_active = -1
+    self.integrator = INTEGRATORS[integrator]
+    self._store = None
+    self._extras_ref = None
+
+
+def _sim_add(self, m=0.0, x=0.0, y=0.0, z=0.0, vx=0.0, vy=0.0, vz=0.0):
+    old = self._store
+    n = self.N
+    new = (Particle * (n + 1))()
+    if old is not None:
+        ctypes.memmove(new, old, ctypes.sizeof(Particle) * n)     # parameter lists move with the particles
+    p = new[n]
+    p.x, p.y, p.z, p.vx, p.vy, p.vz, p.m = x, y, z, vx, vy, vz, m
+    self._store = new
+    self._particles = cast(new, POINTER(Particle))
+    self.N = n + 1
+    for i in range(self.N):
+        new[i]._sim = ctypes.pointer(self)
+
+
+def _sim_particles(self):
+    return self._store
+
+
+def _sim_process_messages(self):
+    """Raises on queued errors, warns on queued warnings (rebound.Simulation.process_messages)."""
+    buf = ctypes.create_string_buffer(1024)
+    err = None
+    while True:
+        kind = lib.rebxamd_pop_message(byref(self), buf, 1024)
+        if kind == 0:
+            break
+        msg = buf.value.decode(errors="replace")
+        if kind == 2 and err is None:
+            err = msg
+        elif kind == 1:
+            warnings.warn(msg, RuntimeWarning)
+    if err is not None:
+        raise RuntimeError(err)
+
+
+def _sim_update_acceleration_hook(self):
+    """What REBOUND does after its gravity routine: call the additional-force hook."""
+    if self.additional_forces:
+        self.additional_forces(byref(self))
+    self.process_messages()
+
+
+def _sim_free_particle_params(self):
+    if self.free_particle_ap and self._store is not None:
+        for i in range(self.N):
+            self.free_particle_ap(byref(self._store[i]))
+
+
+Simulation.__init__ = _sim_init
+Simulation.add = _sim_add
+Simulation.particles = property(_sim_particles)
+Simulation.process_messages = _sim_process_messages
+Simulation.call_additional_forces = _sim_update_acceleration_hook
+Simulation.free_particle_params = _sim_free_particle_params
+
+lib.rebxamd_pop_message.restype = c_int
+lib.rebxamd_pop_message.argtypes = [POINTER(Simulation), c_char_p, c_int]
+
+
+class Param(Structure):
+    _fields_ = [("name", c_char_p), ("type", c_int), ("value", c_void_p)]
+
+
+class Node(Structure):
+    pass
+
+
+Node._fields_ = [("object", c_void_p), ("next", POINTER(Node))]
+
+
+class Force(Structure):
+    @property
+    def force_type(self):
+        return self._force_type
+
+    @force_type.setter
+    def force_type(self, value):
+        self._force_type = REBX_FORCE_TYPE[value.lower()]
+
+    @property
+    def update_accelerations(self):
+        return self._update_accelerations
+
+    @update_accelerations.setter
+    def update_accelerations(self, func):
+        self._ffp = FORCEFUNCPTR(func)      # keep the callback object alive
+        self._update_accelerations = self._ffp
+
+    @property
+    def params(self):
+        return Params(self)
+
+
+FORCEFUNCPTR = CFUNCTYPE(None, POINTER(Simulation), POINTER(Force), POINTER(Particle), c_int)
+Force._fields_ = [("name", c_char_p), ("ap", POINTER(Node)), ("_sim", POINTER(Simulation)),
+                  ("_force_type", c_int), ("_update_accelerations", FORCEFUNCPTR)]
+assert ctypes.sizeof(Force) == 40
+
+
+class Extras(Structure):
+    """struct rebx_extras; allocated by Python, initialised by the library, like the reference wrapper."""
+
+    def __init__(self, sim):
+        Structure.__init__(self)
+        sim._extras_ref = self
+        lib.rebx_initialize(byref(sim), byref(self))
+        lib.rebx_register_default_params(byref(self))
+        self.process_messages()
+
+    def __del__(self):
+        try:
+            if self._b_needsfree_ == 1:
+                lib.rebx_free_pointers(byref(self))
+        except Exception:       # interpreter shutdown
+            pass
+
+    def detach(self, sim):
+        sim._extras_ref = None
+        lib.rebx_detach(byref(sim), byref(self))
+
+    def register_param(self, name, param_type):
+        lib.rebx_register_param(byref(self), name.encode("ascii"), c_int(REBX_C_PARAM_TYPES[param_type]))
+        self.process_messages()
+
+    def load_force(self, name):
+        ptr = lib.rebx_load_force(byref(self), name.encode("ascii"))
+        self.process_messages()
+        return ptr.contents
+
+    def create_force(self, name):
+        ptr = lib.rebx_create_force(byref(self), name.encode("ascii"))
+        self.process_messages()
+        return ptr.contents
+
+    def add_force(self, force):
+        if not isinstance(force, Force):
+            raise TypeError("REBOUNDx Error: Object passed to rebx.add_force is not a reboundx.Force instance.")
+        lib.rebx_add_force(byref(self), byref(force))
+        self.process_messages()
+
+    def get_force(self, name):
+        ptr = lib.rebx_get_force(byref(self), name.encode("ascii"))
+        if ptr:
+            return ptr.contents
+        raise AttributeError("REBOUNDx Error: Force {0} passed to rebx.get_force not found.".format(name))
+
+    def remove_force(self, force):
+        if not isinstance(force, Force):
+            raise TypeError("REBOUNDx Error: Object passed to rebx.remove_force is not a reboundx.Force instance.")
+        if not lib.rebx_remove_force(byref(self), byref(force)):
+            raise AttributeError("REBOUNDx Error: Force passed to rebx.remove_force not found in simulation.")
+
+    def rad_calc_beta(self, G, c, source_mass, source_luminosity, radius, density, Q_pr):
+        return lib.rebx_rad_calc_beta(c_double(G), c_double(c), c_double(source_mass), c_double(source_luminosity),
+                                      c_double(radius), c_double(density), c_double(Q_pr))
+
+    def rad_calc_particle_radius(self, G, c, source_mass, source_luminosity, beta, density, Q_pr):
+        return lib.rebx_rad_calc_particle_radius(c_double(G), c_double(c), c_double(source_mass), c_double(source_luminosity),
+                                                 c_double(beta), c_double(density), c_double(Q_pr))
+
+    # extensions of this library
+    def invalidate_params(self):
+        lib.rebxamd_invalidate_params(byref(self))
+
+    def set_mode(self, mode):
+        lib.rebxamd_set_mode(byref(self), 1 if mode in (1, "exact") else 0)
+
+    def last_timings(self):
+        out = (c_double * 4)()
+        lib.rebxamd_last_timings(byref(self), out)
+        return dict(zip(("pack_ms", "h2d_ms", "kernel_ms", "d2h_unpack_ms"), out))
+
+    def process_messages(self):
+        try:
+            self._sim.contents.process_messages()
+        except ValueError:
+            raise AttributeError("REBOUNDx Error: The Simulation instance REBOUNDx was attached to no longer exists.")
+
+
+Extras._fields_ = [("_sim", POINTER(Simulation)),
+                   ("_additional_forces", POINTER(Node)),
+                   ("_pre_timestep_modifications", POINTER(Node)),
+                   ("_post_timestep_modifications", POINTER(Node)),
+                   ("_registered_params", POINTER(Node)),
+                   ("_allocated_forces", POINTER(Node)),
+                   ("_allocated_operators", POINTER(Node))]
+assert ctypes.sizeof(Extras) == 56
+
+REBX_C_TO_CTYPES = [["REBX_TYPE_NONE", None], ["REBX_TYPE_DOUBLE", c_double], ["REBX_TYPE_INT", c_int],
+                    ["REBX_TYPE_POINTER", c_void_p], ["REBX_TYPE_FORCE", Force], ["REBX_TYPE_UINT32", c_uint32],
+                    ["REBX_TYPE_ORBIT", None]]
+REBX_CTYPES = {i: pair[1] for i, pair in enumerate(REBX_C_TO_CTYPES)}
+REBX_C_PARAM_TYPES = {pair[0]: i for i, pair in enumerate(REBX_C_TO_CTYPES)}
+
+
+class Params(MutableMapping):
+    """Mapping view of a particle's or force's parameter list (reference reboundx/params.py)."""
+
+    def __init__(self, parent):
+        self.parent = parent
+        offset = type(parent).ap.offset
+        self.ap = c_void_p.from_buffer(parent, offset)
+        extrasvp = parent._sim.contents.extras
+        if not extrasvp:
+            raise AttributeError("Need to attach reboundx.Extras instance to simulation before setting params.")
+        self.rebx = cast(extrasvp, POINTER(Extras))
+
+    def _ctype(self, key):
+        ctype = REBX_CTYPES[lib.rebx_get_type(self.rebx, key.encode("ascii"))]
+        if ctype is None:
+            raise AttributeError("REBOUNDx Error: Parameter '{0}' not found in REBOUNDx. Need to register it first.".format(key))
+        return ctype
+
+    def __getitem__(self, key):
+        ctype = self._ctype(key)
+        valptr = lib.rebx_get_param(self.rebx, self.ap, key.encode("ascii"))
+        if valptr is None:
+            raise AttributeError("REBOUNDx Error: Parameter '{0}' not found on object.".format(key))
+        if ctype == c_void_p:
+            return valptr
+        val = cast(valptr, POINTER(ctype)).contents
+        return getattr(val, "value", val)
+
+    def __setitem__(self, key, value):
+        ctype = self._ctype(key)
+        k = key.encode("ascii")
+        if ctype == c_double:
+            lib.rebx_set_param_double(self.rebx, byref(self.ap), k, c_double(value))
+        elif ctype == c_int:
+            lib.rebx_set_param_int(self.rebx, byref(self.ap), k, c_int(value))
+        elif ctype == c_uint32:
+            lib.rebx_set_param_uint32(self.rebx, byref(self.ap), k, c_uint32(value))
+        elif ctype == Force:
+            if not isinstance(value, Force):
+                raise AttributeError("REBOUNDx Error: Parameter '{0}' must be assigned a Force object.".format(key))
+            lib.rebx_set_param_pointer(self.rebx, byref(self.ap), k, byref(value))
+        else:
+            lib.rebx_set_param_pointer(self.rebx, byref(self.ap), k, byref(value))
+
+    def __delitem__(self, key):
+        raise AttributeError("REBOUNDx Error: Removing particle params not implemented.")
+
+    def __iter__(self):
+        raise AttributeError("REBOUNDx Error: Iterator for params not implemented.")
+
+    def __len__(self):
+        return lib.rebx_len(self.ap)
+
+
+# ---- signatures of the plugin API
+_P = POINTER
+lib.rebx_initialize.argtypes = [_P(Simulation), _P(Extras)]
+lib.rebx_initialize.restype = None
+lib.rebx_register_default_params.argtypes = [_P(Extras)]
+lib.rebx_register_default_params.restype = None
+lib.rebx_free_pointers.argtypes = [_P(Extras)]
+lib.rebx_free_pointers.restype = None
+lib.rebx_detach.argtypes = [_P(Simulation), _P(Extras)]
+lib.rebx_detach.restype = None
+lib.rebx_attach.argtypes = [_P(Simulation)]
+lib.rebx_attach.restype = _P(Extras)
+lib.rebx_free.argtypes = [_P(Extras)]
+lib.rebx_free.restype = None
+lib.rebx_register_param.argtypes = [_P(Extras), c_char_p, c_int]
+lib.rebx_register_param.restype = None
+for _n in ("rebx_load_force", "rebx_create_force", "rebx_get_force"):
+    getattr(lib, _n).argtypes = [_P(Extras), c_char_p]
+    getattr(lib, _n).restype = _P(Force)
+lib.rebx_add_force.argtypes = [_P(Extras), _P(Force)]
+lib.rebx_add_force.restype = c_int
+lib.rebx_remove_force.argtypes = [_P(Extras), _P(Force)]
+lib.rebx_remove_force.restype = c_int
+lib.rebx_get_type.argtypes = [_P(Extras), c_char_p]
+lib.rebx_get_type.restype = c_int
+lib.rebx_get_param.argtypes = [_P(Extras), c_void_p, c_char_p]
+lib.rebx_get_param.restype = c_void_p
+lib.rebx_get_param_struct.argtypes = [_P(Extras), c_void_p, c_char_p]
+lib.rebx_get_param_struct.restype = _P(Param)
+lib.rebx_set_param_double.argtypes = [_P(Extras), _P(c_void_p), c_char_p, c_double]
+lib.rebx_set_param_double.restype = None
+lib.rebx_set_param_int.argtypes = [_P(Extras), _P(c_void_p), c_char_p, c_int]
+lib.rebx_set_param_int.restype = None
+lib.rebx_set_param_uint32.argtypes = [_P(Extras), _P(c_void_p), c_char_p, c_uint32]
+lib.rebx_set_param_uint32.restype = None
+lib.rebx_set_param_pointer.argtypes = [_P(Extras), _P(c_void_p), c_char_p, c_void_p]
+lib.rebx_set_param_pointer.restype = None
+lib.rebx_len.argtypes = [c_void_p]
+lib.rebx_len.restype = c_int
+lib.rebx_rad_calc_beta.argtypes = [c_double] * 7
+lib.rebx_rad_calc_beta.restype = c_double
+lib.rebx_rad_calc_particle_radius.argtypes = [c_double] * 7
+lib.rebx_rad_calc_particle_radius.restype = c_double
+lib.rebxamd_invalidate_params.argtypes = [_P(Extras)]
+lib.rebxamd_set_mode.argtypes = [_P(Extras), c_int]
+lib.rebxamd_last_timings.argtypes = [_P(Extras), _P(c_double)]
+for _n in ("rebx_gr", "rebx_gr_full", "rebx_gr_potential", "rebx_radiation_forces", "rebx_modify_orbits_forces",
+           "rebx_tides_precession", "rebx_central_force", "rebx_gravitational_harmonics"):
+    getattr(lib, _n).argtypes = [_P(Simulation), _P(Force), _P(Particle), c_int]
+    getattr(lib, _n).restype = None
+
+PLUGIN_API_SYMBOLS = (
+    "rebx_attach", "rebx_detach", "rebx_extras_cleanup", "rebx_free", "rebx_initialize", "rebx_register_default_params",
+    "rebx_free_pointers", "rebx_free_particle_ap", "rebx_create_force", "rebx_load_force", "rebx_add_force", "rebx_remove_force",
+    "rebx_get_force", "rebx_get_param", "rebx_get_param_struct", "rebx_set_param_pointer", "rebx_set_param_double",
+    "rebx_set_param_int", "rebx_set_param_uint32", "rebx_register_param", "rebx_get_type", "rebx_len", "rebx_error",
+    "rebx_additional_forces", "rebx_reset_accelerations", "rebx_gr", "rebx_gr_full", "rebx_gr_potential",
+    "rebx_radiation_forces", "rebx_modify_orbits_forces", "rebx_tides_precession", "rebx_central_force",
+    "rebx_gravitational_harmonics", "rebx_rad_calc_beta", "rebx_rad_calc_particle_radius",
+    "rebxamd_invalidate_params", "rebxamd_set_mode", "rebxamd_last_timings",
+    "rebx_build_str", "rebx_version_str", "rebx_githash_str",
+)

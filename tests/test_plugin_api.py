@@ -1,0 +1,189 @@
+"""Host-side behaviour of the plugin API (no GPU needed): object model, parameter store,
+force factory and error channel, after the reference's reboundx/test/test_effects.py,
+test_params.py and test_segfaults.py."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from reboundx_amd import LIB_PATH, _lib
+from reboundx_amd.extras import PLUGIN_API_SYMBOLS, Extras, Force, Simulation, lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make_sim():
+    sim = Simulation()
+    sim.add(m=1.)
+    sim.add(m=1e-3, x=1., vy=1.)
+    return sim
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "reboundx_amd.h")).read()
+    header += open(os.path.join(ROOT, "include", "rebound_min.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(rebx_[a-z0-9_]+|rebxamd_[a-z0-9_]+|reb_error|reb_warning)\s*\(", header))
+    declared |= set(re.findall(r"extern const char\* (rebx_[a-z_]+);", header))
+    declared -= {"rebxamd_ctx", "rebxamd_op", "rebxamd_view"}
+    dll = ctypes.CDLL(LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(dll, s)]
+    assert not missing, missing
+    assert len(declared) > 50
+    for s in PLUGIN_API_SYMBOLS + _lib.DEVICE_API_SYMBOLS:
+        assert hasattr(dll, s), s
+
+
+def test_version_strings():
+    assert ctypes.c_char_p.in_dll(lib, "rebx_version_str").value == b"3.0.4"
+    assert ctypes.c_char_p.in_dll(lib, "rebx_build_str").value
+
+
+def test_attach_sets_hooks_and_detach_restores_only_its_own():
+    sim = make_sim()
+    rebx = Extras(sim)
+    assert sim.extras == ctypes.addressof(rebx)
+    assert sim.free_particle_ap and sim.extras_cleanup
+    assert not sim.additional_forces               # installed by the first add_force (core.c:406)
+    gr = rebx.load_force("gr")
+    rebx.add_force(gr)
+    assert sim.additional_forces
+    assert sim.force_is_velocity_dependent == 1     # gr is a velocity-dependent force (core.c:392-394)
+    rebx.detach(sim)
+    assert not sim.additional_forces and not sim.free_particle_ap
+
+
+def test_load_force_unknown_name_is_an_error_and_leaves_nothing_behind():
+    sim = make_sim()
+    rebx = Extras(sim)
+    with pytest.raises(RuntimeError, match="not found in REBOUNDx library"):
+        rebx.load_force("no_such_effect")
+    assert lib.rebx_len(rebx._allocated_forces) == 0
+
+
+def test_every_builtin_force_loads_with_the_reference_force_type():
+    sim = make_sim()
+    rebx = Extras(sim)
+    expected = {"gr": 2, "gr_full": 2, "gr_potential": 1, "radiation_forces": 2, "modify_orbits_forces": 2,
+                "tides_precession": 1, "central_force": 1, "gravitational_harmonics": 1}   # core.c:232-263
+    for name, ftype in expected.items():
+        f = rebx.load_force(name)
+        assert f.force_type == ftype and f.name == name.encode() and f.update_accelerations
+    assert lib.rebx_len(rebx._allocated_forces) == len(expected)
+    assert rebx.get_force("gr_full").name == b"gr_full"
+    with pytest.raises(AttributeError):
+        rebx.get_force("nope")
+
+
+def test_add_force_requires_callback_and_type():
+    sim = make_sim()
+    rebx = Extras(sim)
+    f = rebx.create_force("mine")
+    with pytest.raises(RuntimeError, match="update_accelerations"):
+        rebx.add_force(f)
+    f.update_accelerations = lambda s, fo, p, n: None
+    with pytest.raises(RuntimeError, match="force_type"):
+        rebx.add_force(f)
+    f.force_type = "pos"
+    rebx.add_force(f)
+    assert lib.rebx_len(rebx._additional_forces) == 1
+    assert sim.force_is_velocity_dependent == 0
+
+
+def test_forces_are_listed_in_reverse_order_of_addition():
+    sim = make_sim()
+    rebx = Extras(sim)
+    names = ["gr", "radiation_forces", "tides_precession"]
+    for n in names:
+        rebx.add_force(rebx.load_force(n))
+    node, seen = rebx._additional_forces, []
+    while node:
+        seen.append(ctypes.cast(node.contents.object, ctypes.POINTER(Force)).contents.name.decode())
+        node = node.contents.next
+    assert seen == names[::-1]                      # head insertion, linkedlist.c:33-36
+
+
+def test_remove_force():
+    sim = make_sim()
+    rebx = Extras(sim)
+    a, b = rebx.load_force("gr"), rebx.load_force("gr_potential")
+    rebx.add_force(a)
+    rebx.add_force(b)
+    rebx.remove_force(a)
+    assert lib.rebx_len(rebx._additional_forces) == 1 and lib.rebx_len(rebx._allocated_forces) == 1
+    c = rebx.load_force("central_force")            # loaded but never added: removal reports failure (core.c:659-661)
+    with pytest.raises(AttributeError):
+        rebx.remove_force(c)
+
+
+def test_params_set_get_update_len():
+    sim = make_sim()
+    rebx = Extras(sim)
+    ps = sim.particles
+    gr = rebx.load_force("gr")
+    gr.params["c"] = 1e4
+    gr.params["max_iterations"] = 7
+    assert gr.params["c"] == 1e4 and gr.params["max_iterations"] == 7 and len(gr.params) == 2
+    gr.params["c"] = 3e4                            # update in place: no new node
+    assert gr.params["c"] == 3e4 and len(gr.params) == 2
+    ps[1].params["beta"] = 0.25
+    ps[1].params["tau_a"] = -1e4
+    ps[0].params["radiation_source"] = 1
+    assert ps[1].params["beta"] == 0.25 and len(ps[1].params) == 2 and len(ps[0].params) == 1
+    with pytest.raises(AttributeError, match="not found on object"):
+        ps[0].params["beta"]
+    sim.free_particle_params()
+    assert len(ps[1].params) == 0
+
+
+def test_unregistered_and_duplicate_parameter_names():
+    sim = make_sim()
+    rebx = Extras(sim)
+    with pytest.raises(AttributeError, match="register"):
+        sim.particles[0].params["my_param"] = 1.0
+    rebx.register_param("my_param", "REBX_TYPE_DOUBLE")
+    sim.particles[0].params["my_param"] = 2.5
+    assert sim.particles[0].params["my_param"] == 2.5
+    with pytest.raises(RuntimeError, match="already in registered list"):
+        rebx.register_param("my_param", "REBX_TYPE_INT")
+    with pytest.raises(RuntimeError, match="already in registered list"):
+        rebx.register_param("beta", "REBX_TYPE_DOUBLE")
+    # the C setter reports an unregistered name and changes nothing (core.c:518-524)
+    ap = ctypes.c_void_p()
+    lib.rebx_set_param_double(ctypes.byref(rebx), ctypes.byref(ap), b"other", 1.0)
+    with pytest.raises(RuntimeError, match="Need to register parameter name 'other'"):
+        sim.process_messages()
+    assert not ap.value
+
+
+def test_params_move_with_particles_and_pointer_params_are_borrowed():
+    sim = make_sim()
+    rebx = Extras(sim)
+    sim.particles[1].params["beta"] = 0.5
+    sim.add(m=0., x=2.)                             # reallocates the particle array
+    assert sim.particles[1].params["beta"] == 0.5
+    op = rebx.load_force("gr")
+    host = rebx.load_force("gr_potential")
+    host.params["force"] = op
+    assert host.params["force"].name == b"gr"
+
+
+def test_attach_and_free_through_the_c_entry_points_repeatedly():
+    for _ in range(50):                             # test_segfaults.py: create/free cycles
+        sim = make_sim()
+        rebx = lib.rebx_attach(ctypes.byref(sim))
+        f = lib.rebx_load_force(rebx, b"gr")
+        lib.rebx_add_force(rebx, f)
+        ap = ctypes.c_void_p()
+        lib.rebx_set_param_double(rebx, ctypes.byref(ap), b"c", 1e4)
+        sim.particles[1].params["beta"] = 1.0
+        sim.free_particle_params()
+        lib.rebx_free(rebx)
+        assert not sim.additional_forces
+
+
+def test_rad_calc_beta_matches_reference_notebook():
+    sim = make_sim()
+    rebx = Extras(sim)
+    assert rebx.rad_calc_beta(6.674e-11, 3.e8, 1.99e30, 3.85e26, 1.e-5, 1000., 1.) == pytest.approx(0.05767021830984005, rel=1e-15)
