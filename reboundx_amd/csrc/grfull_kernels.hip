@@ -36,9 +36,61 @@ struct GrFullArgs {
 };
 
 // ------------------------------------------------------------------ fast passes
+struct __align__(16) TileA { double x, y, z, gm; };     // position and G*m of body j
+struct __align__(16) TileB { double a, b, c, d; };      // const: v_j, phi_j - 2 v_j^2 ; sweep: 3.5 (a_newton_j + a_old_j)
+
+__device__ __forceinline__ double rsq_refined(double x) {
+    // hardware estimate (~2^-23) + one third-order correction; see effects.h fast_rsqrt
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-(x * y), y, 1.0);
+    return fma(y * e, fma(0.375, e, 0.5), y);
+}
+
+// One 256-body tile against this thread's row.  DIAG: the tile contains the row itself, so the
+// self pair has to be masked (only one tile per row block pays for the compare).
+template <int PASS, bool DIAG>
+__device__ __forceinline__ void grfull_tile(const TileA* __restrict__ ta, const TileB* __restrict__ tb, int self,
+                                            double xi, double yi, double zi, double vxi, double vyi, double vzi, double vi2, double p4,
+                                            double& s0, double& s1, double& s2) {
+#pragma unroll 4
+    for (int jj = 0; jj < GB; jj++) {
+        const TileA A = ta[jj];
+        const double dx = xi - A.x, dy = yi - A.y, dz = zi - A.z;
+        double r2 = dx * dx + dy * dy + dz * dz;
+        double gm = A.gm;
+        if (DIAG && jj == self) { gm = 0.; r2 = 1.; }
+        const double ri = rsq_refined(r2);
+        if (PASS == PASS_POT) {
+            s0 = fma(gm, ri, s0);
+        } else if (PASS == PASS_CONST) {
+            // B = (v_j, phi_j - 2 v_j^2); ci = 4 phi_i - v_i^2 (passed in p4)
+            const TileB B = tb[jj];
+            const double ri2 = ri * ri;
+            const double g3 = gm * ri2 * ri;
+            const double vivj = vxi * B.a + vyi * B.b + vzi * B.c;
+            const double dvj = dx * B.a + dy * B.b + dz * B.c;
+            const double dvi = dx * vxi + dy * vyi + dz * vzi;
+            const double f1 = fma(1.5 * ri2, dvj * dvj, fma(4., vivj, p4 + B.d));
+            const double f2 = fma(4., dvi, -3. * dvj);
+            s0 = fma(g3, fma(f1, dx, f2 * (vxi - B.a)), s0);
+            s1 = fma(g3, fma(f1, dy, f2 * (vyi - B.b)), s1);
+            s2 = fma(g3, fma(f1, dz, f2 * (vzi - B.c)), s2);
+        } else {
+            // B = 3.5 (a_newton_j + a_old_j); term = G m_j/r ( (d.B) d /(7 r^2) + B )
+            const TileB B = tb[jj];
+            const double h = (ri * ri) * ((dx * B.a + dy * B.b + dz * B.c) * (1. / 7.));
+            const double g1 = gm * ri;
+            s0 = fma(g1, fma(h, dx, B.a), s0);
+            s1 = fma(g1, fma(h, dy, B.b), s1);
+            s2 = fma(g1, fma(h, dz, B.c), s2);
+        }
+    }
+}
+
 template <int PASS>
 __global__ __launch_bounds__(GB) void grfull_fast_kernel(GrFullArgs a) {
-    __shared__ double tj[8][GB];        // column-major tile: tj[c][jj]
+    __shared__ TileA ta[GB];
+    __shared__ TileB tb[GB];
     const int tid = threadIdx.x;
     const long long nrows = a.row1 - a.row0;
     const long long r = (long long)blockIdx.x * GB + tid;
@@ -46,6 +98,7 @@ __global__ __launch_bounds__(GB) void grfull_fast_kernel(GrFullArgs a) {
     const bool live = r < nrows;
     const long long j0 = (long long)blockIdx.y * a.jchunk;
     long long j1 = j0 + a.jchunk; if (j1 > a.n) j1 = a.n;
+    const long long blk_lo = a.row0 + (long long)blockIdx.x * GB, blk_hi = blk_lo + GB;   // rows of this workgroup
 
     double xi = 0., yi = 0., zi = 0., vxi = 0., vyi = 0., vzi = 0., vi2 = 0., p4 = 0.;
     if (live) {
@@ -53,7 +106,7 @@ __global__ __launch_bounds__(GB) void grfull_fast_kernel(GrFullArgs a) {
         if (PASS == PASS_CONST) {
             vxi = a.vx[i]; vyi = a.vy[i]; vzi = a.vz[i];
             vi2 = vxi * vxi + vyi * vyi + vzi * vzi;
-            p4 = 4. * a.pot[i] * a.C2;          // work in units where 1/c^2 is applied once at the end
+            p4 = 4. * a.pot[i] * a.C2 - vi2;    // work in units where 1/c^2 is applied once at the end
         }
     }
     double s0 = 0., s1 = 0., s2 = 0.;
@@ -62,50 +115,29 @@ __global__ __launch_bounds__(GB) void grfull_fast_kernel(GrFullArgs a) {
         const long long j = jt + tid;
         __syncthreads();
         if (j < j1) {
-            tj[0][tid] = a.x[j]; tj[1][tid] = a.y[j]; tj[2][tid] = a.z[j]; tj[3][tid] = a.G * a.m[j];
+            TileA A; A.x = a.x[j]; A.y = a.y[j]; A.z = a.z[j]; A.gm = a.G * a.m[j];
+            ta[tid] = A;
             if (PASS == PASS_CONST) {
-                tj[4][tid] = a.vx[j]; tj[5][tid] = a.vy[j]; tj[6][tid] = a.vz[j]; tj[7][tid] = a.pot[j] * a.C2;
+                TileB B; B.a = a.vx[j]; B.b = a.vy[j]; B.c = a.vz[j];
+                B.d = a.pot[j] * a.C2 - 2. * (B.a * B.a + B.b * B.b + B.c * B.c);
+                tb[tid] = B;
             }
             if (PASS == PASS_SWEEP) {
-                tj[4][tid] = a.anx[j] + a.aox[j]; tj[5][tid] = a.any_[j] + a.aoy[j]; tj[6][tid] = a.anz[j] + a.aoz[j];
+                TileB B; B.a = 3.5 * (a.anx[j] + a.aox[j]); B.b = 3.5 * (a.any_[j] + a.aoy[j]); B.c = 3.5 * (a.anz[j] + a.aoz[j]); B.d = 0.;
+                tb[tid] = B;
             }
         } else {
             // padding bodies: zero mass far away contributes exactly nothing
-            tj[0][tid] = 1.e100; tj[1][tid] = 1.e100; tj[2][tid] = 1.e100; tj[3][tid] = 0.;
-            tj[4][tid] = 0.; tj[5][tid] = 0.; tj[6][tid] = 0.; tj[7][tid] = 0.;
+            TileA A; A.x = 1.e100; A.y = 1.e100; A.z = 1.e100; A.gm = 0.;
+            TileB B; B.a = B.b = B.c = B.d = 0.;
+            ta[tid] = A; tb[tid] = B;
         }
         __syncthreads();
-        const int self = (live && i >= jt && i < jt + GB) ? (int)(i - jt) : -1;
-#pragma unroll 4
-        for (int jj = 0; jj < GB; jj++) {
-            const double dx = xi - tj[0][jj], dy = yi - tj[1][jj], dz = zi - tj[2][jj];
-            const double r2 = dx * dx + dy * dy + dz * dz;
-            double gm = tj[3][jj];
-            if (jj == self) gm = 0.;                    // no self term (r2 == 0 handled below)
-            const double ri = (jj == self) ? 0. : rsqrt(r2);
-            if (PASS == PASS_POT) {
-                s0 += gm * ri;
-            } else if (PASS == PASS_CONST) {
-                const double vxj = tj[4][jj], vyj = tj[5][jj], vzj = tj[6][jj];
-                const double ri2 = ri * ri;
-                const double g3 = gm * ri2 * ri;
-                const double vj2 = vxj * vxj + vyj * vyj + vzj * vzj;
-                const double vivj = vxi * vxj + vyi * vyj + vzi * vzj;
-                const double dvj = dx * vxj + dy * vyj + dz * vzj;
-                const double dvi = dx * vxi + dy * vyi + dz * vzi;
-                const double f1 = p4 + tj[7][jj] - vi2 - 2. * vj2 + 4. * vivj + 1.5 * dvj * dvj * ri2;
-                const double f2 = 4. * dvi - 3. * dvj;
-                s0 += g3 * (f1 * dx + f2 * (vxi - vxj));
-                s1 += g3 * (f1 * dy + f2 * (vyi - vyj));
-                s2 += g3 * (f1 * dz + f2 * (vzi - vzj));
-            } else {
-                const double tx = tj[4][jj], ty = tj[5][jj], tz = tj[6][jj];
-                const double g1 = gm * ri;
-                const double h = 0.5 * (ri * ri) * (dx * tx + dy * ty + dz * tz);
-                s0 += g1 * (h * dx + 3.5 * tx);
-                s1 += g1 * (h * dy + 3.5 * ty);
-                s2 += g1 * (h * dz + 3.5 * tz);
-            }
+        if (jt < blk_hi && jt + GB > blk_lo) {      // workgroup-uniform: this tile overlaps our own rows
+            const int self = (live && i >= jt && i < jt + GB) ? (int)(i - jt) : -1;
+            grfull_tile<PASS, true>(ta, tb, self, xi, yi, zi, vxi, vyi, vzi, vi2, p4, s0, s1, s2);
+        } else {
+            grfull_tile<PASS, false>(ta, tb, -1, xi, yi, zi, vxi, vyi, vzi, vi2, p4, s0, s1, s2);
         }
     }
     if (live) {
