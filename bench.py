@@ -56,26 +56,41 @@ def cpu_baseline(cols, pp, reps):
     return len(cols["x"]) * reps / dt, dt
 
 
-def grfull_section(ctx, n, mode=0):
-    """Secondary metric: gr_full pair-interactions/s at n bodies on this GPU."""
+def grfull_section(ctx, n, mode=0, dist=None, device="cuda:0"):
+    """Secondary metric: gr_full pair-interactions/s at n bodies; rows sharded over the ranks
+    of the job (all-gather of the new accelerations per sweep over RCCL), or one GPU."""
+    from reboundx_amd.dist import HipGrFullEngine, grfull_sharded
     cl = synthetic.cluster(n)
-    dp = DeviceParticles.from_host(cl, n_head=n, tail_massless=False)
+    dp = DeviceParticles.from_host(cl, device=device, n_head=n, tail_massless=False)
     # incoming accelerations: Newtonian gravity is part of REBOUND, not of this path; any smooth
     # field of the right size exercises the same arithmetic
     for k, s in (("ax", "x"), ("ay", "y"), ("az", "z")):
         dp.cols[k].copy_(-dp.cols[s])
-    view = dp.view()
-    sweeps = ctx.grfull(view, 1.0e4, 0, mode)      # warm-up (allocates the workspace)
-    torch.cuda.synchronize()
+    eng = HipGrFullEngine(ctx, dp, mode)
+    world = dist.get_world_size() if dist is not None else 1
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    grfull_sharded(eng, 1.0e4, 0)                  # warm-up (allocates workspaces, sets up RCCL rings)
+    sync()
     t0 = time.perf_counter()
-    sweeps = ctx.grfull(view, 1.0e4, 0, mode)
-    torch.cuda.synchronize()
+    sweeps = grfull_sharded(eng, 1.0e4, 0)
+    sync()
     dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
     pairs = n * (n - 1.0) * (2 + sweeps)
     flops = n * (n - 1.0) * (70 + 36 * sweeps)
-    return {"n": n, "sweeps": sweeps, "ms_per_eval": dt * 1e3, "pair_interactions_per_s": pairs / dt,
-            "roofline": {"bound": "fp64-valu", "achieved": flops / dt / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": flops / dt / 1e12 / FP64_PEAK_TFLOPS}}
+    peak = FP64_PEAK_TFLOPS * world
+    return {"n": n, "n_gpus": world, "sweeps": sweeps, "ms_per_eval": dt * 1e3, "pair_interactions_per_s": pairs / dt,
+            "sharding": "rows i over ranks; all-gather of a_new per sweep" if world > 1 else "single GPU",
+            "roofline": {"bound": "fp64-valu", "achieved": flops / dt / 1e12, "peak": peak, "unit": "TFLOP/s",
+                         "frac": flops / dt / 1e12 / peak}}
 
 
 def main():
@@ -174,8 +189,12 @@ def main():
             v, secs = cpu_baseline(cols, pp, args.cpu_reps)
             out["cpu_baseline"] = {"value": v, "unit": "evals/s", "cores": 1, "kind": "port",
                                    "sample": "%d evaluations of the same %d-particle disk (%.1f s)" % (args.cpu_reps, n_local, secs)}
-        if args.grfull_n > 0 and world == 1:
-            out["gr_full"] = grfull_section(ctx, args.grfull_n, mode)
+    gr = None
+    if args.grfull_n > 0:
+        gr = grfull_section(ctx, args.grfull_n, mode, dist, "cuda:%d" % local_rank)     # collective: every rank takes part
+    if rank == 0:
+        if gr is not None:
+            out["gr_full"] = gr
         print(json.dumps(out), flush=True)
     barrier()
     ctx.close()

@@ -279,6 +279,12 @@ int rebxamd_timing_read(rebxamd_ctx* ctx, double* total_ms, int* launches);
  *           (gr_full.c:181-203); also sets *dev_flag (device uint32) to 1 if any row in range
  *           fails the reference's stopping rule (gr_full.c:206-220)
  */
+/* newton: an = incoming accelerations of ALL bodies (+ the 0-1 pair if gravity_ignore_10,
+ *         gr_full.c:69-102), a0 = 0 (the first iterate, gr_full.c:74-76)
+ * finish: view->a{x,y,z} += a{x,y,z} (gr_full.c:226-230) */
+int rebxamd_grfull_newton(rebxamd_ctx* ctx, const rebxamd_view* view, int gravity_ignore_10,
+                          double* anx, double* any_, double* anz, double* a0x, double* a0y, double* a0z, void* stream);
+int rebxamd_grfull_finish(rebxamd_ctx* ctx, const rebxamd_view* view, const double* ax, const double* ay, const double* az, void* stream);
 int rebxamd_grfull_pot(rebxamd_ctx* ctx, const rebxamd_view* view, double c, int64_t row0, int64_t row1, double* pot, int mode, void* stream);
 int rebxamd_grfull_const(rebxamd_ctx* ctx, const rebxamd_view* view, double c, int64_t row0, int64_t row1, const double* pot,
                          double* acx, double* acy, double* acz, int mode, void* stream);

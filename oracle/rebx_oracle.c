@@ -543,45 +543,34 @@ static inline void sep(const body* p, int i, int j, double* dx, double* dy, doub
     *r = sqrt((*dx) * (*dx) + (*dy) * (*dy) + (*dz) * (*dz));
 }
 
-int orc_gr_full(const orc_sim* s, double c, int gravity_ignore_10) {
+/* :118-130 hoisted out of the pair loop: a2 sum for rows [row0,row1); a1 = 4*a2 exactly
+ * (every term of the reference's a1 sum is the same term scaled by the power of two 4). */
+void orc_gr_full_pot(const orc_sim* s, double c, int row0, int row1, double* pot) {
     const int N = s->N;
-    if (N <= 0) return 0;
     const double G = s->G, C2 = c * c;
     body* p = gather(s);
-    double (*a_const)[3] = malloc((size_t)N * sizeof(*a_const));
-    double (*a_newton)[3] = malloc((size_t)N * sizeof(*a_newton));
-    double (*a_new)[3] = malloc((size_t)N * sizeof(*a_new));
-    double (*a_old)[3] = malloc((size_t)N * sizeof(*a_old));
-    double* a1 = malloc((size_t)N * sizeof(double));
-    double* a2 = malloc((size_t)N * sizeof(double));
-
-    for (int i = 0; i < N; i++) {           /* :69-76 incoming acceleration is the Newtonian term */
-        a_newton[i][0] = p[i].ax; a_newton[i][1] = p[i].ay; a_newton[i][2] = p[i].az;
-        a_new[i][0] = 0.; a_new[i][1] = 0.; a_new[i][2] = 0.;
-    }
-    if (gravity_ignore_10 && N > 1) {       /* :92-102 WHFast-Jacobi gravity left the 0-1 pair out */
-        double dx, dy, dz, r;
-        sep(p, 0, 1, &dx, &dy, &dz, &r);
-        const double prefact = -G / (r * r * r);
-        const double prefact0 = prefact * p[0].m;
-        const double prefact1 = prefact * p[1].m;
-        a_newton[0][0] += prefact1 * dx; a_newton[0][1] += prefact1 * dy; a_newton[0][2] += prefact1 * dz;
-        a_newton[1][0] -= prefact0 * dx; a_newton[1][1] -= prefact0 * dy; a_newton[1][2] -= prefact0 * dz;
-    }
-    for (int i = 0; i < N; i++) {           /* :118-130 hoisted: same terms, same order */
-        double s1 = 0., s2 = 0.;
+    for (int i = row0; i < row1; i++) {
+        double s2 = 0.;
         for (int k = 0; k < N; k++) {
             if (k == i) continue;
             double dx, dy, dz, r;
             sep(p, i, k, &dx, &dy, &dz, &r);
-            s1 += (4. / (C2)) * G * p[k].m / r;
             s2 += (1. / (C2)) * G * p[k].m / r;
         }
-        a1[i] = s1; a2[i] = s2;
+        pot[i] = s2;
     }
-    for (int i = 0; i < N; i++) {           /* :104-170 */
+    free(p);
+}
+
+/* :104-170 for rows [row0,row1); pot must hold the a2 sums of ALL bodies */
+void orc_gr_full_const(const orc_sim* s, double c, int row0, int row1, const double* pot, double* acx, double* acy, double* acz) {
+    const int N = s->N;
+    const double G = s->G, C2 = c * c;
+    body* p = gather(s);
+    for (int i = row0; i < row1; i++) {
         double cx = 0., cy = 0., cz = 0.;
         const double vi2 = p[i].vx * p[i].vx + p[i].vy * p[i].vy + p[i].vz * p[i].vz;
+        const double a1 = 4. * pot[i];
         for (int j = 0; j < N; j++) {
             if (j == i) continue;
             double dx, dy, dz, r;
@@ -594,7 +583,7 @@ int orc_gr_full(const orc_sim* s, double c, int gravity_ignore_10) {
             const double a5 = (4. / (C2)) * (p[i].vx * p[j].vx + p[i].vy * p[j].vy + p[i].vz * p[j].vz);
             const double a6_0 = dx * p[j].vx + dy * p[j].vy + dz * p[j].vz;
             const double a6 = (3. / (2. * C2)) * a6_0 * a6_0 / rij2;
-            const double factor1 = a1[i] + a2[j] + a3 + a4 + a5 + a6;
+            const double factor1 = a1 + pot[j] + a3 + a4 + a5 + a6;
             cx += G * p[j].m * dx * factor1 / rij3;
             cy += G * p[j].m * dy * factor1 / rij3;
             cz += G * p[j].m * dz * factor1 / rij3;
@@ -604,44 +593,87 @@ int orc_gr_full(const orc_sim* s, double c, int gravity_ignore_10) {
             cy += G * p[j].m * factor2 * dvy / rij3 / (C2);
             cz += G * p[j].m * factor2 * dvz / rij3 / (C2);
         }
-        a_const[i][0] = cx; a_const[i][1] = cy; a_const[i][2] = cz;
+        acx[i] = cx; acy[i] = cy; acz[i] = cz;
     }
+    free(p);
+}
+
+/* :181-220 for rows [row0,row1): one substitution sweep; returns 1 if any row in range fails
+ * the stopping rule (signed ratio, threshold 1e-30), else 0 */
+int orc_gr_full_sweep(const orc_sim* s, double c, int row0, int row1,
+                      const double* anx, const double* any_, const double* anz,
+                      const double* aox, const double* aoy, const double* aoz,
+                      const double* acx, const double* acy, const double* acz,
+                      double* outx, double* outy, double* outz) {
+    const int N = s->N;
+    const double G = s->G, C2 = c * c;
+    body* p = gather(s);
+    int unconverged = 0;
+    for (int i = row0; i < row1; i++) {
+        double nx = 0., ny = 0., nz = 0.;
+        for (int j = 0; j < N; j++) {
+            if (j == i) continue;
+            double dx, dy, dz, r;
+            sep(p, i, j, &dx, &dy, &dz, &r);
+            const double rij3 = r * r * r;
+            const double tx = anx[j] + aox[j], ty = any_[j] + aoy[j], tz = anz[j] + aoz[j];
+            nx += (G * p[j].m * dx / rij3) * (dx * tx + dy * ty + dz * tz) / (2. * C2) + (7. / (2. * C2)) * G * p[j].m * tx / r;
+            ny += (G * p[j].m * dy / rij3) * (dx * tx + dy * ty + dz * tz) / (2. * C2) + (7. / (2. * C2)) * G * p[j].m * ty / r;
+            nz += (G * p[j].m * dz / rij3) * (dx * tx + dy * ty + dz * tz) / (2. * C2) + (7. / (2. * C2)) * G * p[j].m * tz / r;
+        }
+        const double a_new[3] = {acx[i] + nx, acy[i] + ny, acz[i] + nz};
+        const double a_old[3] = {aox[i], aoy[i], aoz[i]};
+        for (int d = 0; d < 3; d++) {
+            const double dev = (fabs(a_new[d]) < 1.e-30) ? 0. : fabs(a_new[d] - a_old[d]) / a_new[d];
+            if (dev >= 1.e-30) unconverged = 1;
+        }
+        outx[i] = a_new[0]; outy[i] = a_new[1]; outz[i] = a_new[2];
+    }
+    free(p);
+    return unconverged;
+}
+
+/* :69-102: the Newtonian term is the incoming acceleration, plus the 0-1 pair when REBOUND's
+ * gravity routine left it out (WHFast in Jacobi coordinates) */
+void orc_gr_full_newton(const orc_sim* s, int gravity_ignore_10, double* anx, double* any_, double* anz) {
+    const int N = s->N;
+    for (int i = 0; i < N; i++) { anx[i] = s->ax[i]; any_[i] = s->ay[i]; anz[i] = s->az[i]; }
+    if (gravity_ignore_10 && N > 1) {
+        body* p = gather(s);
+        double dx, dy, dz, r;
+        sep(p, 0, 1, &dx, &dy, &dz, &r);
+        const double prefact = -s->G / (r * r * r);
+        const double prefact0 = prefact * p[0].m;
+        const double prefact1 = prefact * p[1].m;
+        anx[0] += prefact1 * dx; any_[0] += prefact1 * dy; anz[0] += prefact1 * dz;
+        anx[1] -= prefact0 * dx; any_[1] -= prefact0 * dy; anz[1] -= prefact0 * dz;
+        free(p);
+    }
+}
+
+int orc_gr_full(const orc_sim* s, double c, int gravity_ignore_10) {
+    const int N = s->N;
+    if (N <= 0) return 0;
+    double* w = (double*)calloc((size_t)13 * (size_t)N, sizeof(double));
+    double *anx = w, *any_ = w + N, *anz = w + 2 * N, *pot = w + 3 * N;
+    double *acx = w + 4 * N, *acy = w + 5 * N, *acz = w + 6 * N;
+    double *aox = w + 7 * N, *aoy = w + 8 * N, *aoz = w + 9 * N;       /* a_new starts at zero (:74-76) */
+    double *nwx = w + 10 * N, *nwy = w + 11 * N, *nwz = w + 12 * N;
+    orc_gr_full_newton(s, gravity_ignore_10, anx, any_, anz);
+    orc_gr_full_pot(s, c, 0, N, pot);
+    orc_gr_full_const(s, c, 0, N, pot, acx, acy, acz);
     int sweeps = 0;
     for (int k = 0; k < 10; k++) {          /* :173 the loop bound is the literal 10 */
         sweeps = k + 1;
-        memcpy(a_old, a_new, (size_t)N * sizeof(*a_old));
-        for (int i = 0; i < N; i++) {
-            double nx = 0., ny = 0., nz = 0.;
-            for (int j = 0; j < N; j++) {
-                if (j == i) continue;
-                double dx, dy, dz, r;
-                sep(p, i, j, &dx, &dy, &dz, &r);
-                const double rij3 = r * r * r;
-                const double tx = a_newton[j][0] + a_old[j][0];
-                const double ty = a_newton[j][1] + a_old[j][1];
-                const double tz = a_newton[j][2] + a_old[j][2];
-                nx += (G * p[j].m * dx / rij3) * (dx * tx + dy * ty + dz * tz) / (2. * C2) + (7. / (2. * C2)) * G * p[j].m * tx / r;
-                ny += (G * p[j].m * dy / rij3) * (dx * tx + dy * ty + dz * tz) / (2. * C2) + (7. / (2. * C2)) * G * p[j].m * ty / r;
-                nz += (G * p[j].m * dz / rij3) * (dx * tx + dy * ty + dz * tz) / (2. * C2) + (7. / (2. * C2)) * G * p[j].m * tz / r;
-            }
-            a_new[i][0] = a_const[i][0] + nx;
-            a_new[i][1] = a_const[i][1] + ny;
-            a_new[i][2] = a_const[i][2] + nz;
-        }
-        double maxdev = 0.;                  /* :206-220 signed ratio, threshold 1e-30 */
-        for (int i = 0; i < N; i++) {
-            for (int d = 0; d < 3; d++) {
-                const double dev = (fabs(a_new[i][d]) < 1.e-30) ? 0. : fabs(a_new[i][d] - a_old[i][d]) / a_new[i][d];
-                if (dev > maxdev) maxdev = dev;
-            }
-        }
-        if (maxdev < 1.e-30) break;
+        const int unconverged = orc_gr_full_sweep(s, c, 0, N, anx, any_, anz, aox, aoy, aoz, acx, acy, acz, nwx, nwy, nwz);
+        double* t;
+        t = aox; aox = nwx; nwx = t; t = aoy; aoy = nwy; nwy = t; t = aoz; aoz = nwz; nwz = t;
+        if (!unconverged) break;
     }
     for (int i = 0; i < N; i++) {            /* :226-230 */
-        p[i].ax += a_new[i][0]; p[i].ay += a_new[i][1]; p[i].az += a_new[i][2];
+        s->ax[i] += aox[i]; s->ay[i] += aoy[i]; s->az[i] += aoz[i];
     }
-    free(a_const); free(a_newton); free(a_new); free(a_old); free(a1); free(a2);
-    scatter_acc(s, p);
+    free(w);
     return sweeps;
 }
 

@@ -58,6 +58,15 @@ int orc_gr_literal(const orc_sim* s, double c, int max_iterations);
 int orc_gr_potential(const orc_sim* s, double c);
 /* src/gr_full.c:61-249; returns the number of substitution sweeps executed (1..10) */
 int orc_gr_full(const orc_sim* s, double c, int gravity_ignore_10);
+/* the phases of gr_full on row ranges (what a row-sharded driver composes); see rebx_oracle.c */
+void orc_gr_full_newton(const orc_sim* s, int gravity_ignore_10, double* anx, double* any_, double* anz);
+void orc_gr_full_pot(const orc_sim* s, double c, int row0, int row1, double* pot);
+void orc_gr_full_const(const orc_sim* s, double c, int row0, int row1, const double* pot, double* acx, double* acy, double* acz);
+int orc_gr_full_sweep(const orc_sim* s, double c, int row0, int row1,
+                      const double* anx, const double* any_, const double* anz,
+                      const double* aox, const double* aoy, const double* aoz,
+                      const double* acx, const double* acy, const double* acz,
+                      double* outx, double* outy, double* outz);
 /* src/central_force.c:63-95 */
 int orc_central_force(const orc_sim* s, const double* Acentral, const double* gammacentral);
 /* src/tides_precession.c:65-130 */

@@ -386,6 +386,25 @@ extern "C" int rebxamd_grfull_sweep(rebxamd_ctx* ctx, const rebxamd_view* u, dou
     return REBXAMD_OK;
 }
 
+extern "C" int rebxamd_grfull_newton(rebxamd_ctx* ctx, const rebxamd_view* u, int gravity_ignore_10,
+                                     double* anx, double* any_, double* anz, double* a0x, double* a0y, double* a0z, void* stream) {
+    int rc = grfull_check(ctx, u, 0, u ? u->n : 0);
+    if (rc != REBXAMD_OK) return rc;
+    if (!anx || !any_ || !anz || !a0x || !a0y || !a0z || (u->n > 0 && (!u->ax || !u->ay || !u->az)))
+        return fail(ctx, REBXAMD_ERR_ARG, "gr_full: NULL buffer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(launch_grfull_prepare(make_view(u), u->G, gravity_ignore_10, anx, any_, anz, a0x, a0y, a0z, (hipStream_t)stream));
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_grfull_finish(rebxamd_ctx* ctx, const rebxamd_view* u, const double* ax, const double* ay, const double* az, void* stream) {
+    if (!ctx) return REBXAMD_ERR_ARG;
+    if (!u || u->n < 0 || !ax || !ay || !az || (u->n > 0 && (!u->ax || !u->ay || !u->az))) return fail(ctx, REBXAMD_ERR_ARG, "gr_full: NULL buffer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(launch_grfull_finish(make_view(u), ax, ay, az, (hipStream_t)stream));
+    return REBXAMD_OK;
+}
+
 extern "C" int rebxamd_grfull(rebxamd_ctx* ctx, const rebxamd_view* u, double c, int gravity_ignore_10, int mode, int* sweeps, void* stream) {
     int rc = grfull_check(ctx, u, 0, u ? u->n : 0);
     if (rc != REBXAMD_OK) return rc;

@@ -84,6 +84,13 @@ class Context:
         self._check(lib.rebxamd_grfull(self._h, ctypes.byref(view), c, gravity_ignore_10, mode, ctypes.byref(sweeps), self._stream()))
         return sweeps.value
 
+    def grfull_newton(self, view, gravity_ignore_10, an, a0):
+        self._check(lib.rebxamd_grfull_newton(self._h, ctypes.byref(view), gravity_ignore_10, an[0].data_ptr(), an[1].data_ptr(), an[2].data_ptr(),
+                                              a0[0].data_ptr(), a0[1].data_ptr(), a0[2].data_ptr(), self._stream()))
+
+    def grfull_finish(self, view, a):
+        self._check(lib.rebxamd_grfull_finish(self._h, ctypes.byref(view), a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), self._stream()))
+
     def grfull_pot(self, view, c, row0, row1, pot, mode=_lib.MODE_FAST):
         self._check(lib.rebxamd_grfull_pot(self._h, ctypes.byref(view), c, row0, row1, pot.data_ptr(), mode, self._stream()))
 

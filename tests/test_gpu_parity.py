@@ -366,3 +366,18 @@ def test_ten_million_particle_disk_matches_checker_on_a_sample(ctx, mode):
     if mode == EXACT:
         assert ulp_diff(got, ref).max() == 0
     assert rel_err(got, ref).max() <= TOL
+
+
+def test_gr_full_sharded_driver_on_the_hip_engine(ctx):
+    """The multi-GPU driver (reboundx_amd/dist.py) with no process group: all rows on this GPU,
+    through the same engine calls a rank makes for its shard."""
+    from reboundx_amd.device import DeviceParticles
+    from reboundx_amd.dist import HipGrFullEngine, grfull_sharded
+    n = 777
+    cl = cluster_with_gravity(n)
+    ref = oracle.Sim(cl)
+    sweeps_ref = oracle.gr_full(ref, 1e2, 1)
+    dp = DeviceParticles.from_host(cl)
+    sweeps = grfull_sharded(HipGrFullEngine(ctx, dp, EXACT), 1e2, 1)
+    assert sweeps == sweeps_ref
+    assert ulp_diff(np.array(dp.acc_host()), np.array(ref.acc)).max() == 0
