@@ -15,7 +15,7 @@
  * (they need rebound.h / librebound from the REBOUND package, pinned as
  * rebound>=3.10.0 in the reference setup.py:111, which is not vendored and not
  * installed).  The oracle is therefore pinned by the reference's own recorded
- * answers (see tests/test_oracle_kat.py) and by the potential/force
+ * answers (see tests/test_oracle.py) and by the potential/force
  * consistency its conservation tests rely on.  The four REBOUND helpers
  * (centre of mass, Jacobi transforms) are restated from REBOUND 3.x's
  * published algorithm; for those, parity is unpinned at the instruction level.
