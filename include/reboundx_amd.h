@@ -253,6 +253,18 @@ int rebxamd_classify(rebxamd_ctx* ctx, const double* m, int64_t n, int64_t* n_he
  * on `stream`. */
 int rebxamd_apply(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, int mode, void* stream);
 
+/* Particle-sharded runs (no counterpart in the reference).  `view` holds [the replicated head |
+ * this device's slice of the particles] and the slice may contain massive particles.
+ * rebxamd_apply_targets applies `ops` (no gr, no gr_full, modify_orbits_forces in PARTICLE
+ * coordinates only; sources inside the head) to the particles [target_lo, n) only and, instead
+ * of pushing on the source particles, stores each op's total push in sums[3*k..3*k+2] (device
+ * memory, nops*3 doubles).  The caller sums `sums` over devices (all-reduce) and hands the result
+ * to rebxamd_add_pushes, which adds it to the source particles.  The head's own update is the
+ * plain rebxamd_apply on a view of the head alone. */
+int rebxamd_apply_targets(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, int mode,
+                          int64_t target_lo, double* sums, void* stream);
+int rebxamd_add_pushes(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, const double* sums, void* stream);
+
 /* src/core.c:860-866 on device columns. */
 int rebxamd_reset_accelerations(rebxamd_ctx* ctx, const rebxamd_view* view, void* stream);
 

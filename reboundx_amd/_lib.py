@@ -46,6 +46,8 @@ _sig = {
     "rebxamd_last_error": (c_char_p, [c_void_p]),
     "rebxamd_classify": (c_int, [c_void_p, c_void_p, c_int64, POINTER(c_int64), c_void_p]),
     "rebxamd_apply": (c_int, [c_void_p, POINTER(View), POINTER(Op), c_int, c_int, c_void_p]),
+    "rebxamd_apply_targets": (c_int, [c_void_p, POINTER(View), POINTER(Op), c_int, c_int, c_int64, c_void_p, c_void_p]),
+    "rebxamd_add_pushes": (c_int, [c_void_p, POINTER(View), POINTER(Op), c_int, c_void_p, c_void_p]),
     "rebxamd_reset_accelerations": (c_int, [c_void_p, POINTER(View), c_void_p]),
     "rebxamd_fetch_warnings": (c_int, [c_void_p, POINTER(c_uint32), c_void_p]),
     "rebxamd_timing_enable": (c_int, [c_void_p, c_int]),

@@ -201,7 +201,11 @@ static bool has_backreaction(const rebxamd_op& o) {
 }
 
 // Runs ops[lo,hi) (no gr_full inside, at most one gr and one centre-of-mass mof) as one program.
-static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_op* ops, int lo, int hi, int mode, hipStream_t st) {
+// target_lo < 0: the normal path.  target_lo >= 0 (sharded runs): forces act on particles
+// [target_lo, n) only, every layout goes through the reduction path, and the per-op pushes on
+// the sources are stored in sums_out (device, 3 doubles per op of the run) instead of applied.
+static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_op* ops, int lo, int hi, int mode, hipStream_t st,
+                         long long target_lo = -1, double* sums_out = nullptr, bool pushes_only = false) {
     const View v = make_view(u);
     Program prog;
     memset(&prog, 0, sizeof(prog));
@@ -261,7 +265,7 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
     const bool exact = (mode == REBXAMD_MODE_EXACT);
     const bool vec2 = all_aligned(v);
     const long long K = v.n_head < v.n ? v.n_head : v.n;
-    const bool sparse = (u->tail_massless != 0 || K == v.n) && K >= 1 && K <= REBXAMD_MAX_HEAD && max_src < K;
+    const bool sparse = target_lo < 0 && (u->tail_massless != 0 || K == v.n) && K >= 1 && K <= REBXAMD_MAX_HEAD && max_src < K;
 
     if (sparse) {
         HIP_TRY(launch_head(v, prog, ctx->hc, ctx->status, exact, st));
@@ -280,7 +284,16 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
     for (int k = lo; k < hi; k++)
         if (has_backreaction(ops[k])) prog.ops[k - lo].slot = nslots++;
     prog.nslots = nslots;
-    const int nb = stream_block_count(0, v.n, vec2);
+    if (pushes_only) {
+        HIP_TRY(launch_add_pushes(v, prog, sums_out, st));
+        return REBXAMD_OK;
+    }
+    const long long first = target_lo < 0 ? 0 : target_lo;
+    if (first >= v.n) {
+        if (sums_out) HIP_TRY(hipMemsetAsync(sums_out, 0, sizeof(double) * 3 * (size_t)prog.nops, st));
+        return REBXAMD_OK;
+    }
+    const int nb = stream_block_count(first, v.n, vec2);
     if (nslots > 0) {
         const int rc = ensure(ctx, &ctx->partials, &ctx->partials_cap, (size_t)nslots * (size_t)nb * 3 * sizeof(double), st);
         if (rc != REBXAMD_OK) return rc;
@@ -289,9 +302,9 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
     HIP_TRY(launch_stage(v, prog, ctx->hc, st));
     {
         TimedLaunch tl(ctx, st);
-        HIP_TRY(launch_stream(v, prog, 0, ctx->hc, ctx->partials, &nblocks, nslots > 0, exact, vec2, ctx->status, st));
+        HIP_TRY(launch_stream(v, prog, first, ctx->hc, ctx->partials, &nblocks, nslots > 0, exact, vec2, ctx->status, st));
     }
-    if (nslots > 0) HIP_TRY(launch_finalize(v, prog, ctx->partials, nblocks, ctx->chunk_sums, st));
+    if (nslots > 0 || sums_out) HIP_TRY(launch_finalize(v, prog, ctx->partials, nblocks, ctx->chunk_sums, sums_out, st));
     return REBXAMD_OK;
 }
 
@@ -321,6 +334,24 @@ extern "C" int rebxamd_apply(rebxamd_ctx* ctx, const rebxamd_view* view, const r
         lo = hi;
     }
     return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_apply_targets(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, int mode,
+                                     int64_t target_lo, double* sums, void* stream) {
+    if (!ctx) return REBXAMD_ERR_ARG;
+    if (!view || nops <= 0 || nops > REBXAMD_MAX_OPS || !ops || !sums || view->n < 0 || target_lo < 0)
+        return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_apply_targets: bad argument");
+    for (int k = 0; k < nops; k++)
+        if (ops[k].kind == REBXAMD_OP_GR_FULL) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_apply_targets: gr_full is sharded by rows, not by particles");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return run_streaming(ctx, view, ops, 0, nops, mode, (hipStream_t)stream, target_lo, sums, false);
+}
+
+extern "C" int rebxamd_add_pushes(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, const double* sums, void* stream) {
+    if (!ctx) return REBXAMD_ERR_ARG;
+    if (!view || nops <= 0 || nops > REBXAMD_MAX_OPS || !ops || !sums) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_add_pushes: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return run_streaming(ctx, view, ops, 0, nops, REBXAMD_MODE_FAST, (hipStream_t)stream, 0, const_cast<double*>(sums), true);
 }
 
 // ------------------------------------------------------------------ gr_full

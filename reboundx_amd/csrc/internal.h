@@ -68,7 +68,9 @@ hipError_t launch_stream(const View& v, const Program& prog, long long lo, const
                          int* nblocks_out, bool backreact, bool exact, bool vec2, unsigned* status, hipStream_t st);
 hipError_t launch_stage(const View& v, const Program& prog, HeadConsts* hc, hipStream_t st);
 // chunk_sums: scratch of REBXAMD_MAX_OPS * 64 * 3 doubles
-hipError_t launch_finalize(const View& v, const Program& prog, const double* partials, int nblocks, double* chunk_sums, hipStream_t st);
+// sums_out: nullptr = add the totals to the source particles; else store 3 doubles per op there
+hipError_t launch_finalize(const View& v, const Program& prog, const double* partials, int nblocks, double* chunk_sums, double* sums_out, hipStream_t st);
+hipError_t launch_add_pushes(const View& v, const Program& prog, const double* sums, hipStream_t st);
 hipError_t launch_last_massive(const double* m, long long n, long long* out_dev, hipStream_t st);
 hipError_t launch_reset(const View& v, hipStream_t st);
 int stream_block_count(long long lo, long long n, bool vec2);

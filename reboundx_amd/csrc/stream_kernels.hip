@@ -587,17 +587,36 @@ __global__ __launch_bounds__(BLOCK) void finalize_stage1(const double* partials,
     }
 }
 
-__global__ __launch_bounds__(64) void finalize_stage2(View v, Program prog, const double* chunk_sums) {
+// sums_out == nullptr: add each op's total push to its source particle; otherwise store the
+// totals (3 doubles per op, zero for ops that push on nothing) for the caller to combine
+// across devices first.
+__global__ __launch_bounds__(64) void finalize_stage2(View v, Program prog, const double* chunk_sums, double* sums_out) {
     const int lane = threadIdx.x;
     for (int o = 0; o < prog.nops; o++) {
         const int s = prog.ops[o].slot;
-        if (s < 0) continue;
-        const double* q = chunk_sums + ((long long)s * FIN_CHUNKS + lane) * 3;
-        const double x = wave_sum(q[0]), y = wave_sum(q[1]), z = wave_sum(q[2]);
-        if (lane == 0) {
-            const int src = prog.ops[o].src;
-            v.ax[src] += x; v.ay[src] += y; v.az[src] += z;
+        double x = 0., y = 0., z = 0.;
+        if (s >= 0) {
+            const double* q = chunk_sums + ((long long)s * FIN_CHUNKS + lane) * 3;
+            x = wave_sum(q[0]); y = wave_sum(q[1]); z = wave_sum(q[2]);
         }
+        if (lane == 0) {
+            if (sums_out) {
+                sums_out[o * 3 + 0] = x; sums_out[o * 3 + 1] = y; sums_out[o * 3 + 2] = z;
+            } else if (s >= 0) {
+                const int src = prog.ops[o].src;
+                v.ax[src] += x; v.ay[src] += y; v.az[src] += z;
+            }
+        }
+    }
+}
+
+// adds externally combined pushes (3 doubles per op) to the ops' source particles, in op order
+__global__ __launch_bounds__(64) void add_pushes_kernel(View v, Program prog, const double* sums) {
+    if (threadIdx.x != 0) return;
+    for (int o = 0; o < prog.nops; o++) {
+        const int src = prog.ops[o].src;
+        if (prog.ops[o].slot < 0 || src < 0) continue;
+        v.ax[src] += sums[o * 3 + 0]; v.ay[src] += sums[o * 3 + 1]; v.az[src] += sums[o * 3 + 2];
     }
 }
 
@@ -668,10 +687,15 @@ hipError_t launch_stage(const View& v, const Program& prog, HeadConsts* hc, hipS
     return hipGetLastError();
 }
 
-hipError_t launch_finalize(const View& v, const Program& prog, const double* partials, int nblocks, double* chunk_sums, hipStream_t st) {
+hipError_t launch_finalize(const View& v, const Program& prog, const double* partials, int nblocks, double* chunk_sums, double* sums_out, hipStream_t st) {
     static_assert(FIN_CHUNKS == 64, "stage 2 folds the chunk sums with one wavefront");
-    hipLaunchKernelGGL(finalize_stage1, dim3(FIN_CHUNKS, prog.nslots), dim3(BLOCK), 0, st, partials, nblocks, chunk_sums);
-    hipLaunchKernelGGL(finalize_stage2, dim3(1), dim3(64), 0, st, v, prog, chunk_sums);
+    if (prog.nslots > 0) hipLaunchKernelGGL(finalize_stage1, dim3(FIN_CHUNKS, prog.nslots), dim3(BLOCK), 0, st, partials, nblocks, chunk_sums);
+    hipLaunchKernelGGL(finalize_stage2, dim3(1), dim3(64), 0, st, v, prog, chunk_sums, sums_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_add_pushes(const View& v, const Program& prog, const double* sums, hipStream_t st) {
+    hipLaunchKernelGGL(add_pushes_kernel, dim3(1), dim3(64), 0, st, v, prog, sums);
     return hipGetLastError();
 }
 

@@ -63,6 +63,14 @@ class Context:
         arr = (Op * max(len(ops), 1))(*ops)
         self._check(lib.rebxamd_apply(self._h, ctypes.byref(view), arr, len(ops), mode, self._stream()))
 
+    def apply_targets(self, view, ops, target_lo, sums, mode=_lib.MODE_FAST):
+        arr = (Op * len(ops))(*ops)
+        self._check(lib.rebxamd_apply_targets(self._h, ctypes.byref(view), arr, len(ops), mode, target_lo, sums.data_ptr(), self._stream()))
+
+    def add_pushes(self, view, ops, sums):
+        arr = (Op * len(ops))(*ops)
+        self._check(lib.rebxamd_add_pushes(self._h, ctypes.byref(view), arr, len(ops), sums.data_ptr(), self._stream()))
+
     def reset_accelerations(self, view):
         self._check(lib.rebxamd_reset_accelerations(self._h, ctypes.byref(view), self._stream()))
 
@@ -130,6 +138,14 @@ class DeviceParticles:
         if tail_massless is None:
             tail_massless = bool(np.all(m[n_head:] == 0.0))
         return cls(cols, G=G, n_head=n_head, tail_massless=tail_massless)
+
+    def head_view(self):
+        """View of the head particles alone (same columns, n = n_head)."""
+        v = self.view()
+        v.n = min(self.n_head, self.n)
+        v.n_head = v.n
+        v.tail_massless = 1
+        return v
 
     def view(self):
         v = View()

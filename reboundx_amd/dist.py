@@ -30,6 +30,22 @@ def particle_shard(n_total, n_head, world, rank):
     return lo, min(lo + per, n_total)
 
 
+def apply_forces_sharded(ctx, particles, ops, mode=0, group=None):
+    """One evaluation of per-particle forces when `particles` holds [replicated head | this
+    rank's slice] and the slice may be massive: the head is updated redundantly on every rank,
+    the slice locally, and each op's push on its source particle is summed over ranks with one
+    small all-reduce (3 doubles per op)."""
+    import torch.distributed as dist
+    view = particles.view()
+    ctx.apply(particles.head_view(), ops, mode)                   # head on head, with its own back-reactions
+    sums = torch.zeros(3 * len(ops), dtype=torch.float64, device=particles.cols["x"].device)
+    ctx.apply_targets(view, ops, particles.n_head, sums, mode)    # forces on the slice; pushes -> sums
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    ctx.add_pushes(view, ops, sums)
+    return sums
+
+
 class HipGrFullEngine:
     """gr_full phases on one GPU through librebxamd."""
 

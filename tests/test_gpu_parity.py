@@ -381,3 +381,48 @@ def test_gr_full_sharded_driver_on_the_hip_engine(ctx):
     sweeps = grfull_sharded(HipGrFullEngine(ctx, dp, EXACT), 1e2, 1)
     assert sweeps == sweeps_ref
     assert ulp_diff(np.array(dp.acc_host()), np.array(ref.acc)).max() == 0
+
+
+@pytest.mark.parametrize("mode", [EXACT, FAST])
+def test_particle_sharded_run_with_massive_slices_matches_unsharded_checker(ctx, mode):
+    """Config C3 on several devices: every grain has mass, so each shard's pushes on the star
+    have to be summed over shards.  The shards are run one after the other on this GPU; the
+    all-reduce is replaced by a plain sum of the per-shard totals."""
+    import torch
+    from reboundx_amd.device import DeviceParticles
+    from reboundx_amd.dist import particle_shard
+    from reboundx_amd.program import build_ops
+    n, h, w = 40001, 2, 3
+    cols, pp, _ = synthetic.disk(n, h - 1, dust_mass=1e-12)
+    pp["primary"] = np.zeros(n, dtype=np.uint8); pp["primary"][0] = 1
+    cols = zero_acc(cols)
+    ref = run_oracle(cols, pp, C3_STACK)
+    ops = build_ops(C3_STACK, pp)
+    shards, sums = [], []
+    for r in range(w):
+        lo, hi = particle_shard(n, h, w, r)
+        idx = np.concatenate([np.arange(h), np.arange(lo, hi)])
+        host = {k: v[idx] for k, v in cols.items()}
+        for k in ("R_tides", "k1", "tau_a", "tau_e", "tau_inc"):
+            host[k] = pp[k][idx]
+        dp = DeviceParticles.from_host(host, n_head=h, tail_massless=False)
+        ctx.apply(dp.head_view(), ops, mode)
+        s = torch.zeros(3 * len(ops), dtype=torch.float64, device="cuda")
+        ctx.apply_targets(dp.view(), ops, h, s, mode)
+        shards.append((dp, idx)); sums.append(s)
+    total = torch.stack(sums).sum(dim=0)                      # what the all-reduce delivers to every rank
+    got = np.zeros((3, n))
+    heads = []
+    for dp, idx in shards:
+        ctx.add_pushes(dp.view(), ops, total)
+        a = np.array(dp.acc_host())
+        got[:, idx[h:]] = a[:, h:]
+        heads.append(a[:, :h])
+    for hd in heads[1:]:
+        assert np.array_equal(hd, heads[0])                   # replicated head identical on every rank
+    got[:, :h] = heads[0]
+    if mode == EXACT:
+        assert ulp_diff(got[:, h:], ref[:, h:]).max() == 0
+    assert rel_err(got[:, 1:], ref[:, 1:]).max() <= TOL
+    scale = max(np.abs(ref[:, 1:]).max() * 1e-12 * n, np.abs(ref[:, 0]).max())
+    assert np.abs(got[:, 0] - ref[:, 0]).max() <= 1e-12 * scale
