@@ -22,6 +22,8 @@ struct rebxamd_ctx {
     size_t gf_cap = 0;
     unsigned* gf_flag = nullptr;
     double* chunk_sums = nullptr;       // second-stage scratch of the back-reaction reduction
+    double* scan = nullptr;             // workspace of the prefix/suffix-sum passes (gr, Jacobi/barycentric mof, any layout)
+    size_t scan_cap = 0;
     // optional timing of the dominant kernels with HIP events on the launch stream
     bool timing = false;
     std::vector<hipEvent_t> ev;         // pairs: start, stop
@@ -95,6 +97,7 @@ extern "C" void rebxamd_destroy(rebxamd_ctx* ctx) {
     if (ctx->gf) (void)hipFree(ctx->gf);
     if (ctx->gf_flag) (void)hipFree(ctx->gf_flag);
     if (ctx->chunk_sums) (void)hipFree(ctx->chunk_sums);
+    if (ctx->scan) (void)hipFree(ctx->scan);
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     delete ctx;
 }
@@ -276,10 +279,30 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
         return REBXAMD_OK;
     }
     // general regime
-    if (prog.gr_op >= 0)
-        return fail(ctx, REBXAMD_ERR_UNSUPPORTED, "gr needs the massive bodies to form a prefix of at most 64 particles followed by massless ones");
-    if (prog.mofcom_op >= 0)
-        return fail(ctx, REBXAMD_ERR_UNSUPPORTED, "modify_orbits_forces in Jacobi/barycentric coordinates needs the massive bodies to form a prefix of at most 64 particles; use REBX_COORDINATES_PARTICLE");
+    if (prog.gr_op >= 0 || prog.mofcom_op >= 0) {
+        // massive bodies anywhere: gr and centre-of-mass mof become prefix/suffix-sum passes of
+        // their own; the ops around them keep streaming (no op reads accelerations, so only the
+        // order of additions into a_i is affected, and it is kept)
+        if (target_lo >= 0)
+            return fail(ctx, REBXAMD_ERR_UNSUPPORTED, "gr and Jacobi/barycentric modify_orbits_forces are not available on particle shards that hold massive bodies outside the replicated head");
+        const int rcw = ensure(ctx, &ctx->scan, &ctx->scan_cap, scan_workspace_doubles(v.n) * sizeof(double), st);
+        if (rcw != REBXAMD_OK) return rcw;
+        int a = lo;
+        for (int k = lo; k <= hi; k++) {
+            const bool scan = k < hi && (k - lo == prog.gr_op || k - lo == prog.mofcom_op);
+            if (k < hi && !scan) continue;
+            if (k > a) {
+                const int rc = run_streaming(ctx, u, ops, a, k, mode, st);
+                if (rc != REBXAMD_OK) return rc;
+            }
+            if (scan) {
+                TimedLaunch tl(ctx, st);
+                HIP_TRY(launch_scan_op(v, prog.ops[k - lo], prog.G, exact, ctx->scan, ctx->status, st));
+            }
+            a = k + 1;
+        }
+        return REBXAMD_OK;
+    }
     int nslots = 0;
     for (int k = lo; k < hi; k++)
         if (has_backreaction(ops[k])) prog.ops[k - lo].slot = nslots++;

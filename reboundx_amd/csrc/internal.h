@@ -75,6 +75,10 @@ hipError_t launch_last_massive(const double* m, long long n, long long* out_dev,
 hipError_t launch_reset(const View& v, hipStream_t st);
 int stream_block_count(long long lo, long long n, bool vec2);
 
+// gr and Jacobi/barycentric modify_orbits_forces for arbitrary mass layouts (scan_kernels.hip)
+size_t scan_workspace_doubles(long long n);
+hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, double* ws, unsigned* status, hipStream_t st);
+
 // gr_full launchers implemented in grfull_kernels.hip
 // pass: 0 = potential sums, 1 = acceleration-independent part, 2 = one substitution sweep
 size_t grfull_partial_bytes(long long n, long long nrows);

@@ -1,0 +1,328 @@
+// scan_kernels.hip -- gr and Jacobi/barycentric modify_orbits_forces for arbitrary mass layouts.
+//
+// With massive bodies anywhere in the array the reference's sequential recurrences cannot be
+// folded into constants; they are prefix/suffix sums instead:
+//   * Jacobi coordinates (REBOUND's inertial_to_jacobi, used by src/gr.c:108): body i is measured
+//     from  S_i / eta_i  with  eta_i = sum_{k<i} m_k,  S_i = sum_{k<i} m_k q_k   (q = pos, vel, acc)
+//     -> exclusive prefix sums of (m, m x, m v, m a).
+//   * back to inertial accelerations (jacobi_to_inertial_acc, src/gr.c:162): unrolling the reverse
+//     recurrence gives  a_i = aJ_i - sum_{k>=i} (m_k / eta_{k+1}) aJ_k  (aJ_0 = 0)
+//     -> inclusive suffix sums of w_k = (m_k / (eta_k + m_k)) aJ_k.
+//   * modify_orbits_forces in Jacobi coordinates (src/rebxtools.c:71-107): reference point of body
+//     i = centre of mass of bodies 0..i-1 = S_i / eta_i; every body j <= i loses
+//     (m_i / (eta_i + m_i)) a_i -> the same two scans.  Barycentric: the sums over all bodies.
+//   * the Newtonian term of gr (src/gr.c:86-103) needs every massive body: they are compacted
+//     (deterministically, by a prefix sum of the "is massive" flags) and each body loops over
+//     the compact list in LDS tiles -> O(N * massive).
+// Sums are evaluated as parallel scans, so results differ from the sequential reference at
+// rounding level (the 1e-12 bar), in either arithmetic mode.
+#include "internal.h"
+#include "effects.h"
+
+namespace rebxamd {
+
+static constexpr int SB = 256;          // elements per scan workgroup (one per thread)
+static constexpr int SW = SB / 64;
+
+enum ScanKind { SCAN_GR = 0, SCAN_MOF_JACOBI = 1, SCAN_MOF_BARY = 2 };
+
+__device__ __forceinline__ double wave_incl_scan(double v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_incl_scan_rev(double v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double t = __shfl_down(v, off, 64);
+        if (lane + off < 64) v += t;
+    }
+    return v;
+}
+
+// Workgroup-wide scan of C values per thread.  REVERSE: suffix instead of prefix.
+// On return v[c] holds the INCLUSIVE scan and tot[c] the workgroup total.
+template <int C, bool REVERSE>
+__device__ __forceinline__ void block_scan(double (&v)[C], double (&tot)[C], double (*lds)[C]) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int c = 0; c < C; c++) v[c] = REVERSE ? wave_incl_scan_rev(v[c], lane) : wave_incl_scan(v[c], lane);
+    __syncthreads();
+    if (lane == (REVERSE ? 0 : 63)) {
+#pragma unroll
+        for (int c = 0; c < C; c++) lds[wave][c] = v[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        double before = 0., all = 0.;
+        for (int w = 0; w < SW; w++) {
+            const double t = lds[w][c];
+            all += t;
+            if (REVERSE ? (w > wave) : (w < wave)) before += t;
+        }
+        v[c] += before;
+        tot[c] = all;
+    }
+}
+
+// ---- per-element quantities that get scanned
+template <int C>
+__device__ __forceinline__ void weighted_state(const View& v, const double* nax, const double* nay, const double* naz, long long i, double (&q)[C]) {
+    const double m = v.m[i];
+    q[0] = m;
+    q[1] = m * v.x[i]; q[2] = m * v.y[i]; q[3] = m * v.z[i];
+    q[4] = m * v.vx[i]; q[5] = m * v.vy[i]; q[6] = m * v.vz[i];
+    if (C == 10) { q[7] = m * nax[i]; q[8] = m * nay[i]; q[9] = m * naz[i]; }
+}
+
+// pass 1: workgroup totals of the weighted state
+template <int C>
+__global__ __launch_bounds__(SB) void scan_block_totals(View v, const double* nax, const double* nay, const double* naz, double* blocksums) {
+    __shared__ double lds[SW][C];
+    const long long i = (long long)blockIdx.x * SB + threadIdx.x;
+    double q[C], tot[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) q[c] = 0.;
+    if (i < v.n) weighted_state<C>(v, nax, nay, naz, i, q);
+    block_scan<C, false>(q, tot, lds);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int c = 0; c < C; c++) blocksums[(long long)blockIdx.x * C + c] = tot[c];
+    }
+}
+
+// pass 2: exclusive scan of the workgroup totals, in place, by ONE workgroup; totals[c] = grand total.
+template <int C, bool REVERSE>
+__global__ __launch_bounds__(1024) void scan_of_totals(double* blocksums, long long nb, double* totals) {
+    __shared__ double lds[16][C];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long long chunk = (nb + 1023) / 1024;
+    long long b0 = (long long)tid * chunk, b1 = b0 + chunk;
+    if (b0 > nb) b0 = nb;
+    if (b1 > nb) b1 = nb;
+    if (REVERSE) { const long long t0 = nb - b1, t1 = nb - b0; b0 = t0; b1 = t1; }     // thread 0 owns the last rows
+    double local[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) local[c] = 0.;
+    for (long long b = b0; b < b1; b++)
+#pragma unroll
+        for (int c = 0; c < C; c++) local[c] += blocksums[b * C + c];
+    // exclusive scan of `local` over threads (thread order = scan order in both directions)
+    double incl[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) incl[c] = wave_incl_scan(local[c], lane);
+    if (lane == 63) {
+#pragma unroll
+        for (int c = 0; c < C; c++) lds[wave][c] = incl[c];
+    }
+    __syncthreads();
+    double run[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        double before = 0., all = 0.;
+        for (int w = 0; w < 16; w++) { const double t = lds[w][c]; all += t; if (w < wave) before += t; }
+        run[c] = incl[c] - local[c] + before;
+        if (tid == 0) totals[c] = all;
+    }
+    if (!REVERSE) {
+        for (long long b = b0; b < b1; b++)
+#pragma unroll
+            for (int c = 0; c < C; c++) { const double t = blocksums[b * C + c]; blocksums[b * C + c] = run[c]; run[c] += t; }
+    } else {
+        for (long long b = b1 - 1; b >= b0; b--)
+#pragma unroll
+            for (int c = 0; c < C; c++) { const double t = blocksums[b * C + c]; blocksums[b * C + c] = run[c]; run[c] += t; }
+    }
+}
+
+// pass 3: per-body force in its own frame (aJ) and its weighted reaction (w); workgroup totals of w
+template <int KIND, bool EXACT>
+__global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, const double* nax, const double* nay, const double* naz,
+                                                const double* blocksums, const double* totals,
+                                                double* ajx, double* ajy, double* ajz, double* wx, double* wy, double* wz,
+                                                double* wsums, unsigned* status) {
+    constexpr int C = (KIND == SCAN_GR) ? 10 : 7;
+    __shared__ double lds[SW][C];
+    __shared__ double lds3[SW][3];
+    const long long i = (long long)blockIdx.x * SB + threadIdx.x;
+    const bool live = i < v.n;
+    double q[C], own[C], tot[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) q[c] = 0.;
+    if (live) weighted_state<C>(v, nax, nay, naz, i, q);
+#pragma unroll
+    for (int c = 0; c < C; c++) own[c] = q[c];
+    block_scan<C, false>(q, tot, lds);
+    V3 a = {0., 0., 0.};
+    double w[3] = {0., 0., 0.};
+    if (live) {
+        double S[C];        // exclusive prefix (bodies before i), or the grand total for barycentric
+#pragma unroll
+        for (int c = 0; c < C; c++) S[c] = (KIND == SCAN_MOF_BARY) ? totals[c] : blocksums[(long long)blockIdx.x * C + c] + (q[c] - own[c]);
+        const double eta = S[0], mi = own[0];
+        Part p;
+        p.x = v.x[i]; p.y = v.y[i]; p.z = v.z[i]; p.vx = v.vx[i]; p.vy = v.vy[i]; p.vz = v.vz[i]; p.m = mi;
+        p.beta = p.Rt = p.k1 = __builtin_nan("");
+        p.ta = v.ta ? v.ta[i] : __builtin_nan(""); p.te = v.te ? v.te[i] : __builtin_nan(""); p.ti = v.ti ? v.ti[i] : __builtin_nan("");
+        if (KIND == SCAN_GR) {
+            if (i >= 1) {
+                const double ei = 1. / eta;
+                Jac j;
+                j.x = p.x - S[1] * ei; j.y = p.y - S[2] * ei; j.z = p.z - S[3] * ei;
+                j.vx = p.vx - S[4] * ei; j.vy = p.vy - S[5] * ei; j.vz = p.vz - S[6] * ei;
+                j.ax = nax[i] - S[7] * ei; j.ay = nay[i] - S[8] * ei; j.az = naz[i] - S[9] * ei;
+                const double mu = G * v.m[0];
+                const int it = EXACT ? gr_term_exact(j, mu, op.c, op.iarg, a)
+                                     : gr_term_fast(j, fast_rsqrt(j.x * j.x + j.y * j.y + j.z * j.z), mu, op.d, op.iarg, a);
+                if (it == 10) atomicOr(status, WARN_GR_ITER);
+                const double f = mi / (eta + mi);
+                w[0] = f * a.x; w[1] = f * a.y; w[2] = f * a.z;
+            }
+        } else {
+            const bool acts = (KIND == SCAN_MOF_BARY) || i >= 1;
+            if (acts) {
+                Src ref;
+                const double inv = eta > 0. ? 1. / eta : 1.;
+                ref.x = S[1] * inv; ref.y = S[2] * inv; ref.z = S[3] * inv; ref.vx = S[4] * inv; ref.vy = S[5] * inv; ref.vz = S[6] * inv; ref.m = eta;
+                mof_exact(p, ref, a);
+                const double f = (KIND == SCAN_MOF_BARY) ? mi / eta : mi / (eta + mi);
+                w[0] = f * a.x; w[1] = f * a.y; w[2] = f * a.z;
+            }
+        }
+        ajx[i] = a.x; ajy[i] = a.y; ajz[i] = a.z;
+        wx[i] = w[0]; wy[i] = w[1]; wz[i] = w[2];
+    }
+    double wt[3];
+    block_scan<3, true>(w, wt, lds3);
+    if (threadIdx.x == 0) { wsums[(long long)blockIdx.x * 3 + 0] = wt[0]; wsums[(long long)blockIdx.x * 3 + 1] = wt[1]; wsums[(long long)blockIdx.x * 3 + 2] = wt[2]; }
+}
+
+// pass 5: a_i += aJ_i - (sum of w over bodies k >= i)   [barycentric: over all bodies]
+template <bool TOTAL>
+__global__ __launch_bounds__(SB) void scan_apply(View v, const double* ajx, const double* ajy, const double* ajz,
+                                                 const double* wx, const double* wy, const double* wz,
+                                                 const double* wsums_excl, const double* wtotals) {
+    __shared__ double lds3[SW][3];
+    const long long i = (long long)blockIdx.x * SB + threadIdx.x;
+    const bool live = i < v.n;
+    double w[3] = {0., 0., 0.}, wt[3];
+    if (live && !TOTAL) { w[0] = wx[i]; w[1] = wy[i]; w[2] = wz[i]; }
+    if (!TOTAL) block_scan<3, true>(w, wt, lds3);
+    if (live) {
+        double s0, s1, s2;
+        if (TOTAL) { s0 = wtotals[0]; s1 = wtotals[1]; s2 = wtotals[2]; }
+        else {
+            s0 = w[0] + wsums_excl[(long long)blockIdx.x * 3 + 0];
+            s1 = w[1] + wsums_excl[(long long)blockIdx.x * 3 + 1];
+            s2 = w[2] + wsums_excl[(long long)blockIdx.x * 3 + 2];
+        }
+        v.ax[i] += ajx[i] - s0; v.ay[i] += ajy[i] - s1; v.az[i] += ajz[i] - s2;
+    }
+}
+
+// ---- Newtonian term of gr: compact the massive bodies, then every body sums over them
+__global__ __launch_bounds__(SB) void massive_flag_totals(View v, double* blocksums) {
+    __shared__ double lds[SW][1];
+    const long long i = (long long)blockIdx.x * SB + threadIdx.x;
+    double q[1] = {(i < v.n && v.m[i] != 0.) ? 1. : 0.}, tot[1];
+    block_scan<1, false>(q, tot, lds);
+    if (threadIdx.x == 0) blocksums[blockIdx.x] = tot[0];
+}
+__global__ __launch_bounds__(SB) void massive_compact(View v, const double* blocksums, double* cx, double* cy, double* cz, double* cgm, long long* cidx, double G) {
+    __shared__ double lds[SW][1];
+    const long long i = (long long)blockIdx.x * SB + threadIdx.x;
+    const bool massive = i < v.n && v.m[i] != 0.;
+    double q[1] = {massive ? 1. : 0.}, tot[1];
+    block_scan<1, false>(q, tot, lds);
+    if (massive) {
+        const long long pos = (long long)(blocksums[blockIdx.x] + q[0] - 1.);      // counts are exact in fp64
+        cx[pos] = v.x[i]; cy[pos] = v.y[i]; cz[pos] = v.z[i]; cgm[pos] = G * v.m[i]; cidx[pos] = i;
+    }
+}
+template <bool EXACT>
+__global__ __launch_bounds__(SB) void newton_from_compact(View v, const double* cx, const double* cy, const double* cz, const double* cgm,
+                                                          const long long* cidx, const double* count, double* nax, double* nay, double* naz) {
+    __shared__ double tx[SB], ty[SB], tz[SB], tg[SB];
+    __shared__ long long ti[SB];
+    const long long i = (long long)blockIdx.x * SB + threadIdx.x;
+    const bool live = i < v.n;
+    const long long M = (long long)count[0];
+    double xi = 0., yi = 0., zi = 0.;
+    if (live) { xi = v.x[i]; yi = v.y[i]; zi = v.z[i]; }
+    double ax = 0., ay = 0., az = 0.;
+    for (long long j0 = 0; j0 < M; j0 += SB) {
+        const long long j = j0 + threadIdx.x;
+        __syncthreads();
+        if (j < M) { tx[threadIdx.x] = cx[j]; ty[threadIdx.x] = cy[j]; tz[threadIdx.x] = cz[j]; tg[threadIdx.x] = cgm[j]; ti[threadIdx.x] = cidx[j]; }
+        __syncthreads();
+        const int cnt = (int)((M - j0) < SB ? (M - j0) : SB);
+        for (int k = 0; k < cnt; k++) {
+            if (ti[k] == i) continue;
+            const double dx = tx[k] - xi, dy = ty[k] - yi, dz = tz[k] - zi;
+            const double r2 = dx * dx + dy * dy + dz * dz;
+            if (EXACT) {
+#pragma clang fp contract(off)
+                const double w = tg[k] / (r2 * sqrt(r2));
+                ax += w * dx; ay += w * dy; az += w * dz;
+            } else {
+                const double ri = fast_rsqrt(r2);
+                const double w = tg[k] * (ri * ri * ri);
+                ax = fma(w, dx, ax); ay = fma(w, dy, ay); az = fma(w, dz, az);
+            }
+        }
+    }
+    if (live) { nax[i] = ax; nay[i] = ay; naz[i] = az; }
+}
+
+// ------------------------------------------------------------------ host driver
+size_t scan_workspace_doubles(long long n) {
+    const long long nb = (n + SB - 1) / SB;
+    // 9 body columns (newton, aJ, w) + compact list (4 doubles + 1 index) + workgroup sums (10 + 3 + 1) + totals
+    return (size_t)(9 * n + 5 * n + 14 * nb + 64);
+}
+
+hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, double* ws, unsigned* status, hipStream_t st) {
+    const long long n = v.n;
+    if (n <= 0) return hipSuccess;
+    const long long nb = (n + SB - 1) / SB;
+    double* nax = ws; double* nay = nax + n; double* naz = nay + n;
+    double* ajx = naz + n; double* ajy = ajx + n; double* ajz = ajy + n;
+    double* wx = ajz + n; double* wy = wx + n; double* wz = wy + n;
+    double* cx = wz + n; double* cy = cx + n; double* cz = cy + n; double* cgm = cz + n;
+    long long* cidx = reinterpret_cast<long long*>(cgm + n);
+    double* bs = reinterpret_cast<double*>(cidx + n);      // nb * 10
+    double* wsum = bs + 10 * nb;                            // nb * 3
+    double* fl = wsum + 3 * nb;                             // nb
+    double* totals = fl + nb;                               // 16
+    double* wtot = totals + 16;                             // 3
+    double* count = wtot + 3;                               // 1
+    const dim3 g((unsigned)nb), b(SB);
+    int kind = SCAN_GR;
+    if (op.kind == REBXAMD_OP_MOF) kind = (op.iarg == REBX_COORDINATES_BARYCENTRIC) ? SCAN_MOF_BARY : SCAN_MOF_JACOBI;
+    if (kind == SCAN_GR) {
+        hipLaunchKernelGGL(massive_flag_totals, g, b, 0, st, v, fl);
+        hipLaunchKernelGGL((scan_of_totals<1, false>), dim3(1), dim3(1024), 0, st, fl, nb, count);
+        hipLaunchKernelGGL(massive_compact, g, b, 0, st, v, fl, cx, cy, cz, cgm, cidx, G);
+        if (exact) hipLaunchKernelGGL(newton_from_compact<true>, g, b, 0, st, v, cx, cy, cz, cgm, cidx, count, nax, nay, naz);
+        else hipLaunchKernelGGL(newton_from_compact<false>, g, b, 0, st, v, cx, cy, cz, cgm, cidx, count, nax, nay, naz);
+        hipLaunchKernelGGL(scan_block_totals<10>, g, b, 0, st, v, nax, nay, naz, bs);
+        hipLaunchKernelGGL((scan_of_totals<10, false>), dim3(1), dim3(1024), 0, st, bs, nb, totals);
+        if (exact) hipLaunchKernelGGL((scan_main<SCAN_GR, true>), g, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status);
+        else hipLaunchKernelGGL((scan_main<SCAN_GR, false>), g, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status);
+    } else {
+        hipLaunchKernelGGL(scan_block_totals<7>, g, b, 0, st, v, nax, nay, naz, bs);
+        hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(1024), 0, st, bs, nb, totals);
+        if (kind == SCAN_MOF_JACOBI) hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), g, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status);
+        else hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), g, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status);
+    }
+    hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(1), dim3(1024), 0, st, wsum, nb, wtot);
+    if (kind == SCAN_MOF_BARY) hipLaunchKernelGGL(scan_apply<true>, g, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, wsum, wtot);
+    else hipLaunchKernelGGL(scan_apply<false>, g, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, wsum, wtot);
+    return hipGetLastError();
+}
+
+}  // namespace rebxamd

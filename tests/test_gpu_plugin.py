@@ -259,3 +259,30 @@ def test_larger_host_array_round_trip_and_timings():
     got = np.array([view[:, 6], view[:, 7], view[:, 8]])
     assert ulp_diff(got, np.array(ref.acc)).max() == 0
     sim.free_particle_params()
+
+
+def test_gr_and_jacobi_drag_with_massive_bodies_anywhere_through_the_hook():
+    """Planets behind massless particles (no massive prefix): the hook must still run gr and
+    Jacobi-coordinate modify_orbits_forces on the device (prefix-sum path).  Tolerance: 1e-12
+    relative to the largest component of the body's update (sequential vs. parallel order of the
+    interior-mass sums; see test_gpu_parity.scan_check)."""
+    n = 600
+    cols, pp, _ = synthetic.disk(n, 3)
+    perm = np.concatenate([[0], 1 + np.random.default_rng(2).permutation(n - 1)])
+    cols = {k: np.ascontiguousarray(v[perm]) for k, v in cols.items()}
+    pp = {k: np.ascontiguousarray(v[perm]) for k, v in pp.items()}
+    sim = sim_from(cols)
+    rebx = Extras(sim)
+    for name in ("modify_orbits_forces", "gr"):               # executed: gr, then mof (Jacobi by default)
+        f = rebx.load_force(name)
+        if name == "gr":
+            f.params["c"] = C
+        rebx.add_force(f)
+    set_params(sim, {k: pp[k] for k in ("tau_a", "tau_e", "tau_inc")})
+    sim.call_additional_forces()
+    ref = oracle.Sim(cols)
+    oracle.apply_forces(ref, [("gr", {"c": C}), ("modify_orbits_forces", {})], pp)
+    got, want = acc_of(sim.particles, n), np.array(ref.acc)
+    big = np.abs(want).max(axis=0)
+    assert (np.abs(got - want) / big[None, :]).max() <= TOL
+    sim.free_particle_params()

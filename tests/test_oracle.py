@@ -270,3 +270,22 @@ def test_harmonics_reproduce_notebook_pericentre_advance():
     cols = _integrate(cols, 1.0, 1.e4, lambda s: oracle.gravitational_harmonics(s, J2, J4, Req), rtol=1e-12)
     # stored cell output: "pomega = 0.037037080331452"
     assert _pomega(cols) == pytest.approx(0.037037080331452, abs=2e-7)
+
+
+def test_sequential_interior_mass_drift():
+    """The reference's Jacobi transforms accumulate the interior mass eta_i sequentially
+    (REBOUND transformations.c, restated in the checker's to_jacobi).  Adding 1e-9 to ~1 rounds
+    with a fixed bias, so eta_i drifts linearly: this is the size of the disagreement a parallel
+    (tree-ordered) evaluation of the same sums must be allowed."""
+    n = 6000
+    m = np.full(n, 1e-9)
+    m[0], m[1], m[2] = 1.0, 1e-3, 1e-3
+    eta = np.zeros(n)
+    run = m[0]
+    for i in range(1, n):
+        eta[i] = run
+        run += m[i]
+    exact = np.concatenate([[0.0], np.cumsum(m.astype(np.longdouble))[:-1]])
+    drift = np.abs((eta[1:] - exact[1:]) / exact[1:]).astype(np.float64)
+    assert 1e-13 < drift[-1] < 2e-12          # ~8e-17 per body
+    assert drift[-1] > 3 * drift[n // 10]      # grows with the index
