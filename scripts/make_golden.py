@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Writes the fixtures under tests/golden/ from data the reference itself holds.
+
+Runs in the development container only (it reads /root/reference); the tests read the
+committed JSON files, never the reference tree.
+
+  reference_archives.json -- from reboundx/test/binaries/<force>.sa, the trajectory archives
+      the reference's test_machine_independent.py replays: REBOUND SimulationArchive files
+      (version 3.9.0) of the three-body `twoplanets` system integrated with WHFast,
+      dt = P1/100, one force each.  Extracted: time and particle state (x y z vx vy vz m) of
+      the first two snapshots (t = 0 and t ~ 1000).  File format as found in the files: a
+      64-byte header, then records {uint32 type, uint32 pad, uint64 size, payload}; type 0 =
+      time, type 85 = the particle array (128-byte records: x y z vx vy vz ax ay az m ...),
+      type 9999 ends a snapshot and is followed by an 8-byte index blob.
+  notebook_kats.json -- numbers printed in the stored outputs of the reference's notebooks
+      (ipython_examples/*.ipynb), with the cell they come from.
+
+Floats are stored as C99 hex strings so that the fixtures are exact.
+"""
+import json
+import os
+import struct
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+FORCES = ["tides_precession", "gr", "gr_potential", "gr_full", "radiation_forces", "central_force",
+          "gravitational_harmonics", "modify_orbits_forces"]
+
+
+def read_sa(path, max_snapshots):
+    d = open(path, "rb").read()
+    header = d[:64].split(b"\0")[0].decode()
+    off, out = 64, []
+    while off < len(d) and len(out) < max_snapshots:
+        info = {}
+        while True:
+            t, _, s = struct.unpack_from("<IIQ", d, off)
+            if t == 9999:
+                off += 16 + 8
+                break
+            info[t] = (s, off + 16)
+            off += 16 + s
+        time = struct.unpack_from("<d", d, info[0][1])[0]
+        p = np.frombuffer(d, dtype=np.float64, count=info[85][0] // 8, offset=info[85][1]).reshape(-1, 16)
+        out.append((time, p))
+    return header, out
+
+
+def hexrow(a):
+    return [float(v).hex() for v in a]
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    arch = {"source": "reboundx/test/binaries/<force>.sa (reference test fixtures), first two snapshots",
+            "columns": ["x", "y", "z", "vx", "vy", "vz", "m"], "forces": {}}
+    for name in FORCES:
+        header, snaps = read_sa(os.path.join(REF, "reboundx", "test", "binaries", name + ".sa"), 2)
+        arch["header"] = header
+        arch["forces"][name] = [{"t": float(t).hex(), "particles": [hexrow(np.concatenate([row[:6], row[9:10]])) for row in p]}
+                                for t, p in snaps]
+    with open(os.path.join(OUT, "reference_archives.json"), "w") as f:
+        json.dump(arch, f, indent=1)
+
+    kats = {
+        "rad_calc_beta": {"source": "ipython_examples/Radiation_Forces_Circumplanetary_Dust.ipynb cell 11",
+                          "args": {"G": 6.674e-11, "c": 3.e8, "source_mass": 1.99e30, "source_luminosity": 3.85e26,
+                                   "radius": 1.e-5, "density": 1000., "Q_pr": 1.}, "beta": "0.05767021830984005"},
+        "gr_pomega": {"source": "ipython_examples/GeneralRelativity.ipynb cells 1-9: star m=1, planet m=1.66013e-07 a=0.387098 "
+                                "e=0.205630, COM frame; 10 time units of gravity only, then 100 with gr, c=10065.32012038219",
+                      "pomega_t110": "0.0000332591781488"},
+        "gr_pomega_from_t0": {"source": "ipython_examples/SavingAndLoadingSimulations.ipynb cells 1-12: same system, gr from t=0",
+                              "pomega_t10": "3.418184768435803e-06", "pomega_t20": "6.317055505806844e-06"},
+        "j2_pomega": {"source": "ipython_examples/J2.ipynb cells 1-6: star J2=0.1 J4=0.2 R_eq=1/200, planet m=1e-5 a=1 e=0.01; "
+                                "gravity only to t=1, then harmonics to t=1e4", "pomega_t1e4": "0.037037080331452"},
+    }
+    with open(os.path.join(OUT, "notebook_kats.json"), "w") as f:
+        json.dump(kats, f, indent=1)
+    print("wrote", sorted(os.listdir(OUT)))
+
+
+if __name__ == "__main__":
+    main()

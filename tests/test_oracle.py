@@ -8,16 +8,27 @@ What pins it:
     ipython_examples/J2.ipynb (cell 6), reproduced by integrating Newtonian gravity plus the
     checker's force with an 8th-order Runge-Kutta scheme (the notebooks used REBOUND's IAS15;
     both integrate to ~1e-12, so the stored digits are reproduced to ~1e-9);
+  * the trajectory archives the reference's own test suite replays
+    (reboundx/test/binaries/<force>.sa, extracted to tests/golden/reference_archives.json by
+    scripts/make_golden.py): the displacement each force causes over ~159 inner orbits, taken
+    as the difference between the archive of that force and the archive of a force with no
+    measurable effect, is reproduced by the checker's force to ~1e-4 (the O(dt^2) splitting
+    error of the reference's WHFast run);
   * force = -grad(potential) for every effect whose potential the reference's
     test_conservation.py relies on (reboundx/test/test_conservation.py:38-96).
 """
+import json
 import math
+import os
 
 import numpy as np
 import pytest
 
 import oracle
 from reboundx_amd import synthetic
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def rel(a, b):
@@ -289,3 +300,82 @@ def test_sequential_interior_mass_drift():
     drift = np.abs((eta[1:] - exact[1:]) / exact[1:]).astype(np.float64)
     assert 1e-13 < drift[-1] < 2e-12          # ~8e-17 per body
     assert drift[-1] > 3 * drift[n // 10]      # grows with the index
+
+
+def test_gr_reproduces_second_notebook_pericentre_advance():
+    kat = json.load(open(os.path.join(GOLDEN, "notebook_kats.json")))["gr_pomega_from_t0"]
+    cols = _two_body(1.66013e-07, 0.387098, 0.205630)
+    force = lambda s: oracle.gr(s, synthetic.C_DEFAULT)
+    cols = _integrate(cols, 0.0, 10.0, force)
+    assert _pomega(cols) == pytest.approx(float(kat["pomega_t10"]), abs=1e-9)
+    cols = _integrate(cols, 10.0, 20.0, force)
+    assert _pomega(cols) == pytest.approx(float(kat["pomega_t20"]), abs=1e-9)
+
+
+# ------------------------------------------------------------- reference trajectory archives
+
+def _params3(**kw):
+    out = {}
+    for k, v in kw.items():
+        a = np.full(3, np.nan)
+        for i, x in v.items():
+            a[i] = x
+        out[k] = a
+    return out
+
+
+# parameters of reboundx/test/test_machine_independent.py for each archive
+ARCHIVE_FORCES = {
+    "gr": ([("gr", {"c": 1e4})], {}),
+    "gr_potential": ([("gr_potential", {"c": 1e4})], {}),
+    "gr_full": ([("gr_full", {"c": 1e4})], {}),
+    "radiation_forces": ([("radiation_forces", {"c": 1e4})], _params3(beta={1: .5, 2: .3})),
+    "central_force": ([("central_force", {})], _params3(Acentral={0: 1e-3}, gammacentral={0: -1.})),
+    "gravitational_harmonics": ([("gravitational_harmonics", {})], _params3(J2={0: 1e-3}, J4={0: 1e-3}, R_eq={0: 1e-3})),
+    "modify_orbits_forces": ([("modify_orbits_forces", {})], _params3(tau_a={1: -1e4}, tau_e={1: -1e3, 2: -1e3}, tau_inc={2: -1e3})),
+}
+
+
+def _archive_state(entry):
+    p = np.array([[float.fromhex(v) for v in row] for row in entry["particles"]])
+    cols = {k: p[:, j].copy() for j, k in enumerate(("x", "y", "z", "vx", "vy", "vz", "m"))}
+    for k in ("ax", "ay", "az"):
+        cols[k] = np.zeros(len(p))
+    return float.fromhex(entry["t"]), cols, p[:, :6]
+
+
+@pytest.fixture(scope="module")
+def archive_baseline():
+    """tides_precession with R_tides=1e-3, k1=0.4 at a=1 changes accelerations by ~1e-20 of
+    gravity: its archive is the force-free WHFast trajectory.  Returns it next to the
+    force-free trajectory of the high-order integrator."""
+    arch = json.load(open(os.path.join(GOLDEN, "reference_archives.json")))["forces"]
+    _, c0, _ = _archive_state(arch["tides_precession"][0])
+    t1, _, ref1 = _archive_state(arch["tides_precession"][1])
+    end = _integrate(c0, 0.0, t1, None)
+    free = np.array([end[k] for k in ("x", "y", "z", "vx", "vy", "vz")]).T
+    # the two integrators agree on the force-free motion to the WHFast truncation error
+    assert np.abs(free - ref1).max() < 5e-4
+    return arch, c0, t1, ref1, free
+
+
+@pytest.mark.parametrize("name", sorted(ARCHIVE_FORCES))
+def test_reference_trajectory_archive_pins_force(archive_baseline, name):
+    arch, c0, t1, ref_free, orc_free = archive_baseline
+    t0, start, _ = _archive_state(arch[name][0])
+    ta, _, ref_forced = _archive_state(arch[name][1])
+    assert t0 == 0.0 and ta == t1 and all(np.array_equal(start[k], c0[k]) for k in c0)
+    forces, pp = ARCHIVE_FORCES[name]
+    end = _integrate(c0, 0.0, t1, lambda s: oracle.apply_forces(s, forces, pp))
+    orc_forced = np.array([end[k] for k in ("x", "y", "z", "vx", "vy", "vz")]).T
+    effect_ref = ref_forced - ref_free
+    effect_orc = orc_forced - orc_free
+    scale = np.abs(effect_ref).max()
+    assert scale > 1e-6                                   # the force left a measurable mark
+    tol = 2e-3 if name == "radiation_forces" else 5e-4    # beta=0.5 unbinds planet 1: larger excursion
+    assert np.abs(effect_orc - effect_ref).max() <= tol * scale
+    # and the mark is specific: the wrong relativity flavour misses by far more than the tolerance
+    if name == "gr_potential":
+        end = _integrate(c0, 0.0, t1, lambda s: oracle.gr(s, 1e4))
+        wrong = np.array([end[k] for k in ("x", "y", "z", "vx", "vy", "vz")]).T - orc_free
+        assert np.abs(wrong - effect_ref).max() > 0.1 * scale
