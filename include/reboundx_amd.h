@@ -268,9 +268,38 @@ int rebxamd_add_pushes(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd
 /* src/core.c:860-866 on device columns. */
 int rebxamd_reset_accelerations(rebxamd_ctx* ctx, const rebxamd_view* view, void* stream);
 
+/* Values of enum rebx_integrator, src/reboundx.h:157-163. */
+enum rebxamd_integrator {
+    REBXAMD_INTEGRATOR_NONE = -1,
+    REBXAMD_INTEGRATOR_IMPLICIT_MIDPOINT = 0,
+    REBXAMD_INTEGRATOR_RK4 = 1,
+    REBXAMD_INTEGRATOR_EULER = 2,
+    REBXAMD_INTEGRATOR_RK2 = 3
+};
+
+/* The "integrate a force across a timestep" operator on device columns: replaces
+ * rebx_integrate_force (src/integrate_force.c:34-78) and the schemes it dispatches to
+ * (src/integrator_euler.c:33-41, integrator_rk2.c:38-67, integrator_rk4.c:40-91,
+ * integrator_implicit_midpoint.c:83-124).  `ops` plays the role of the `force` parameter.
+ * Integrates dv/dt = a(x, v) over dt at fixed positions: view->vx/vy/vz are UPDATED IN PLACE
+ * (the const in rebxamd_view is cast away for them); as in the reference, view->ax/ay/az are
+ * cleared first and hold the first-stage accelerations on return (zero for the implicit
+ * midpoint rule).  *iterations (may be NULL) receives the implicit-midpoint loop counter; 10
+ * means not converged and raises warning bit 4.  The implicit midpoint rule synchronises the
+ * stream once per iteration (its convergence test is a global sum); the others are asynchronous. */
+int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, int integrator,
+                            double dt, int mode, int* iterations, void* stream);
+
+/* v += dt*a on device columns: the velocity update of rebx_kick_step (src/steppers.c:123-133;
+ * the accelerations are whatever the columns hold -- gravity is REBOUND's, not this library's). */
+int rebxamd_kick(rebxamd_ctx* ctx, const rebxamd_view* view, double dt, int mode, void* stream);
+/* x += dt*v on device columns: rebx_drift_step (src/steppers.c:112-121). */
+int rebxamd_drift(rebxamd_ctx* ctx, const rebxamd_view* view, double dt, int mode, void* stream);
+
 /* Bits raised by kernels since the last call (synchronises, then clears):
  *  1 = a gr particle used 10 inner iterations (reference warns, gr.c:137-140)
- *  2 = gr_full ran all 10 sweeps without meeting its stopping rule (gr_full.c:221-223) */
+ *  2 = gr_full ran all 10 sweeps without meeting its stopping rule (gr_full.c:221-223)
+ *  4 = the implicit midpoint rule used 10 iterations (reference warns, integrator_implicit_midpoint.c:116-118) */
 int rebxamd_fetch_warnings(rebxamd_ctx* ctx, uint32_t* bits, void* stream);
 
 /* Timing aid (no counterpart in the reference).  While enabled, every streaming pass launched

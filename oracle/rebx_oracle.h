@@ -78,6 +78,16 @@ int orc_modify_orbits_forces(const orc_sim* s, int coordinates, const double* ta
 /* src/core.c:860-866 */
 void orc_reset_accelerations(const orc_sim* s);
 
+/* "integrate a force across a timestep" operator (src/integrate_force.c:34-78) with the schemes
+ * of src/integrator_{euler,rk2,rk4,implicit_midpoint}.c; enum values of src/reboundx.h:157-163.
+ * `f` adds the force's accelerations to the acceleration columns of the state it is handed
+ * (the reference's update_accelerations callback). */
+enum { ORC_INTEGRATOR_NONE = -1, ORC_INTEGRATOR_IMPLICIT_MIDPOINT = 0, ORC_INTEGRATOR_RK4 = 1, ORC_INTEGRATOR_EULER = 2, ORC_INTEGRATOR_RK2 = 3 };
+typedef void (*orc_force_fn)(orc_sim* state, void* user);
+int orc_integrate_force(orc_sim* s, int integrator, double dt, orc_force_fn f, void* user);
+void orc_drift_step(orc_sim* s, double dt);   /* src/steppers.c:112-121 */
+void orc_kick_step(orc_sim* s, double dt);    /* src/steppers.c:123-133 (acceleration columns as given) */
+
 /* potentials used by the reference's conservation tests */
 double orc_gravitational_harmonics_potential(const orc_sim* s, const double* J2, const double* J4, const double* R_eq); /* gravitational_harmonics.c:142-231 */
 double orc_central_force_potential(const orc_sim* s, const double* Acentral, const double* gammacentral);               /* central_force.c:97-141 */

@@ -38,7 +38,8 @@ MODE_FAST, MODE_EXACT = 0, 1
 COORD_JACOBI, COORD_BARYCENTRIC, COORD_PARTICLE = 0, 1, 2
 OK, ERR_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_PARAM = range(5)
 MAX_OPS, MAX_HEAD = 32, 64
-WARN_GR_ITER, WARN_GRFULL_SWEEPS = 1, 2
+WARN_GR_ITER, WARN_GRFULL_SWEEPS, WARN_IM_ITER = 1, 2, 4
+INTEGRATOR_NONE, INTEGRATOR_IMPLICIT_MIDPOINT, INTEGRATOR_RK4, INTEGRATOR_EULER, INTEGRATOR_RK2 = -1, 0, 1, 2, 3
 
 _sig = {
     "rebxamd_create": (c_int, [c_int, POINTER(c_void_p)]),
@@ -49,6 +50,9 @@ _sig = {
     "rebxamd_apply_targets": (c_int, [c_void_p, POINTER(View), POINTER(Op), c_int, c_int, c_int64, c_void_p, c_void_p]),
     "rebxamd_add_pushes": (c_int, [c_void_p, POINTER(View), POINTER(Op), c_int, c_void_p, c_void_p]),
     "rebxamd_reset_accelerations": (c_int, [c_void_p, POINTER(View), c_void_p]),
+    "rebxamd_integrate_force": (c_int, [c_void_p, POINTER(View), POINTER(Op), c_int, c_int, c_double, c_int, POINTER(c_int), c_void_p]),
+    "rebxamd_kick": (c_int, [c_void_p, POINTER(View), c_double, c_int, c_void_p]),
+    "rebxamd_drift": (c_int, [c_void_p, POINTER(View), c_double, c_int, c_void_p]),
     "rebxamd_fetch_warnings": (c_int, [c_void_p, POINTER(c_uint32), c_void_p]),
     "rebxamd_timing_enable": (c_int, [c_void_p, c_int]),
     "rebxamd_timing_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int)]),

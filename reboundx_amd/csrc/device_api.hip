@@ -22,6 +22,8 @@ struct rebxamd_ctx {
     size_t gf_cap = 0;
     unsigned* gf_flag = nullptr;
     double* chunk_sums = nullptr;       // second-stage scratch of the back-reaction reduction
+    double* integ = nullptr;            // stage columns of the force integrators
+    size_t integ_cap = 0;
     double* scan = nullptr;             // workspace of the prefix/suffix-sum passes (gr, Jacobi/barycentric mof, any layout)
     size_t scan_cap = 0;
     // optional timing of the dominant kernels with HIP events on the launch stream
@@ -98,6 +100,7 @@ extern "C" void rebxamd_destroy(rebxamd_ctx* ctx) {
     if (ctx->gf_flag) (void)hipFree(ctx->gf_flag);
     if (ctx->chunk_sums) (void)hipFree(ctx->chunk_sums);
     if (ctx->scan) (void)hipFree(ctx->scan);
+    if (ctx->integ) (void)hipFree(ctx->integ);
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     delete ctx;
 }
@@ -375,6 +378,141 @@ extern "C" int rebxamd_add_pushes(rebxamd_ctx* ctx, const rebxamd_view* view, co
     if (!view || nops <= 0 || nops > REBXAMD_MAX_OPS || !ops || !sums) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_add_pushes: bad argument");
     HIP_TRY(hipSetDevice(ctx->device));
     return run_streaming(ctx, view, ops, 0, nops, REBXAMD_MODE_FAST, (hipStream_t)stream, 0, const_cast<double*>(sums), true);
+}
+
+// ------------------------------------------------------------------ force integrators, kick, drift
+
+static int check_step_view(rebxamd_ctx* ctx, const rebxamd_view* v, const char* who, bool need_pos, bool need_acc) {
+    if (!ctx) return REBXAMD_ERR_ARG;
+    if (!v || v->n < 0) return fail(ctx, REBXAMD_ERR_ARG, who);
+    if (v->n == 0) return REBXAMD_OK;
+    if (!v->vx || !v->vy || !v->vz) return fail(ctx, REBXAMD_ERR_ARG, "velocity columns missing");
+    if (need_pos && (!v->x || !v->y || !v->z)) return fail(ctx, REBXAMD_ERR_ARG, "position columns missing");
+    if (need_acc && (!v->ax || !v->ay || !v->az)) return fail(ctx, REBXAMD_ERR_ARG, "acceleration columns missing");
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_kick(rebxamd_ctx* ctx, const rebxamd_view* view, double dt, int mode, void* stream) {
+    const int rc = check_step_view(ctx, view, "rebxamd_kick: bad argument", false, true);
+    if (rc != REBXAMD_OK || view->n == 0) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    double* const v[3] = {const_cast<double*>(view->vx), const_cast<double*>(view->vy), const_cast<double*>(view->vz)};
+    const double* const cv[3] = {view->vx, view->vy, view->vz};
+    const double* const a[3] = {view->ax, view->ay, view->az};
+    HIP_TRY(launch_lincomb(v, cv, a, dt, view->n, mode == REBXAMD_MODE_EXACT, (hipStream_t)stream));
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_drift(rebxamd_ctx* ctx, const rebxamd_view* view, double dt, int mode, void* stream) {
+    const int rc = check_step_view(ctx, view, "rebxamd_drift: bad argument", true, false);
+    if (rc != REBXAMD_OK || view->n == 0) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    double* const x[3] = {const_cast<double*>(view->x), const_cast<double*>(view->y), const_cast<double*>(view->z)};
+    const double* const cx[3] = {view->x, view->y, view->z};
+    const double* const v[3] = {view->vx, view->vy, view->vz};
+    HIP_TRY(launch_lincomb(x, cx, v, dt, view->n, mode == REBXAMD_MODE_EXACT, (hipStream_t)stream));
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, int integrator,
+                                       double dt, int mode, int* iterations, void* stream) {
+    if (iterations) *iterations = 0;
+    int rc = check_step_view(ctx, view, "rebxamd_integrate_force: bad argument", true, true);
+    if (rc != REBXAMD_OK) return rc;
+    if (nops < 0 || (nops > 0 && !ops)) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_integrate_force: bad op list");
+    if (mode != REBXAMD_MODE_FAST && mode != REBXAMD_MODE_EXACT) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_integrate_force: bad mode");
+    hipStream_t st = (hipStream_t)stream;
+    const bool exact = mode == REBXAMD_MODE_EXACT;
+    const long long n = view->n;
+    HIP_TRY(hipSetDevice(ctx->device));
+    // integrate_force.c:46 -- the simulation's accelerations are cleared first, whatever the scheme
+    rc = rebxamd_reset_accelerations(ctx, view, stream);
+    if (rc != REBXAMD_OK || n == 0) return rc;
+    if (integrator != REBXAMD_INTEGRATOR_EULER && integrator != REBXAMD_INTEGRATOR_RK2 && integrator != REBXAMD_INTEGRATOR_RK4 &&
+        integrator != REBXAMD_INTEGRATOR_IMPLICIT_MIDPOINT)
+        return REBXAMD_OK;                       // REBX_INTEGRATOR_NONE and unknown values do nothing (integrate_force.c:69-76)
+
+    double* const v[3] = {const_cast<double*>(view->vx), const_cast<double*>(view->vy), const_cast<double*>(view->vz)};
+    const double* const cv[3] = {view->vx, view->vy, view->vz};
+    const double* const ca1[3] = {view->ax, view->ay, view->az};
+
+    if (integrator == REBXAMD_INTEGRATOR_EULER) {              // integrator_euler.c:33-41
+        rc = rebxamd_apply(ctx, view, ops, nops, mode, stream);
+        if (rc != REBXAMD_OK) return rc;
+        HIP_TRY(launch_lincomb(v, cv, ca1, dt, n, exact, st));
+        return REBXAMD_OK;
+    }
+
+    const long long npart = im_partial_count(n);
+    const size_t stride = ((size_t)n + 1) & ~(size_t)1;         // keeps every column 16-byte aligned
+    rc = ensure(ctx, &ctx->integ, &ctx->integ_cap, (9 * stride + 2 * (size_t)npart + 2) * sizeof(double), st);
+    if (rc != REBXAMD_OK) return rc;
+    double* w = ctx->integ;
+    double* const sv[3] = {w, w + stride, w + 2 * stride};                       // stage velocities
+    double* const ka[3] = {w + 3 * stride, w + 4 * stride, w + 5 * stride};     // stage accelerations
+    double* const kb[3] = {w + 6 * stride, w + 7 * stride, w + 8 * stride};
+    const double* const cka[3] = {ka[0], ka[1], ka[2]};
+    const double* const ckb[3] = {kb[0], kb[1], kb[2]};
+    double* partials = w + 9 * stride;
+    double* sums = partials + 2 * npart;
+    rebxamd_view sa = *view, sb = *view;                        // stage states share positions, masses, parameters
+    sa.vx = sv[0]; sa.vy = sv[1]; sa.vz = sv[2]; sa.ax = ka[0]; sa.ay = ka[1]; sa.az = ka[2];
+    sb.vx = sv[0]; sb.vy = sv[1]; sb.vz = sv[2]; sb.ax = kb[0]; sb.ay = kb[1]; sb.az = kb[2];
+    // the reference copies the particle array after the reset: stage accelerations start at zero
+    HIP_TRY(hipMemsetAsync(ka[0], 0, 6 * stride * sizeof(double), st));
+
+    if (integrator == REBXAMD_INTEGRATOR_RK2) {                // integrator_rk2.c:38-67
+        rc = rebxamd_apply(ctx, view, ops, nops, mode, stream);
+        if (rc != REBXAMD_OK) return rc;
+        HIP_TRY(launch_lincomb(sv, cv, ca1, 2. * dt / 3., n, exact, st));
+        rc = rebxamd_apply(ctx, &sa, ops, nops, mode, stream);
+        if (rc != REBXAMD_OK) return rc;
+        HIP_TRY(launch_rk2_final(v, ca1, cka, dt / 4., 3. * dt / 4., n, exact, st));
+        return REBXAMD_OK;
+    }
+    if (integrator == REBXAMD_INTEGRATOR_RK4) {                // integrator_rk4.c:40-91
+        const double dt2 = dt / 2.;
+        rc = rebxamd_apply(ctx, view, ops, nops, mode, stream);                 // k1
+        if (rc != REBXAMD_OK) return rc;
+        HIP_TRY(launch_lincomb(sv, cv, ca1, dt2, n, exact, st));
+        rc = rebxamd_apply(ctx, &sa, ops, nops, mode, stream);                  // k2 -> ka
+        if (rc != REBXAMD_OK) return rc;
+        HIP_TRY(launch_lincomb(sv, cv, cka, dt2, n, exact, st));
+        rc = rebxamd_apply(ctx, &sb, ops, nops, mode, stream);                  // k3 -> kb
+        if (rc != REBXAMD_OK) return rc;
+        HIP_TRY(launch_rk4_mid(sv, cv, ka, kb, dt, n, exact, st));              // kb = k3 + k2, ka = 0
+        rc = rebxamd_apply(ctx, &sa, ops, nops, mode, stream);                  // k4 -> ka
+        if (rc != REBXAMD_OK) return rc;
+        HIP_TRY(launch_rk4_final(v, ca1, cka, ckb, dt / 6., n, exact, st));
+        return REBXAMD_OK;
+    }
+    // implicit midpoint (integrator_implicit_midpoint.c:83-124): sv = averaged velocities,
+    // ka = accelerations at the averaged state, kb = current estimate of the final velocities
+    for (int k = 0; k < 3; k++) {
+        HIP_TRY(hipMemcpyAsync(sv[k], cv[k], (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(kb[k], cv[k], (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    int it = 0;
+    for (it = 0; it < 10; it++) {
+        rc = rebxamd_apply(ctx, &sa, ops, nops, mode, stream);
+        if (rc != REBXAMD_OK) return rc;
+        HIP_TRY(launch_im_update(kb, cv, sv, ka, dt, n, partials, sums, exact, st));
+        double h[2] = {0., 0.};
+        HIP_TRY(hipMemcpyAsync(h, sums, sizeof(h), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (h[0] / h[1] < 2.220446049250313e-16 * 2.220446049250313e-16) break;   // compare(), :57
+    }
+    if (it == 10) {
+        unsigned cur = 0;
+        HIP_TRY(hipMemcpyAsync(&cur, ctx->status, sizeof(cur), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        cur |= WARN_IM_ITER;
+        HIP_TRY(hipMemcpyAsync(ctx->status, &cur, sizeof(cur), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    for (int k = 0; k < 3; k++) HIP_TRY(hipMemcpyAsync(v[k], ckb[k], (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (iterations) *iterations = it;
+    return REBXAMD_OK;
 }
 
 // ------------------------------------------------------------------ gr_full

@@ -60,7 +60,7 @@ struct HeadConsts {
     double bary[REBXAMD_MAX_HEAD][3];   // massratio_i * a_i for i = nbary-1 .. 0 (application order)
 };
 
-enum { WARN_GR_ITER = 1u, WARN_GRFULL_SWEEPS = 2u };
+enum { WARN_GR_ITER = 1u, WARN_GRFULL_SWEEPS = 2u, WARN_IM_ITER = 4u };
 
 // launchers implemented in stream_kernels.hip
 hipError_t launch_head(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, bool exact, hipStream_t st);
@@ -78,6 +78,15 @@ int stream_block_count(long long lo, long long n, bool vec2);
 // gr and Jacobi/barycentric modify_orbits_forces for arbitrary mass layouts (scan_kernels.hip)
 size_t scan_workspace_doubles(long long n);
 hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, double* ws, unsigned* status, hipStream_t st);
+
+// velocity/position updates of the force integrators and steppers (step_kernels.hip)
+hipError_t launch_lincomb(double* const out[3], const double* const v[3], const double* const a[3], double coef, long long n, bool exact, hipStream_t st);
+hipError_t launch_rk2_final(double* const v[3], const double* const a1[3], const double* const a2[3], double b1, double b2, long long n, bool exact, hipStream_t st);
+hipError_t launch_rk4_mid(double* const sv[3], const double* const v[3], double* const k2a[3], double* const k3a[3], double dt, long long n, bool exact, hipStream_t st);
+hipError_t launch_rk4_final(double* const v[3], const double* const a1[3], const double* const a4[3], const double* const k23[3], double dt6, long long n, bool exact, hipStream_t st);
+long long im_partial_count(long long n);
+hipError_t launch_im_update(double* const fin[3], const double* const orig[3], double* const avgv[3], double* const avga[3], double dt,
+                            long long n, double* partials, double* sums, bool exact, hipStream_t st);
 
 // gr_full launchers implemented in grfull_kernels.hip
 // pass: 0 = potential sums, 1 = acceleration-independent part, 2 = one substitution sweep

@@ -1,0 +1,183 @@
+// step_kernels.hip -- elementwise velocity/position updates of the "integrate a force across a
+// timestep" schemes (reference src/integrator_euler.c, integrator_rk2.c, integrator_rk4.c,
+// integrator_implicit_midpoint.c) and of the kick/drift steppers (src/steppers.c:112-133).
+// All are HBM-bound one-pass kernels over column triples.  EXACT keeps the reference's
+// expression order without FMA contraction (bitwise equal to a non-FMA CPU build).
+#include "internal.h"
+
+namespace rebxamd {
+
+static constexpr int TB = 256;
+
+struct Cols3 { double *x, *y, *z; };
+struct CCols3 { const double *x, *y, *z; };
+
+template <bool EXACT>
+__device__ __forceinline__ double axpy1(double v, double c, double a) {
+    if (EXACT) {
+#pragma clang fp contract(off)
+        return v + c * a;
+    } else {
+        return fma(c, a, v);
+    }
+}
+
+// out = v + coef * a   (out may alias v: kick, drift, euler)
+template <bool EXACT>
+__global__ __launch_bounds__(TB) void lincomb_kernel(Cols3 out, CCols3 v, CCols3 a, double coef, long long n) {
+    const long long i = (long long)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    out.x[i] = axpy1<EXACT>(v.x[i], coef, a.x[i]);
+    out.y[i] = axpy1<EXACT>(v.y[i], coef, a.y[i]);
+    out.z[i] = axpy1<EXACT>(v.z[i], coef, a.z[i]);
+}
+
+// integrator_rk2.c:61-66:  v += b1*a1 + b2*a2
+template <bool EXACT>
+__global__ __launch_bounds__(TB) void rk2_final_kernel(Cols3 v, CCols3 a1, CCols3 a2, double b1, double b2, long long n) {
+    const long long i = (long long)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    if (EXACT) {
+#pragma clang fp contract(off)
+        v.x[i] += b1 * a1.x[i] + b2 * a2.x[i];
+        v.y[i] += b1 * a1.y[i] + b2 * a2.y[i];
+        v.z[i] += b1 * a1.z[i] + b2 * a2.z[i];
+    } else {
+        v.x[i] += b1 * a1.x[i] + b2 * a2.x[i];
+        v.y[i] += b1 * a1.y[i] + b2 * a2.y[i];
+        v.z[i] += b1 * a1.z[i] + b2 * a2.z[i];
+    }
+}
+
+// integrator_rk4.c:74-82:  stage velocity for k4 = v + dt*k3;  k3 += k2;  k2's accelerations reset
+template <bool EXACT>
+__global__ __launch_bounds__(TB) void rk4_mid_kernel(Cols3 sv, CCols3 v, Cols3 k2a, Cols3 k3a, double dt, long long n) {
+    const long long i = (long long)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    const double k3x = k3a.x[i], k3y = k3a.y[i], k3z = k3a.z[i];
+    sv.x[i] = axpy1<EXACT>(v.x[i], dt, k3x);
+    sv.y[i] = axpy1<EXACT>(v.y[i], dt, k3y);
+    sv.z[i] = axpy1<EXACT>(v.z[i], dt, k3z);
+    k3a.x[i] = k3x + k2a.x[i]; k3a.y[i] = k3y + k2a.y[i]; k3a.z[i] = k3z + k2a.z[i];
+    k2a.x[i] = 0.; k2a.y[i] = 0.; k2a.z[i] = 0.;
+}
+
+// integrator_rk4.c:85-90:  v += dt6*(a1 + a4 + 2.*(k2+k3))
+template <bool EXACT>
+__global__ __launch_bounds__(TB) void rk4_final_kernel(Cols3 v, CCols3 a1, CCols3 a4, CCols3 k23, double dt6, long long n) {
+    const long long i = (long long)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    if (EXACT) {
+#pragma clang fp contract(off)
+        v.x[i] += dt6 * (a1.x[i] + a4.x[i] + 2. * k23.x[i]);
+        v.y[i] += dt6 * (a1.y[i] + a4.y[i] + 2. * k23.y[i]);
+        v.z[i] += dt6 * (a1.z[i] + a4.z[i] + 2. * k23.z[i]);
+    } else {
+        v.x[i] += dt6 * (a1.x[i] + a4.x[i] + 2. * k23.x[i]);
+        v.y[i] += dt6 * (a1.y[i] + a4.y[i] + 2. * k23.y[i]);
+        v.z[i] += dt6 * (a1.z[i] + a4.z[i] + 2. * k23.z[i]);
+    }
+}
+
+// integrator_implicit_midpoint.c:101-114: new estimate of the final velocities from the
+// accelerations at the averaged state; squared change and squared size (compare(), :47-62) as
+// per-workgroup partial sums; then the averaged state for the next round (avg_particles, :32-45).
+template <bool EXACT>
+__global__ __launch_bounds__(TB) void im_update_kernel(Cols3 fin, CCols3 orig, Cols3 avgv, Cols3 avga, double dt, long long n, double* partials) {
+    __shared__ double red[2][TB / 64];
+    const long long i = (long long)blockIdx.x * TB + threadIdx.x;
+    double d2 = 0., t2 = 0.;
+    if (i < n) {
+        const double ox = orig.x[i], oy = orig.y[i], oz = orig.z[i];
+        const double fx = axpy1<EXACT>(ox, dt, avga.x[i]);
+        const double fy = axpy1<EXACT>(oy, dt, avga.y[i]);
+        const double fz = axpy1<EXACT>(oz, dt, avga.z[i]);
+        const double dx = fx - fin.x[i], dy = fy - fin.y[i], dz = fz - fin.z[i];
+        d2 = dx * dx + dy * dy + dz * dz;
+        t2 = fx * fx + fy * fy + fz * fz;
+        fin.x[i] = fx; fin.y[i] = fy; fin.z[i] = fz;
+        avgv.x[i] = 0.5 * (ox + fx); avgv.y[i] = 0.5 * (oy + fy); avgv.z[i] = 0.5 * (oz + fz);
+        avga.x[i] = 0.; avga.y[i] = 0.; avga.z[i] = 0.;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { d2 += __shfl_down(d2, off, 64); t2 += __shfl_down(t2, off, 64); }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { red[0][wave] = d2; red[1][wave] = t2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0., b = 0.;
+        for (int w = 0; w < TB / 64; w++) { a += red[0][w]; b += red[1][w]; }
+        partials[2 * (long long)blockIdx.x] = a;
+        partials[2 * (long long)blockIdx.x + 1] = b;
+    }
+}
+
+// fixed-order sum of the per-workgroup pairs -> out[0], out[1]
+__global__ __launch_bounds__(1024) void im_sum_kernel(const double* partials, long long nb, double* out) {
+    __shared__ double red[2][16];
+    double a = 0., b = 0.;
+    for (long long k = threadIdx.x; k < nb; k += 1024) { a += partials[2 * k]; b += partials[2 * k + 1]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { red[0][wave] = a; red[1][wave] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0., t = 0.;
+        for (int w = 0; w < 16; w++) { s += red[0][w]; t += red[1][w]; }
+        out[0] = s; out[1] = t;
+    }
+}
+
+static inline dim3 grid_for(long long n) { return dim3((unsigned)((n + TB - 1) / TB)); }
+
+hipError_t launch_lincomb(double* const out[3], const double* const v[3], const double* const a[3], double coef, long long n, bool exact, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const Cols3 o = {out[0], out[1], out[2]};
+    const CCols3 cv = {v[0], v[1], v[2]}, ca = {a[0], a[1], a[2]};
+    if (exact) hipLaunchKernelGGL(lincomb_kernel<true>, grid_for(n), dim3(TB), 0, st, o, cv, ca, coef, n);
+    else hipLaunchKernelGGL(lincomb_kernel<false>, grid_for(n), dim3(TB), 0, st, o, cv, ca, coef, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_rk2_final(double* const v[3], const double* const a1[3], const double* const a2[3], double b1, double b2, long long n, bool exact, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const Cols3 o = {v[0], v[1], v[2]};
+    const CCols3 c1 = {a1[0], a1[1], a1[2]}, c2 = {a2[0], a2[1], a2[2]};
+    if (exact) hipLaunchKernelGGL(rk2_final_kernel<true>, grid_for(n), dim3(TB), 0, st, o, c1, c2, b1, b2, n);
+    else hipLaunchKernelGGL(rk2_final_kernel<false>, grid_for(n), dim3(TB), 0, st, o, c1, c2, b1, b2, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_rk4_mid(double* const sv[3], const double* const v[3], double* const k2a[3], double* const k3a[3], double dt, long long n, bool exact, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const Cols3 s = {sv[0], sv[1], sv[2]}, k2 = {k2a[0], k2a[1], k2a[2]}, k3 = {k3a[0], k3a[1], k3a[2]};
+    const CCols3 cv = {v[0], v[1], v[2]};
+    if (exact) hipLaunchKernelGGL(rk4_mid_kernel<true>, grid_for(n), dim3(TB), 0, st, s, cv, k2, k3, dt, n);
+    else hipLaunchKernelGGL(rk4_mid_kernel<false>, grid_for(n), dim3(TB), 0, st, s, cv, k2, k3, dt, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_rk4_final(double* const v[3], const double* const a1[3], const double* const a4[3], const double* const k23[3], double dt6, long long n, bool exact, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const Cols3 o = {v[0], v[1], v[2]};
+    const CCols3 c1 = {a1[0], a1[1], a1[2]}, c4 = {a4[0], a4[1], a4[2]}, c23 = {k23[0], k23[1], k23[2]};
+    if (exact) hipLaunchKernelGGL(rk4_final_kernel<true>, grid_for(n), dim3(TB), 0, st, o, c1, c4, c23, dt6, n);
+    else hipLaunchKernelGGL(rk4_final_kernel<false>, grid_for(n), dim3(TB), 0, st, o, c1, c4, c23, dt6, n);
+    return hipGetLastError();
+}
+
+long long im_partial_count(long long n) { return (n + TB - 1) / TB; }
+
+hipError_t launch_im_update(double* const fin[3], const double* const orig[3], double* const avgv[3], double* const avga[3], double dt,
+                            long long n, double* partials, double* sums, bool exact, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const Cols3 f = {fin[0], fin[1], fin[2]}, av = {avgv[0], avgv[1], avgv[2]}, aa = {avga[0], avga[1], avga[2]};
+    const CCols3 o = {orig[0], orig[1], orig[2]};
+    if (exact) hipLaunchKernelGGL(im_update_kernel<true>, grid_for(n), dim3(TB), 0, st, f, o, av, aa, dt, n, partials);
+    else hipLaunchKernelGGL(im_update_kernel<false>, grid_for(n), dim3(TB), 0, st, f, o, av, aa, dt, n, partials);
+    hipLaunchKernelGGL(im_sum_kernel, dim3(1), dim3(1024), 0, st, partials, im_partial_count(n), sums);
+    return hipGetLastError();
+}
+
+}  // namespace rebxamd

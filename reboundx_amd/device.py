@@ -71,6 +71,23 @@ class Context:
         arr = (Op * len(ops))(*ops)
         self._check(lib.rebxamd_add_pushes(self._h, ctypes.byref(view), arr, len(ops), sums.data_ptr(), self._stream()))
 
+    def integrate_force(self, view, ops, integrator, dt, mode=_lib.MODE_FAST):
+        """rebx_integrate_force on device columns: velocities of `view` are updated in place.
+        `integrator`: one of "euler", "rk2", "rk4", "implicit_midpoint", "none" (or the enum
+        value).  Returns the implicit-midpoint loop counter."""
+        code = {"none": -1, "implicit_midpoint": 0, "rk4": 1, "euler": 2, "rk2": 3}.get(integrator, integrator)
+        arr = (Op * max(len(ops), 1))(*ops)
+        it = ctypes.c_int(0)
+        self._check(lib.rebxamd_integrate_force(self._h, ctypes.byref(view), arr, len(ops), int(code), float(dt), mode,
+                                                ctypes.byref(it), self._stream()))
+        return it.value
+
+    def kick(self, view, dt, mode=_lib.MODE_FAST):
+        self._check(lib.rebxamd_kick(self._h, ctypes.byref(view), float(dt), mode, self._stream()))
+
+    def drift(self, view, dt, mode=_lib.MODE_FAST):
+        self._check(lib.rebxamd_drift(self._h, ctypes.byref(view), float(dt), mode, self._stream()))
+
     def reset_accelerations(self, view):
         self._check(lib.rebxamd_reset_accelerations(self._h, ctypes.byref(view), self._stream()))
 

@@ -164,3 +164,35 @@ def apply_forces(sim, forces, pp, gravity_ignore_terms=0):
             assert rc == 0
         else:
             raise ValueError(name)
+
+
+INTEGRATORS = {"none": -1, "implicit_midpoint": 0, "rk4": 1, "euler": 2, "rk2": 3}
+_FORCE_FN = ctypes.CFUNCTYPE(None, POINTER(OrcSim), c_void_p)
+lib.orc_integrate_force.restype = c_int
+lib.orc_integrate_force.argtypes = [POINTER(OrcSim), c_int, c_double, _FORCE_FN, c_void_p]
+lib.orc_drift_step.argtypes = [POINTER(OrcSim), c_double]
+lib.orc_kick_step.argtypes = [POINTER(OrcSim), c_double]
+
+
+class _StateView:
+    """A stage state handed to the force callback by the checker's integrators."""
+
+    def __init__(self, s):
+        self.s, self.N, self.G = s, s.N, s.G
+
+
+def integrate_force(sim, integrator, dt, forces, pp, gravity_ignore_terms=0):
+    """src/integrate_force.c:34-78 with `forces` (execution order) as the integrated force.
+    Velocities of `sim` are updated in place; returns the implicit-midpoint loop counter."""
+    def cb(ptr, _user):
+        apply_forces(_StateView(ptr.contents), forces, pp, gravity_ignore_terms)
+    return lib.orc_integrate_force(ctypes.byref(sim.s), INTEGRATORS[integrator] if isinstance(integrator, str) else integrator,
+                                   float(dt), _FORCE_FN(cb), None)
+
+
+def drift_step(sim, dt):
+    lib.orc_drift_step(ctypes.byref(sim.s), float(dt))
+
+
+def kick_step(sim, dt):
+    lib.orc_kick_step(ctypes.byref(sim.s), float(dt))

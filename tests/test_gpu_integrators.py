@@ -1,0 +1,139 @@
+"""The "integrate a force across a timestep" operator and the kick/drift steppers on the GPU
+(rebxamd_integrate_force / rebxamd_kick / rebxamd_drift through the C ABI) against the CPU
+checker's restatement of src/integrate_force.c and src/integrator_*.c.
+
+Bars: reference-order arithmetic (MODE_EXACT) on a star + planets + massless-dust layout is
+bitwise equal to the checker for the explicit schemes (everything is elementwise); the default
+arithmetic and layouts with parallel reductions meet 1e-12 relative to the velocity change of
+the particle (the quantity the operator computes; the velocity itself is O(1) and would hide
+errors)."""
+import numpy as np
+import pytest
+
+import oracle
+from gpu_common import TOL, ulp_diff
+from reboundx_amd import synthetic
+from reboundx_amd.device import DeviceParticles
+from reboundx_amd.program import build_ops
+
+pytestmark = pytest.mark.gpu
+C = synthetic.C_DEFAULT
+EXACT, FAST = 1, 0
+C5_STACK = [("radiation_forces", {"c": C}), ("gravitational_harmonics", {}), ("gr_potential", {"c": C}),
+            ("tides_precession", {}), ("modify_orbits_forces", {})]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from reboundx_amd.device import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def device_state(cols, pp, **kw):
+    host = dict(cols)
+    for k in ("beta", "R_tides", "k1", "tau_a", "tau_e", "tau_inc"):
+        if pp.get(k) is not None:
+            host[k] = pp[k]
+    return DeviceParticles.from_host(host, device="cuda:0", **kw)
+
+
+def vel(dp):
+    return np.array([dp.cols[k].cpu().numpy() for k in ("vx", "vy", "vz")])
+
+
+def run_pair(ctx, cols, pp, forces, integrator, dt, mode, **kw):
+    ref = oracle.Sim(cols)
+    n_ref = oracle.integrate_force(ref, integrator, dt, forces, pp)
+    dp = device_state(cols, pp, **kw)
+    n_dev = ctx.integrate_force(dp.view(), build_ops(forces, pp), integrator, dt, mode)
+    v0 = np.array([cols[k] for k in ("vx", "vy", "vz")])
+    vr = np.array([ref.cols[k] for k in ("vx", "vy", "vz")])
+    return v0, vr, vel(dp), np.array(ref.acc), np.array(dp.acc_host()), n_ref, n_dev
+
+
+def dv_err(v0, vr, vd):
+    dv = vr - v0
+    scale = np.abs(dv).max(axis=0)
+    scale = np.where(scale == 0., 1., scale)
+    # the update is formed as v + dt*a: it cannot carry more digits than eps*|v| allows
+    floor = 4 * np.finfo(float).eps * np.abs(vr).max(axis=0)
+    return (np.abs(vd - vr) / np.maximum(scale, floor / TOL)[None, :]).max()
+
+
+@pytest.mark.parametrize("mode", [EXACT, FAST])
+@pytest.mark.parametrize("integrator", ["euler", "rk2", "rk4", "implicit_midpoint"])
+def test_five_effect_stack_star_planets_dust(ctx, integrator, mode):
+    n = 6001
+    cols, pp, _ = synthetic.disk(n, 2)
+    v0, vr, vd, ar, ad, n_ref, n_dev = run_pair(ctx, cols, pp, C5_STACK, integrator, 0.01, mode)
+    assert n_ref == n_dev
+    if mode == EXACT and integrator != "implicit_midpoint":
+        assert ulp_diff(vd, vr).max() == 0
+        assert ulp_diff(ad, ar).max() == 0            # what is left in the acceleration columns (k1)
+    assert dv_err(v0, vr, vd) <= TOL
+    if integrator == "implicit_midpoint":
+        assert 1 <= n_dev < 10 and not ad.any() and not ar.any()
+
+
+@pytest.mark.parametrize("integrator", ["rk4", "implicit_midpoint"])
+def test_every_particle_massive_uses_reductions(ctx, integrator):
+    n = 20011
+    cols, pp, _ = synthetic.disk(n, 1, dust_mass=1e-12)
+    pp["primary"] = np.zeros(n, dtype=np.uint8)
+    pp["primary"][0] = 1
+    forces = [("tides_precession", {}), ("modify_orbits_forces", {"coordinates": 2}), ("gr_potential", {"c": C})]
+    v0, vr, vd, *_ = run_pair(ctx, cols, pp, forces, integrator, 0.02, EXACT)
+    assert dv_err(v0[:, 1:], vr[:, 1:], vd[:, 1:]) <= TOL
+    # the star's update is a sum over all bodies
+    push = np.abs(vr[:, 1:] - v0[:, 1:]).max() * 1e-12 * n
+    assert np.abs(vd[:, 0] - vr[:, 0]).max() <= 1e-12 * max(push, np.abs(vr[:, 0] - v0[:, 0]).max()) + 4e-16 * np.abs(vr[:, 0]).max()
+
+
+def test_none_integrator_only_clears_accelerations(ctx):
+    cols, pp, _ = synthetic.disk(100, 1)
+    synthetic.add_newtonian(cols, n_head=2)
+    dp = device_state(cols, pp)
+    ctx.integrate_force(dp.view(), build_ops(C5_STACK, pp), "none", 0.1)
+    assert np.array_equal(vel(dp), np.array([cols[k] for k in ("vx", "vy", "vz")]))
+    assert not np.array(dp.acc_host()).any()
+
+
+def test_implicit_midpoint_reports_non_convergence(ctx):
+    """A drag so strong that the fixed-point iteration diverges: 10 rounds, warning bit 4
+    (reference: reb_warning, integrator_implicit_midpoint.c:116-118)."""
+    n = 50
+    cols, pp, _ = synthetic.disk(n, 1)
+    pp["tau_a"] = np.full(n, np.nan)
+    pp["tau_a"][1:] = -1e-3
+    forces = [("modify_orbits_forces", {})]
+    ref = oracle.Sim(cols)
+    assert oracle.integrate_force(ref, "implicit_midpoint", 1.0, forces, pp) == 10
+    dp = device_state(cols, pp)
+    ctx.fetch_warnings()
+    assert ctx.integrate_force(dp.view(), build_ops(forces, pp), "implicit_midpoint", 1.0, EXACT) == 10
+    assert ctx.fetch_warnings() & 4
+
+
+@pytest.mark.parametrize("mode", [EXACT, FAST])
+def test_kick_and_drift(ctx, mode):
+    n = 4097
+    cols, pp, _ = synthetic.disk(n, 1)
+    synthetic.add_newtonian(cols, n_head=2)
+    ref = oracle.Sim(cols)
+    oracle.kick_step(ref, 0.03)
+    oracle.drift_step(ref, 0.07)
+    dp = device_state(cols, pp)
+    ctx.kick(dp.view(), 0.03, mode)
+    ctx.drift(dp.view(), 0.07, mode)
+    got = np.array([dp.cols[k].cpu().numpy() for k in ("x", "y", "z", "vx", "vy", "vz")])
+    want = np.array([ref.cols[k] for k in ("x", "y", "z", "vx", "vy", "vz")])
+    if mode == EXACT:
+        assert ulp_diff(got, want).max() == 0
+    else:
+        # fused multiply-add: one rounding instead of two; where x + dt*v cancels, the
+        # difference is bounded by the size of the terms, not of the result
+        vk = np.array([cols[k] for k in ("vx", "vy", "vz")]) + 0.03 * np.array([cols[k] for k in ("ax", "ay", "az")])
+        terms = np.concatenate([np.abs(np.array([cols[k] for k in ("x", "y", "z")])) + 0.07 * np.abs(vk), np.abs(vk) + 1.0])
+        assert (np.abs(got - want) <= 2.3e-16 * terms).all()

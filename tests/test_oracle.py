@@ -379,3 +379,35 @@ def test_reference_trajectory_archive_pins_force(archive_baseline, name):
         end = _integrate(c0, 0.0, t1, lambda s: oracle.gr(s, 1e4))
         wrong = np.array([end[k] for k in ("x", "y", "z", "vx", "vy", "vz")]).T - orc_free
         assert np.abs(wrong - effect_ref).max() > 0.1 * scale
+
+
+# ------------------------------------------------------------- force integrators of the checker
+
+@pytest.mark.parametrize("integrator,order", [("euler", 1), ("rk2", 2), ("rk4", 4), ("implicit_midpoint", 2)])
+def test_integrate_force_schemes_have_their_order(integrator, order):
+    """dv/dt = a(x, v) with a velocity-dependent force (radiation + orbit damping) at fixed
+    positions: halving dt must shrink the one-step error by 2^(order+1)."""
+    cols, pp, _ = synthetic.disk(40, 1)
+    forces = [("radiation_forces", {"c": 50.0}), ("modify_orbits_forces", {})]
+    pp = dict(pp)
+    pp["tau_a"] = np.where(np.isnan(pp["tau_a"]), np.nan, -3.0)
+
+    def step(dt, scheme, nsub=1):
+        s = oracle.Sim(cols)
+        for _ in range(nsub):
+            oracle.integrate_force(s, scheme, dt / nsub, forces, pp)
+        return np.array([s.cols[k] for k in ("vx", "vy", "vz")])
+
+    exact = step(0.4, "rk4", 64)
+    e1 = np.abs(step(0.4, integrator) - exact).max()
+    e2 = np.abs(step(0.2, integrator, 1) - step(0.2, "rk4", 32)).max()
+    assert e1 / e2 == pytest.approx(2.0 ** (order + 1), rel=0.35)
+
+
+def test_integrate_force_none_only_clears_accelerations():
+    cols, pp, _ = synthetic.disk(10, 1)
+    synthetic.add_newtonian(cols, n_head=2)
+    s = oracle.Sim(cols)
+    assert oracle.integrate_force(s, "none", 0.1, [("gr_potential", {"c": 100.0})], pp) == 0
+    assert not np.array(s.acc).any()
+    assert all(np.array_equal(s.cols[k], cols[k]) for k in ("vx", "vy", "vz"))
