@@ -77,6 +77,22 @@ struct rebx_force {
     void (*update_accelerations)(struct reb_simulation* const sim, struct rebx_force* const force,
                                  struct reb_particle* const particles, const int N);
 };
+/* src/reboundx.h:73-76, :90-94 */
+enum rebx_timing { REBX_TIMING_PRE = -1, REBX_TIMING_POST = 1 };
+enum rebx_operator_type { REBX_OPERATOR_NONE, REBX_OPERATOR_UPDATER, REBX_OPERATOR_RECORDER };
+/* src/reboundx.h:203-210 -- 40 bytes (mirrored by ctypes, reference reboundx/extras.py:254-258) */
+struct rebx_operator {
+    char* name;
+    struct rebx_node* ap;
+    struct reb_simulation* sim;
+    enum rebx_operator_type operator_type;
+    void (*step_function)(struct reb_simulation* sim, struct rebx_operator* op, const double dt);
+};
+/* src/reboundx.h:216-219 */
+struct rebx_step {
+    struct rebx_operator* op;
+    double dt_fraction;
+};
 /* src/reboundx.h:233-243 -- 56 bytes; Python allocates this struct itself
  * (reference reboundx/extras.py:39-45, :291-297), so the size and field order are frozen.
  * Device state hangs off a side table keyed by the struct's address. */
@@ -137,6 +153,31 @@ void rebx_error(struct rebx_extras* rebx, const char* const msg);
  * maximal run of built-in forces as one fused device pass, and calls user-supplied
  * callbacks on the host in between. */
 void rebx_additional_forces(struct reb_simulation* sim);
+
+/* Operators on the additional-force path: the "integrate a force across a timestep" operator and
+ * the kick/drift steppers.  src/reboundx.h:331, :329, :327, :280; src/core.c:279-368, :411-510,
+ * :637-648, :697-728.  rebx_load_operator knows "integrate_force", "kick" and "drift"; the
+ * reference's other operators (modify_mass, modify_orbits_direct, track_min_distance, kepler,
+ * jump, interaction, ias15) are not part of this library and report "not found". */
+struct rebx_operator* rebx_create_operator(struct rebx_extras* const rebx, const char* name);
+struct rebx_operator* rebx_load_operator(struct rebx_extras* const rebx, const char* name);
+int rebx_add_operator(struct rebx_extras* rebx, struct rebx_operator* op);
+int rebx_add_operator_step(struct rebx_extras* rebx, struct rebx_operator* op, const double dt_fraction, enum rebx_timing timing);
+int rebx_remove_operator(struct rebx_extras* rebx, struct rebx_operator* op);
+struct rebx_operator* rebx_get_operator(struct rebx_extras* const rebx, const char* const name);
+/* src/core.c:882-912: installed as sim->pre/post_timestep_modifications; run every step of the
+ * respective list with dt = sim->dt * dt_fraction */
+void rebx_pre_timestep_modifications(struct reb_simulation* sim);
+void rebx_post_timestep_modifications(struct reb_simulation* sim);
+/* src/integrate_force.c:34-78 (operator parameters "force" and "integrator").  A built-in force
+ * is integrated on the device in one round trip (rebxamd_integrate_force); a user callback is
+ * integrated on the host with the same schemes, calling it on the stage arrays. */
+void rebx_integrate_force(struct reb_simulation* const sim, struct rebx_operator* const op, const double dt);
+/* src/steppers.c:112-133.  rebx_kick_step uses the accelerations held in sim->particles; when
+ * built against REBOUND (REBXAMD_WITH_REBOUND) it first calls reb_update_acceleration as the
+ * reference does. */
+void rebx_drift_step(struct reb_simulation* const sim, struct rebx_operator* const op, const double dt);
+void rebx_kick_step(struct reb_simulation* const sim, struct rebx_operator* const op, const double dt);
 /* src/core.h:61, src/core.c:860-866 */
 void rebx_reset_accelerations(struct reb_particle* const ps, const int N);
 

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cfloat>
 #include <chrono>
 #include <mutex>
 #include <string>
@@ -70,6 +71,7 @@ extern "C" void rebxamd_clear_messages(struct reb_simulation* r) {
 
 using rebxamd::WARN_GR_ITER;
 using rebxamd::WARN_GRFULL_SWEEPS;
+using rebxamd::WARN_IM_ITER;
 
 // ------------------------------------------------------------------ per-extras device state
 namespace {
@@ -377,6 +379,8 @@ extern "C" void rebx_detach(struct reb_simulation* sim, struct rebx_extras* rebx
     rebx->sim = NULL;
     if (sim->extras == rebx) {          // only un-hook what is still ours
         if (sim->additional_forces == rebx_additional_forces) sim->additional_forces = NULL;
+        if (sim->pre_timestep_modifications == rebx_pre_timestep_modifications) sim->pre_timestep_modifications = NULL;
+        if (sim->post_timestep_modifications == rebx_post_timestep_modifications) sim->post_timestep_modifications = NULL;
         if (sim->free_particle_ap == rebx_free_particle_ap) sim->free_particle_ap = NULL;
     }
 }
@@ -406,6 +410,25 @@ extern "C" void rebx_free_pointers(struct rebx_extras* rebx) {                  
         cur = next;
     }
     rebx->additional_forces = NULL;
+    for (struct rebx_node** head : {&rebx->pre_timestep_modifications, &rebx->post_timestep_modifications}) {
+        for (struct rebx_node* cur = *head; cur;) {
+            struct rebx_node* next = cur->next;
+            free(cur->object);          // the step; its operator is owned by allocated_operators
+            free(cur);
+            cur = next;
+        }
+        *head = NULL;
+    }
+    for (struct rebx_node* cur = rebx->allocated_operators; cur;) {
+        struct rebx_node* next = cur->next;
+        struct rebx_operator* op = (struct rebx_operator*)cur->object;
+        free(op->name);
+        free_param_list(&op->ap);
+        free(op);
+        free(cur);
+        cur = next;
+    }
+    rebx->allocated_operators = NULL;
     for (struct rebx_node* cur = rebx->registered_params; cur;) {
         struct rebx_node* next = cur->next;
         free_param((struct rebx_param*)cur->object, false);
@@ -671,15 +694,13 @@ bool ops_of_force(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* 
     return true;
 }
 
-// Runs a run of built-in forces on `particles` (host array-of-structs) in one device round trip.
-void run_builtin(struct reb_simulation* sim, struct rebx_extras* rebx, const std::vector<Pending>& batch,
-                 struct reb_particle* const particles, const int N) {
-    if (batch.empty() || N <= 0) return;
-    Bridge* b = bridge_of(rebx, true);
-    if (!ensure_capacity(rebx, b, (size_t)N)) return;
-
-    // ---- pack: array-of-structs -> columns; fold the parameter-list heads into a checksum
-    const double t0 = now_ms();
+// Host array-of-structs -> device columns: packs, re-flattens the parameter lists if they changed,
+// uploads.  On success `v` describes the device copy; t[0..2] = times at start, after packing,
+// after the upload.
+bool stage_in(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* b, const struct reb_particle* particles, const int N,
+              rebxamd_view& v, double t[3]) {
+    if (!ensure_capacity(rebx, b, (size_t)N)) return false;
+    t[0] = now_ms();
     unsigned long long sum = 1469598103934665603ull;
     long long last_massive = -1;
     double* const* h = b->h_dyn;
@@ -694,14 +715,8 @@ void run_builtin(struct reb_simulation* sim, struct rebx_extras* rebx, const std
     }
     const bool rebuild = b->built_generation != b->generation || b->built_n != N || b->built_checksum != sum;
     if (rebuild) flatten_params(rebx, b, particles, N);
-    const double t1 = now_ms();
+    t[1] = now_ms();
 
-    // ---- ops (effect parameters are read on every call: they are a handful of list walks)
-    std::vector<rebxamd_op> ops;
-    for (const Pending& pf : batch) ops_of_force(sim, rebx, b, pf, ops);
-    if (ops.empty()) { b->timings[0] = t1 - t0; b->timings[1] = b->timings[2] = b->timings[3] = 0.; return; }
-
-    // ---- host -> device
     hipStream_t st = nullptr;
     const size_t bytes = (size_t)N * sizeof(double);
     bool ok = true;
@@ -712,11 +727,9 @@ void run_builtin(struct reb_simulation* sim, struct rebx_extras* rebx, const std
         b->built_generation = b->generation; b->built_n = N; b->built_checksum = sum;
     }
     ok = ok && hipStreamSynchronize(st) == hipSuccess;
-    const double t2 = now_ms();
-    if (!ok) { rebx_error(rebx, "REBOUNDx (MI355X) Error: host to device copy failed.\n"); return; }
+    t[2] = now_ms();
+    if (!ok) { rebx_error(rebx, "REBOUNDx (MI355X) Error: host to device copy failed.\n"); return false; }
 
-    // ---- kernels
-    rebxamd_view v;
     memset(&v, 0, sizeof(v));
     v.n = N;
     v.n_head = last_massive + 1 < 1 ? 1 : last_massive + 1;
@@ -732,6 +745,33 @@ void run_builtin(struct reb_simulation* sim, struct rebx_extras* rebx, const std
     v.tau_a = b->par_used[P_TA] ? b->d_par[P_TA] : nullptr;
     v.tau_e = b->par_used[P_TE] ? b->d_par[P_TE] : nullptr;
     v.tau_inc = b->par_used[P_TI] ? b->d_par[P_TI] : nullptr;
+    return true;
+}
+
+void report_warnings(struct reb_simulation* sim, uint32_t bits) {
+    if (bits & WARN_GR_ITER)
+        reb_warning(sim, "REBOUNDx Warning: 10 iterations in gr.c failed to converge. This is typically because the perturbation is too strong for the current implementation.");
+    if (bits & WARN_GRFULL_SWEEPS) reb_warning(sim, "10 loops in rebx_gr_full did not converge.\n");
+    if (bits & WARN_IM_ITER)
+        reb_warning(sim, "REBOUNDx: 10 iterations in integrator_implicit_midpoint.c failed to converge. This is typically because the perturbation is too strong for the current implementation.");
+}
+
+// Runs a run of built-in forces on `particles` (host array-of-structs) in one device round trip.
+void run_builtin(struct reb_simulation* sim, struct rebx_extras* rebx, const std::vector<Pending>& batch,
+                 struct reb_particle* const particles, const int N) {
+    if (batch.empty() || N <= 0) return;
+    Bridge* b = bridge_of(rebx, true);
+    rebxamd_view v;
+    double t[3];
+    if (!stage_in(sim, rebx, b, particles, N, v, t)) return;
+
+    // ---- ops (effect parameters are read on every call: they are a handful of list walks)
+    std::vector<rebxamd_op> ops;
+    for (const Pending& pf : batch) ops_of_force(sim, rebx, b, pf, ops);
+    if (ops.empty()) { b->timings[0] = t[1] - t[0]; b->timings[1] = t[2] - t[1]; b->timings[2] = b->timings[3] = 0.; return; }
+
+    // ---- kernels
+    hipStream_t st = nullptr;
     const int rc = rebxamd_apply(b->ctx, &v, ops.data(), (int)ops.size(), b->mode, st);
     if (rc != REBXAMD_OK) {
         char str[400];
@@ -740,10 +780,12 @@ void run_builtin(struct reb_simulation* sim, struct rebx_extras* rebx, const std
         reb_error(sim, str);
         return;
     }
-    ok = hipStreamSynchronize(st) == hipSuccess;
+    bool ok = hipStreamSynchronize(st) == hipSuccess;
     const double t3 = now_ms();
 
     // ---- device -> host, columns -> array-of-structs
+    const size_t bytes = (size_t)N * sizeof(double);
+    double* const* h = b->h_dyn;
     for (int k = H_AX; k <= H_AZ && ok; k++) ok = hipMemcpyAsync(b->h_dyn[k], b->d_dyn[k], bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
     uint32_t bits = 0;
     ok = ok && rebxamd_fetch_warnings(b->ctx, &bits, st) == REBXAMD_OK;     // synchronises the stream
@@ -752,10 +794,8 @@ void run_builtin(struct reb_simulation* sim, struct rebx_extras* rebx, const std
         particles[i].ax = h[H_AX][i]; particles[i].ay = h[H_AY][i]; particles[i].az = h[H_AZ][i];
     }
     const double t4 = now_ms();
-    if (bits & WARN_GR_ITER)
-        reb_warning(sim, "REBOUNDx Warning: 10 iterations in gr.c failed to converge. This is typically because the perturbation is too strong for the current implementation.");
-    if (bits & WARN_GRFULL_SWEEPS) reb_warning(sim, "10 loops in rebx_gr_full did not converge.\n");
-    b->timings[0] = t1 - t0; b->timings[1] = t2 - t1; b->timings[2] = t3 - t2; b->timings[3] = t4 - t3;
+    report_warnings(sim, bits);
+    b->timings[0] = t[1] - t[0]; b->timings[1] = t[2] - t[1]; b->timings[2] = t3 - t[2]; b->timings[3] = t4 - t3;
 }
 
 void run_single(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N) {
@@ -797,3 +837,298 @@ extern "C" void rebx_modify_orbits_forces(struct reb_simulation* const sim, stru
 extern "C" void rebx_tides_precession(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N) { run_single(sim, force, particles, N); }
 extern "C" void rebx_central_force(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N) { run_single(sim, force, particles, N); }
 extern "C" void rebx_gravitational_harmonics(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N) { run_single(sim, force, particles, N); }
+
+// ------------------------------------------------------------------ operators
+static void free_operator(struct rebx_operator* op) {                               // src/core.c:780-786
+    free(op->name);
+    free_param_list(&op->ap);
+    free(op);
+}
+
+extern "C" struct rebx_operator* rebx_create_operator(struct rebx_extras* const rebx, const char* name) {     // src/core.c:279-314
+    if (rebx->sim == NULL) { rebx_error(rebx, ""); return NULL; }
+    struct rebx_operator* op = (struct rebx_operator*)checked_malloc(rebx, sizeof(*op));
+    if (!op) return NULL;
+    op->ap = NULL;
+    op->sim = rebx->sim;
+    op->operator_type = REBX_OPERATOR_NONE;
+    op->step_function = NULL;
+    op->name = NULL;
+    if (name != NULL) {
+        op->name = dup_name(rebx, name);
+        if (!op->name) { free(op); return NULL; }
+    }
+    struct rebx_node* n = new_node(rebx, op);
+    if (!n) { free(op->name); free(op); return NULL; }
+    list_push_front(&rebx->allocated_operators, n);
+    return op;
+}
+
+extern "C" struct rebx_operator* rebx_load_operator(struct rebx_extras* const rebx, const char* name) {       // src/core.c:316-368
+    struct rebx_operator* op = rebx_create_operator(rebx, name);
+    if (!op) return NULL;
+    if (strcmp(name, "integrate_force") == 0) op->step_function = rebx_integrate_force;
+    else if (strcmp(name, "drift") == 0) op->step_function = rebx_drift_step;
+    else if (strcmp(name, "kick") == 0) op->step_function = rebx_kick_step;
+    else {
+        char str[300];
+        snprintf(str, sizeof(str), "REBOUNDx error: Operator '%s' not found in REBOUNDx library.\n", name);
+        rebx_error(rebx, str);
+        rebx_remove_operator(rebx, op);
+        return NULL;
+    }
+    op->operator_type = REBX_OPERATOR_UPDATER;
+    return op;
+}
+
+extern "C" int rebx_add_operator_step(struct rebx_extras* rebx, struct rebx_operator* op, const double dt_fraction, enum rebx_timing timing) {   // src/core.c:411-460
+    if (rebx->sim == NULL) { rebx_error(rebx, ""); return 0; }
+    if (op == NULL) { rebx_error(rebx, "REBOUNDx error: Passed NULL pointer to rebx_add_operator_step.\n"); return 0; }
+    if (op->step_function == NULL) {
+        rebx_error(rebx, "REBOUNDx error: Need to set step_function pointer on operator before adding to simulation. See custom effects example.\n");
+        return 0;
+    }
+    if (op->operator_type == REBX_OPERATOR_NONE) {
+        rebx_error(rebx, "REBOUNDx error: Need to set operator_type field on operator before adding to simulation. See custom effects example.\n");
+        return 0;
+    }
+    if (timing != REBX_TIMING_PRE && timing != REBX_TIMING_POST) return 0;
+    struct rebx_step* step = (struct rebx_step*)checked_malloc(rebx, sizeof(*step));
+    if (!step) return 0;
+    step->op = op;
+    step->dt_fraction = dt_fraction;
+    struct rebx_node* n = new_node(rebx, step);
+    if (!n) { free(step); return 0; }
+    struct reb_simulation* sim = rebx->sim;
+    if (timing == REBX_TIMING_PRE) {
+        list_push_front(&rebx->pre_timestep_modifications, n);
+        if (sim->pre_timestep_modifications != NULL && sim->pre_timestep_modifications != rebx_pre_timestep_modifications)
+            reb_warning(sim, "REBOUNDx Warning: pre_timestep_modifications was set in the simulation and is being overwritten by REBOUNDx. To incorporate both, you can add your own custom effects through REBOUNDx.\n");
+        sim->pre_timestep_modifications = rebx_pre_timestep_modifications;
+    } else {
+        list_push_front(&rebx->post_timestep_modifications, n);
+        if (sim->post_timestep_modifications != NULL && sim->post_timestep_modifications != rebx_post_timestep_modifications)
+            reb_warning(sim, "REBOUNDx Warning: post_timestep_modifications was set in the simulation and is being overwritten by REBOUNDx. To incorporate both, you can add your own custom effects through REBOUNDx.\n");
+        sim->post_timestep_modifications = rebx_post_timestep_modifications;
+    }
+    return 1;
+}
+
+extern "C" int rebx_add_operator(struct rebx_extras* rebx, struct rebx_operator* op) {      // src/core.c:462-506
+    if (rebx->sim == NULL) { rebx_error(rebx, ""); return 0; }
+    if (op == NULL) { rebx_error(rebx, "REBOUNDx error: Passed NULL pointer to rebx_add_operator.\n"); return 0; }
+    struct reb_simulation* const sim = rebx->sim;
+    if (op->operator_type == REBX_OPERATOR_RECORDER) return rebx_add_operator_step(rebx, op, 1., REBX_TIMING_POST);
+    switch (sim->integrator) {
+    case REB_INTEGRATOR_IAS15:          // the step size is not known before the step: whole step afterwards
+        return rebx_add_operator_step(rebx, op, 1., REBX_TIMING_POST);
+    case REB_INTEGRATOR_WHFAST: {       // half a step before, half a step after
+        const int before = rebx_add_operator_step(rebx, op, 1. / 2., REBX_TIMING_PRE);
+        const int after = rebx_add_operator_step(rebx, op, 1. / 2., REBX_TIMING_POST);
+        return before && after;
+    }
+    case REB_INTEGRATOR_MERCURIUS:
+        if (op->operator_type == REBX_OPERATOR_UPDATER)
+            reb_error(sim, "REBOUNDx Error: Operators that affect particle trajectories are not supported with Mercurius. Must add as forces.\n");
+        return 0;
+    default:
+        return 0;
+    }
+}
+
+// removes the first step that uses `op`; 1 if one was found (src/core.c:667-695)
+static int remove_one_step(struct rebx_node** head, struct rebx_operator* op) {
+    for (struct rebx_node** link = head; *link; link = &(*link)->next) {
+        struct rebx_step* step = (struct rebx_step*)(*link)->object;
+        if (step->op == op) {
+            struct rebx_node* dead = *link;
+            *link = dead->next;
+            free(step);
+            free(dead);
+            return 1;
+        }
+    }
+    return 0;
+}
+
+extern "C" int rebx_remove_operator(struct rebx_extras* rebx, struct rebx_operator* op) {   // src/core.c:697-728
+    const int allocated = list_remove_object(&rebx->allocated_operators, op);
+    int success = 0;
+    while (remove_one_step(&rebx->pre_timestep_modifications, op)) success = 1;
+    while (remove_one_step(&rebx->post_timestep_modifications, op)) success = 1;
+    if (allocated) free_operator(op);
+    return success;
+}
+
+extern "C" struct rebx_operator* rebx_get_operator(struct rebx_extras* const rebx, const char* const name) {  // src/core.c:637-648
+    for (struct rebx_node* cur = rebx->allocated_operators; cur; cur = cur->next) {
+        struct rebx_operator* op = (struct rebx_operator*)cur->object;
+        if (op->name && strcmp(op->name, name) == 0) return op;
+    }
+    return NULL;
+}
+
+static void run_steps(struct reb_simulation* sim, struct rebx_node* head) {         // src/core.c:882-912
+    const double dt = sim->dt;
+    for (struct rebx_node* cur = head; cur; cur = cur->next) {
+        struct rebx_step* step = (struct rebx_step*)cur->object;
+#ifdef REBXAMD_WITH_REBOUND
+        if (sim->integrator == REB_INTEGRATOR_IAS15 && sim->ri_ias15.epsilon != 0 && step->op->operator_type == REBX_OPERATOR_UPDATER)
+            reb_warning(sim, "REBOUNDx: Operators that affect particle trajectories with adaptive timesteps can give spurious results. Use sim.ri_ias15.epsilon=0 for fixed timestep with IAS, or use a different integrator.");
+#endif
+        step->op->step_function(sim, step->op, dt * step->dt_fraction);
+    }
+}
+extern "C" void rebx_pre_timestep_modifications(struct reb_simulation* sim) {
+    if (struct rebx_extras* rebx = (struct rebx_extras*)sim->extras) run_steps(sim, rebx->pre_timestep_modifications);
+}
+extern "C" void rebx_post_timestep_modifications(struct reb_simulation* sim) {
+    if (struct rebx_extras* rebx = (struct rebx_extras*)sim->extras) run_steps(sim, rebx->post_timestep_modifications);
+}
+
+extern "C" void rebx_drift_step(struct reb_simulation* const sim, struct rebx_operator* const, const double dt) {   // src/steppers.c:112-121
+    struct reb_particle* const ps = sim->particles;
+    for (int i = 0; i < sim->N; i++) {
+        ps[i].x += dt * ps[i].vx; ps[i].y += dt * ps[i].vy; ps[i].z += dt * ps[i].vz;
+    }
+}
+
+extern "C" void rebx_kick_step(struct reb_simulation* const sim, struct rebx_operator* const, const double dt) {    // src/steppers.c:123-133
+#ifdef REBXAMD_WITH_REBOUND
+    reb_update_acceleration(sim);
+#endif
+    struct reb_particle* const ps = sim->particles;
+    for (int i = 0; i < sim->N; i++) {
+        ps[i].vx += dt * ps[i].ax; ps[i].vy += dt * ps[i].ay; ps[i].vz += dt * ps[i].az;
+    }
+}
+
+namespace {
+
+typedef void (*force_fn)(struct reb_simulation* const, struct rebx_force* const, struct reb_particle* const, const int);
+
+// The four schemes on host arrays, for a force that is a user callback (it can only run on the
+// host).  Stage arrays are full copies of the particle array, as the callback contract expects
+// (src/integrator_rk4.c:40-91, integrator_rk2.c:38-67, integrator_euler.c:33-41,
+// integrator_implicit_midpoint.c:83-124).
+void integrate_on_host(struct reb_simulation* sim, struct rebx_force* force, int integrator, double dt, int N) {
+    struct reb_particle* const ps = sim->particles;
+    const force_fn f = force->update_accelerations;
+    auto stage = [&](std::vector<struct reb_particle>& k, const struct reb_particle* acc_of, double h) {
+        for (int i = 0; i < N; i++) {
+            k[i].vx = ps[i].vx + h * acc_of[i].ax; k[i].vy = ps[i].vy + h * acc_of[i].ay; k[i].vz = ps[i].vz + h * acc_of[i].az;
+        }
+    };
+    if (integrator == REBXAMD_INTEGRATOR_EULER) {
+        f(sim, force, ps, N);
+        for (int i = 0; i < N; i++) { ps[i].vx += dt * ps[i].ax; ps[i].vy += dt * ps[i].ay; ps[i].vz += dt * ps[i].az; }
+    } else if (integrator == REBXAMD_INTEGRATOR_RK2) {
+        std::vector<struct reb_particle> k2(ps, ps + N);
+        f(sim, force, ps, N);
+        stage(k2, ps, 2. * dt / 3.);
+        f(sim, force, k2.data(), N);
+        const double b1 = dt / 4., b2 = 3. * dt / 4.;
+        for (int i = 0; i < N; i++) {
+            ps[i].vx += b1 * ps[i].ax + b2 * k2[i].ax; ps[i].vy += b1 * ps[i].ay + b2 * k2[i].ay; ps[i].vz += b1 * ps[i].az + b2 * k2[i].az;
+        }
+    } else if (integrator == REBXAMD_INTEGRATOR_RK4) {
+        rebx_reset_accelerations(ps, N);
+        std::vector<struct reb_particle> k2(ps, ps + N), k3(ps, ps + N);
+        f(sim, force, ps, N);
+        stage(k2, ps, dt / 2.);
+        f(sim, force, k2.data(), N);
+        stage(k3, k2.data(), dt / 2.);
+        f(sim, force, k3.data(), N);
+        stage(k2, k3.data(), dt);
+        for (int i = 0; i < N; i++) { k3[i].ax += k2[i].ax; k3[i].ay += k2[i].ay; k3[i].az += k2[i].az; }
+        rebx_reset_accelerations(k2.data(), N);
+        f(sim, force, k2.data(), N);
+        const double dt6 = dt / 6.;
+        for (int i = 0; i < N; i++) {
+            ps[i].vx += dt6 * (ps[i].ax + k2[i].ax + 2. * k3[i].ax);
+            ps[i].vy += dt6 * (ps[i].ay + k2[i].ay + 2. * k3[i].ay);
+            ps[i].vz += dt6 * (ps[i].az + k2[i].az + 2. * k3[i].az);
+        }
+    } else if (integrator == REBXAMD_INTEGRATOR_IMPLICIT_MIDPOINT) {
+        std::vector<struct reb_particle> fin(ps, ps + N), avg(ps, ps + N), prev(N);
+        int n = 0;
+        for (n = 0; n < 10; n++) {
+            prev = fin;
+            f(sim, force, avg.data(), N);
+            stage(fin, avg.data(), dt);
+            double tot2 = 0., delta2 = 0.;
+            for (int i = 0; i < N; i++) {
+                const double dx = fin[i].vx - prev[i].vx, dy = fin[i].vy - prev[i].vy, dz = fin[i].vz - prev[i].vz;
+                delta2 += dx * dx + dy * dy + dz * dz;
+                tot2 += fin[i].vx * fin[i].vx + fin[i].vy * fin[i].vy + fin[i].vz * fin[i].vz;
+            }
+            if (delta2 / tot2 < DBL_EPSILON * DBL_EPSILON) break;
+            for (int i = 0; i < N; i++) {
+                avg[i].vx = 0.5 * (ps[i].vx + fin[i].vx); avg[i].vy = 0.5 * (ps[i].vy + fin[i].vy); avg[i].vz = 0.5 * (ps[i].vz + fin[i].vz);
+                avg[i].ax = 0.; avg[i].ay = 0.; avg[i].az = 0.;
+            }
+        }
+        if (n == 10) report_warnings(sim, WARN_IM_ITER);
+        for (int i = 0; i < N; i++) { ps[i].vx = fin[i].vx; ps[i].vy = fin[i].vy; ps[i].vz = fin[i].vz; }
+    }
+}
+
+}  // namespace
+
+extern "C" void rebx_integrate_force(struct reb_simulation* const sim, struct rebx_operator* const op, const double dt) {    // src/integrate_force.c:34-78
+    struct rebx_extras* rebx = (struct rebx_extras*)sim->extras;
+    if (!rebx) return;
+    struct rebx_force* force = (struct rebx_force*)rebx_get_param(rebx, op->ap, "force");
+    if (force == NULL) {
+        reb_error(sim, "REBOUNDx Error: Force parameter not set in rebx_integrate operator. See examples for how to add as a parameter.\n");
+        return;                         // the reference goes on and dereferences the NULL force
+    }
+    int integrator = REBXAMD_INTEGRATOR_EULER;
+    if (const int* ip = (const int*)rebx_get_param(rebx, op->ap, "integrator")) integrator = *ip;
+    rebx_reset_accelerations(sim->particles, sim->N);
+    const int N = sim->N - sim->N_var;
+    if (N <= 0) return;
+    if (integrator != REBXAMD_INTEGRATOR_EULER && integrator != REBXAMD_INTEGRATOR_RK2 && integrator != REBXAMD_INTEGRATOR_RK4 &&
+        integrator != REBXAMD_INTEGRATOR_IMPLICIT_MIDPOINT)
+        return;
+    const Builtin* bi = builtin_of(force);
+    if (!bi) {
+        if (force->update_accelerations) integrate_on_host(sim, force, integrator, dt, N);
+        return;
+    }
+    // built-in force: one round trip, every stage on the device
+    Bridge* b = bridge_of(rebx, true);
+    rebxamd_view v;
+    double t[3];
+    if (!stage_in(sim, rebx, b, sim->particles, N, v, t)) return;
+    std::vector<rebxamd_op> ops;
+    const Pending pf{force, bi};
+    if (!ops_of_force(sim, rebx, b, pf, ops)) return;
+    hipStream_t st = nullptr;
+    int iterations = 0;
+    const int rc = rebxamd_integrate_force(b->ctx, &v, ops.data(), (int)ops.size(), integrator, dt, b->mode, &iterations, st);
+    if (rc != REBXAMD_OK) {
+        char str[400];
+        snprintf(str, sizeof(str), "REBOUNDx (MI355X) Error: %s. Velocities were not updated.\n", rebxamd_last_error(b->ctx));
+        (void)hipStreamSynchronize(st);
+        reb_error(sim, str);
+        return;
+    }
+    bool ok = hipStreamSynchronize(st) == hipSuccess;
+    const double t3 = now_ms();
+    const size_t bytes = (size_t)N * sizeof(double);
+    static const int back[6] = {H_VX, H_VY, H_VZ, H_AX, H_AY, H_AZ};
+    for (int k = 0; k < 6 && ok; k++) ok = hipMemcpyAsync(b->h_dyn[back[k]], b->d_dyn[back[k]], bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
+    uint32_t bits = 0;
+    ok = ok && rebxamd_fetch_warnings(b->ctx, &bits, st) == REBXAMD_OK;
+    if (!ok) { rebx_error(rebx, "REBOUNDx (MI355X) Error: device to host copy failed.\n"); return; }
+    double* const* h = b->h_dyn;
+    struct reb_particle* const ps = sim->particles;
+    for (int i = 0; i < N; i++) {
+        ps[i].vx = h[H_VX][i]; ps[i].vy = h[H_VY][i]; ps[i].vz = h[H_VZ][i];
+        ps[i].ax = h[H_AX][i]; ps[i].ay = h[H_AY][i]; ps[i].az = h[H_AZ][i];
+    }
+    const double t4 = now_ms();
+    report_warnings(sim, bits);
+    b->timings[0] = t[1] - t[0]; b->timings[1] = t[2] - t[1]; b->timings[2] = t3 - t[2]; b->timings[3] = t4 - t3;
+}

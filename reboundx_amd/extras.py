@@ -14,6 +14,9 @@ from ctypes import (CFUNCTYPE, POINTER, Structure, byref, c_char_p, c_double, c_
 from ._lib import lib
 
 REBX_FORCE_TYPE = {"none": 0, "pos": 1, "vel": 2}
+REBX_OPERATOR_TYPE = {"none": 0, "updater": 1, "recorder": 2}
+REBX_TIMING = {"pre": -1, "post": 1}
+REBX_INTEGRATORS = {"implicit_midpoint": 0, "rk4": 1, "euler": 2, "rk2": 3, "none": -1}
 COORDINATES = {"JACOBI": 0, "BARYCENTRIC": 1, "PARTICLE": 2}
 INTEGRATORS = {"ias15": 0, "whfast": 1, "mercurius": 9}
 
@@ -160,6 +163,41 @@ Force._fields_ = [("name", c_char_p), ("ap", POINTER(Node)), ("_sim", POINTER(Si
 assert ctypes.sizeof(Force) == 40
 
 
+class Operator(Structure):
+    """struct rebx_operator (reference reboundx/extras.py:225-258)."""
+
+    @property
+    def operator_type(self):
+        return self._operator_type
+
+    @operator_type.setter
+    def operator_type(self, value):
+        self._operator_type = REBX_OPERATOR_TYPE[value.lower()]
+
+    @property
+    def step_function(self):
+        return self._step_function
+
+    @step_function.setter
+    def step_function(self, func):
+        self._sfp = STEPFUNCPTR(func)       # keep the callback object alive
+        self._step_function = self._sfp
+
+    def step(self, sim, dt):
+        self._step_function(byref(sim), byref(self), dt)
+        sim.process_messages()
+
+    @property
+    def params(self):
+        return Params(self)
+
+
+STEPFUNCPTR = CFUNCTYPE(None, POINTER(Simulation), POINTER(Operator), c_double)
+Operator._fields_ = [("name", c_char_p), ("ap", POINTER(Node)), ("_sim", POINTER(Simulation)),
+                     ("_operator_type", c_int), ("_step_function", STEPFUNCPTR)]
+assert ctypes.sizeof(Operator) == 40
+
+
 class Extras(Structure):
     """struct rebx_extras; allocated by Python, initialised by the library, like the reference wrapper."""
 
@@ -212,6 +250,37 @@ class Extras(Structure):
             raise TypeError("REBOUNDx Error: Object passed to rebx.remove_force is not a reboundx.Force instance.")
         if not lib.rebx_remove_force(byref(self), byref(force)):
             raise AttributeError("REBOUNDx Error: Force passed to rebx.remove_force not found in simulation.")
+
+    def load_operator(self, name):
+        ptr = lib.rebx_load_operator(byref(self), name.encode("ascii"))
+        self.process_messages()
+        return ptr.contents
+
+    def create_operator(self, name):
+        ptr = lib.rebx_create_operator(byref(self), name.encode("ascii"))
+        self.process_messages()
+        return ptr.contents
+
+    def add_operator(self, operator, dtfraction=None, timing="post"):
+        if not isinstance(operator, Operator):
+            raise TypeError("REBOUNDx Error: Object passed to rebx.add_operator is not a reboundx.Operator instance.")
+        if dtfraction is None:
+            lib.rebx_add_operator(byref(self), byref(operator))
+        else:
+            lib.rebx_add_operator_step(byref(self), byref(operator), c_double(dtfraction), c_int(REBX_TIMING[timing]))
+        self.process_messages()
+
+    def get_operator(self, name):
+        ptr = lib.rebx_get_operator(byref(self), name.encode("ascii"))
+        if ptr:
+            return ptr.contents
+        raise AttributeError("REBOUNDx Error: Operator {0} passed to rebx.get_operator not found.".format(name))
+
+    def remove_operator(self, operator):
+        if not isinstance(operator, Operator):
+            raise TypeError("REBOUNDx Error: Object passed to rebx.remove_operator is not a reboundx.Operator instance.")
+        if not lib.rebx_remove_operator(byref(self), byref(operator)):
+            raise AttributeError("REBOUNDx Error: Operator passed to rebx.remove_operator not found in simulation.")
 
     def rad_calc_beta(self, G, c, source_mass, source_luminosity, radius, density, Q_pr):
         return lib.rebx_rad_calc_beta(c_double(G), c_double(c), c_double(source_mass), c_double(source_luminosity),
@@ -361,7 +430,23 @@ for _n in ("rebx_gr", "rebx_gr_full", "rebx_gr_potential", "rebx_radiation_force
     getattr(lib, _n).argtypes = [_P(Simulation), _P(Force), _P(Particle), c_int]
     getattr(lib, _n).restype = None
 
+lib.rebx_create_operator.argtypes = [_P(Extras), c_char_p]
+lib.rebx_create_operator.restype = _P(Operator)
+lib.rebx_load_operator.argtypes = [_P(Extras), c_char_p]
+lib.rebx_load_operator.restype = _P(Operator)
+lib.rebx_get_operator.argtypes = [_P(Extras), c_char_p]
+lib.rebx_get_operator.restype = _P(Operator)
+lib.rebx_add_operator.argtypes = [_P(Extras), _P(Operator)]
+lib.rebx_add_operator.restype = c_int
+lib.rebx_add_operator_step.argtypes = [_P(Extras), _P(Operator), c_double, c_int]
+lib.rebx_add_operator_step.restype = c_int
+lib.rebx_remove_operator.argtypes = [_P(Extras), _P(Operator)]
+lib.rebx_remove_operator.restype = c_int
+
 PLUGIN_API_SYMBOLS = (
+    "rebx_create_operator", "rebx_load_operator", "rebx_add_operator", "rebx_add_operator_step", "rebx_remove_operator",
+    "rebx_get_operator", "rebx_pre_timestep_modifications", "rebx_post_timestep_modifications", "rebx_integrate_force",
+    "rebx_drift_step", "rebx_kick_step",
     "rebx_attach", "rebx_detach", "rebx_extras_cleanup", "rebx_free", "rebx_initialize", "rebx_register_default_params",
     "rebx_free_pointers", "rebx_free_particle_ap", "rebx_create_force", "rebx_load_force", "rebx_add_force", "rebx_remove_force",
     "rebx_get_force", "rebx_get_param", "rebx_get_param_struct", "rebx_set_param_pointer", "rebx_set_param_double",

@@ -286,3 +286,36 @@ def test_gr_and_jacobi_drag_with_massive_bodies_anywhere_through_the_hook():
     big = np.abs(want).max(axis=0)
     assert (np.abs(got - want) / big[None, :]).max() <= TOL
     sim.free_particle_params()
+
+
+@pytest.mark.parametrize("integrator", ["euler", "rk2", "rk4", "implicit_midpoint"])
+def test_integrate_force_operator_with_a_builtin_force_runs_on_the_device(integrator):
+    """The reference's IntegrateForce setup (ipython_examples/IntegrateForce.ipynb: a
+    velocity-dependent force applied as an operator): built-in force + integrate_force operator,
+    stepped once through the operator's step function.  Reference-order arithmetic: the explicit
+    schemes are bitwise equal to the checker's restatement."""
+    from reboundx_amd.extras import REBX_INTEGRATORS
+    n = 1500
+    cols, pp, _ = synthetic.disk(n, 2)
+    synthetic.add_newtonian(cols, n_head=3)          # whatever is in the accelerations must be cleared first
+    sim = sim_from(cols)
+    rebx = Extras(sim)
+    rebx.set_mode("exact")
+    force = rebx.load_force("modify_orbits_forces")
+    op = rebx.load_operator("integrate_force")
+    op.params["force"] = force
+    op.params["integrator"] = REBX_INTEGRATORS[integrator]
+    set_params(sim, {k: pp[k] for k in ("tau_a", "tau_e", "tau_inc")})
+    dt = 0.05
+    op.step(sim, dt)
+    ref = oracle.Sim(cols)
+    oracle.integrate_force(ref, integrator, dt, [("modify_orbits_forces", {})], pp)
+    got = np.array([[sim.particles[i].vx for i in range(n)], [sim.particles[i].vy for i in range(n)], [sim.particles[i].vz for i in range(n)]])
+    want = np.array([ref.cols[k] for k in ("vx", "vy", "vz")])
+    if integrator == "implicit_midpoint":
+        dv = np.abs(want - np.array([cols[k] for k in ("vx", "vy", "vz")])).max(axis=0)
+        assert (np.abs(got - want).max(axis=0) <= TOL * np.maximum(dv, 1e-3)).all()
+    else:
+        assert ulp_diff(got, want).max() == 0
+        assert ulp_diff(acc_of(sim.particles, n), np.array(ref.acc)).max() == 0
+    sim.free_particle_params()

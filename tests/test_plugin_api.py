@@ -187,3 +187,99 @@ def test_rad_calc_beta_matches_reference_notebook():
     sim = make_sim()
     rebx = Extras(sim)
     assert rebx.rad_calc_beta(6.674e-11, 3.e8, 1.99e30, 3.85e26, 1.e-5, 1000., 1.) == pytest.approx(0.05767021830984005, rel=1e-15)
+
+
+# ------------------------------------------------------------------ operators (host side)
+
+def test_operator_factory_and_step_lists():
+    """rebx_load_operator / rebx_add_operator follow src/core.c:316-368, :462-506: with WHFast a
+    half step before and a half step after the timestep; with IAS15 one whole step after."""
+    from reboundx_amd.extras import Operator
+    sim = Simulation(integrator="whfast")
+    sim.add(m=1.)
+    sim.add(m=1e-3, x=1., vy=1.)
+    sim.dt = 0.5
+    rebx = Extras(sim)
+    with pytest.raises(RuntimeError, match="Operator 'modify_mass' not found"):
+        rebx.load_operator("modify_mass")
+    assert lib.rebx_len(rebx._allocated_operators) == 0
+    drift = rebx.load_operator("drift")
+    assert isinstance(drift, Operator) and drift.name == b"drift" and drift.operator_type == 1
+    rebx.add_operator(drift)
+    assert lib.rebx_len(rebx._pre_timestep_modifications) == 1 and lib.rebx_len(rebx._post_timestep_modifications) == 1
+    assert sim.pre_timestep_modifications and sim.post_timestep_modifications
+    sim.pre_timestep_modifications(ctypes.byref(sim))            # what REBOUND does before a step
+    assert sim.particles[1].y == pytest.approx(0.25)             # dt/2 * vy
+    sim.post_timestep_modifications(ctypes.byref(sim))
+    assert sim.particles[1].y == pytest.approx(0.5)
+    assert rebx.get_operator("drift").name == b"drift"
+    rebx.remove_operator(drift)
+    assert lib.rebx_len(rebx._pre_timestep_modifications) == 0 and lib.rebx_len(rebx._post_timestep_modifications) == 0
+    with pytest.raises(AttributeError):
+        rebx.get_operator("drift")
+
+    sim2 = Simulation(integrator="ias15")
+    sim2.add(m=1.)
+    rebx2 = Extras(sim2)
+    kick = rebx2.load_operator("kick")
+    rebx2.add_operator(kick)
+    assert lib.rebx_len(rebx2._pre_timestep_modifications) == 0 and lib.rebx_len(rebx2._post_timestep_modifications) == 1
+    rebx2.add_operator(kick, dtfraction=0.25, timing="pre")
+    assert lib.rebx_len(rebx2._pre_timestep_modifications) == 1
+
+
+def test_custom_operator_needs_type_and_step_function():
+    sim = make_sim()
+    rebx = Extras(sim)
+    op = rebx.create_operator("mine")
+    with pytest.raises(RuntimeError, match="step_function"):
+        rebx.add_operator(op, dtfraction=1.)
+    calls = []
+    op.step_function = lambda s, o, dt: calls.append(dt)
+    with pytest.raises(RuntimeError, match="operator_type"):
+        rebx.add_operator(op, dtfraction=1.)
+    op.operator_type = "recorder"
+    rebx.add_operator(op)                                        # recorders: one whole step after
+    sim.dt = 0.1
+    sim.post_timestep_modifications(ctypes.byref(sim))
+    assert calls == [pytest.approx(0.1)]
+
+
+@pytest.mark.parametrize("integrator", ["euler", "rk2", "rk4", "implicit_midpoint"])
+def test_integrate_force_with_a_user_callback_runs_the_schemes_on_the_host(integrator):
+    """A linear drag a = -k v has the exact solution v(t) = v0 exp(-k t); each scheme must
+    reproduce its own stability polynomial R(-k dt) (no GPU involved: the force is a Python
+    callback, so the stages run on the host arrays)."""
+    import math
+    from reboundx_amd.extras import REBX_INTEGRATORS
+    sim = make_sim()
+    rebx = Extras(sim)
+    k, dt = 0.7, (0.02 if integrator == "implicit_midpoint" else 0.3)   # the fixed-point iteration needs k*dt/2 << 1
+
+    def drag(simp, forcep, particles, n):
+        for i in range(n):
+            particles[i].ax -= k * particles[i].vx
+            particles[i].ay -= k * particles[i].vy
+            particles[i].az -= k * particles[i].vz
+
+    force = rebx.create_force("drag")
+    force.force_type = "vel"
+    force.update_accelerations = drag
+    op = rebx.load_operator("integrate_force")
+    op.params["force"] = force
+    op.params["integrator"] = REBX_INTEGRATORS[integrator]
+    sim.particles[1].ax = 123.0                                   # must be cleared first (integrate_force.c:46)
+    op.step(sim, dt)
+    z = -k * dt
+    growth = {"euler": 1 + z, "rk2": 1 + z + z * z / 2, "rk4": 1 + z + z * z / 2 + z ** 3 / 6 + z ** 4 / 24,
+              "implicit_midpoint": (1 + z / 2) / (1 - z / 2)}[integrator]
+    assert sim.particles[1].vy == pytest.approx(growth, rel=1e-14)
+    assert abs(growth - math.exp(z)) < 0.03
+
+
+def test_integrate_force_without_force_parameter_is_an_error():
+    sim = make_sim()
+    rebx = Extras(sim)
+    op = rebx.load_operator("integrate_force")
+    with pytest.raises(RuntimeError, match="Force parameter not set"):
+        op.step(sim, 0.1)
