@@ -154,6 +154,14 @@ void rebx_error(struct rebx_extras* rebx, const char* const msg);
  * callbacks on the host in between. */
 void rebx_additional_forces(struct reb_simulation* sim);
 
+/* Potentials of the position-dependent forces, evaluated on the device from sim->particles
+ * (src/reboundx.h:483-504; gravitational_harmonics.c:221-231, central_force.c:122-141,
+ * tides_precession.c:182-202, gr_potential.c:122-132). */
+double rebx_gravitational_harmonics_potential(struct rebx_extras* const rebx);
+double rebx_central_force_potential(struct rebx_extras* const rebx);
+double rebx_tides_precession_potential(struct rebx_extras* const rebx);
+double rebx_gr_potential_potential(struct rebx_extras* const rebx, const struct rebx_force* const gr_potential);
+
 /* Operators on the additional-force path: the "integrate a force across a timestep" operator and
  * the kick/drift steppers.  src/reboundx.h:331, :329, :327, :280; src/core.c:279-368, :411-510,
  * :637-648, :697-728.  rebx_load_operator knows "integrate_force", "kick" and "drift"; the
@@ -308,6 +316,14 @@ int rebxamd_add_pushes(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd
 
 /* src/core.c:860-866 on device columns. */
 int rebxamd_reset_accelerations(rebxamd_ctx* ctx, const rebxamd_view* view, void* stream);
+
+/* Potential energy of each op in `ops` (J2, J4, central_force, tides_precession, gr_potential),
+ * summed over the particles of `view`: out[k] (host memory, nops doubles) is what the
+ * reference's per-source potential routine returns for op k
+ * (src/gravitational_harmonics.c:142-193, central_force.c:97-120, tides_precession.c:132-180,
+ * gr_potential.c:100-120).  For tides_precession the caller picks the source as the reference's
+ * potential does (the last particle flagged "primary", else 0).  Synchronises the stream. */
+int rebxamd_potentials(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, double* out, void* stream);
 
 /* Values of enum rebx_integrator, src/reboundx.h:157-163. */
 enum rebxamd_integrator {

@@ -515,6 +515,43 @@ extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* vie
     return REBXAMD_OK;
 }
 
+// ------------------------------------------------------------------ potentials
+
+extern "C" int rebxamd_potentials(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, double* out, void* stream) {
+    if (!ctx) return REBXAMD_ERR_ARG;
+    if (!view || view->n < 0 || nops < 0 || nops > REBXAMD_MAX_OPS || (nops > 0 && (!ops || !out)))
+        return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_potentials: bad argument");
+    for (int k = 0; k < nops; k++) out[k] = 0.;
+    if (nops == 0 || view->n == 0) return REBXAMD_OK;
+    const View v = make_view(view);
+    if (!v.x || !v.y || !v.z || !v.m) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_potentials: position/mass columns missing");
+    Program prog;
+    memset(&prog, 0, sizeof(prog));
+    prog.nops = nops;
+    prog.G = view->G;
+    for (int k = 0; k < nops; k++) {
+        const rebxamd_op& o = ops[k];
+        DevOp& d = prog.ops[k];
+        d.kind = o.kind; d.src = o.src; d.iarg = o.iarg; d.slot = -1; d.a = o.a; d.b = o.b; d.c = 0.; d.d = 0.;
+        switch (o.kind) {
+        case REBXAMD_OP_J2: case REBXAMD_OP_J4: case REBXAMD_OP_CENTRAL: case REBXAMD_OP_TIDES: break;
+        case REBXAMD_OP_GR_POTENTIAL: d.src = 0; d.c = o.a * o.a; break;
+        default: return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_potentials: this op has no potential (J2, J4, central_force, tides_precession, gr_potential do)");
+        }
+        if (d.src < 0 || d.src >= v.n) return fail(ctx, REBXAMD_ERR_ARG, "op source index out of range");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const long long nb = potential_block_count(v.n);
+    const int rc = ensure(ctx, &ctx->partials, &ctx->partials_cap, ((size_t)nops * (size_t)nb + (size_t)nops) * sizeof(double), st);
+    if (rc != REBXAMD_OK) return rc;
+    double* dout = ctx->partials + (size_t)nops * (size_t)nb;
+    HIP_TRY(launch_potentials(v, prog, ctx->partials, dout, st));
+    HIP_TRY(hipMemcpyAsync(out, dout, (size_t)nops * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return REBXAMD_OK;
+}
+
 // ------------------------------------------------------------------ gr_full
 
 static int grfull_check(rebxamd_ctx* ctx, const rebxamd_view* u, int64_t row0, int64_t row1) {

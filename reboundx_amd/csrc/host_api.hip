@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <cfloat>
 #include <chrono>
 #include <mutex>
@@ -1131,4 +1132,63 @@ extern "C" void rebx_integrate_force(struct reb_simulation* const sim, struct re
     const double t4 = now_ms();
     report_warnings(sim, bits);
     b->timings[0] = t[1] - t[0]; b->timings[1] = t[2] - t[1]; b->timings[2] = t3 - t[2]; b->timings[3] = t4 - t3;
+}
+
+// ------------------------------------------------------------------ potentials
+namespace {
+enum PotentialKind { POT_HARMONICS, POT_CENTRAL, POT_TIDES, POT_GR };
+
+double host_potential(struct rebx_extras* rebx, PotentialKind kind, double c) {
+    if (rebx->sim == NULL) { rebx_error(rebx, ""); return 0; }
+    struct reb_simulation* sim = rebx->sim;
+    const int N = sim->N - sim->N_var;
+    if (N <= 0) return 0.;
+    Bridge* b = bridge_of(rebx, true);
+    rebxamd_view v;
+    double t[3];
+    if (!stage_in(sim, rebx, b, sim->particles, N, v, t)) return 0.;
+    std::vector<rebxamd_op> ops;
+    auto add = [&](int k, int src, double a, double bb) {
+        rebxamd_op o; o.kind = k; o.src = src; o.iarg = 0; o.reserved = 0; o.a = a; o.b = bb; ops.push_back(o);
+    };
+    if (kind == POT_HARMONICS) {
+        for (const SourceJ& s : b->j2) add(REBXAMD_OP_J2, s.idx, s.J, s.Req);
+        for (const SourceJ& s : b->j4) add(REBXAMD_OP_J4, s.idx, s.J, s.Req);
+    } else if (kind == POT_CENTRAL) {
+        for (const SourceC& s : b->central) add(REBXAMD_OP_CENTRAL, s.idx, s.A, s.gamma);
+    } else if (kind == POT_TIDES) {
+        // tides_precession.c:190-199: the LAST particle carrying "primary" wins (H is overwritten), else index 0
+        int src = 0;
+        for (int i = 0; i < N; i++)
+            if (rebx_get_param(rebx, (struct rebx_node*)sim->particles[i].ap, "primary") != NULL) src = i;
+        add(REBXAMD_OP_TIDES, src, 0., 0.);
+    } else {
+        add(REBXAMD_OP_GR_POTENTIAL, 0, c, 0.);
+    }
+    double H = 0.;
+    for (size_t lo = 0; lo < ops.size(); lo += REBXAMD_MAX_OPS) {
+        const int cnt = (int)std::min<size_t>(REBXAMD_MAX_OPS, ops.size() - lo);
+        double out[REBXAMD_MAX_OPS];
+        if (rebxamd_potentials(b->ctx, &v, ops.data() + lo, cnt, out, nullptr) != REBXAMD_OK) {
+            char str[400];
+            snprintf(str, sizeof(str), "REBOUNDx (MI355X) Error: %s.\n", rebxamd_last_error(b->ctx));
+            reb_error(sim, str);
+            return 0.;
+        }
+        for (int k = 0; k < cnt; k++) H += out[k];
+    }
+    return H;
+}
+}  // namespace
+
+extern "C" double rebx_gravitational_harmonics_potential(struct rebx_extras* const rebx) { return host_potential(rebx, POT_HARMONICS, 0.); }
+extern "C" double rebx_central_force_potential(struct rebx_extras* const rebx) { return host_potential(rebx, POT_CENTRAL, 0.); }
+extern "C" double rebx_tides_precession_potential(struct rebx_extras* const rebx) { return host_potential(rebx, POT_TIDES, 0.); }
+extern "C" double rebx_gr_potential_potential(struct rebx_extras* const rebx, const struct rebx_force* const gr_potential) {
+    const double* c = (const double*)rebx_get_param(rebx, gr_potential->ap, "c");
+    if (c == NULL) {
+        rebx_error(rebx, "Need to set speed of light in gr effect.  See examples in documentation.\n");
+        return 0;                       // the reference goes on and dereferences NULL
+    }
+    return host_potential(rebx, POT_GR, *c);
 }

@@ -88,6 +88,10 @@ long long im_partial_count(long long n);
 hipError_t launch_im_update(double* const fin[3], const double* const orig[3], double* const avgv[3], double* const avga[3], double dt,
                             long long n, double* partials, double* sums, bool exact, hipStream_t st);
 
+// potential energies of the position-dependent forces (potential_kernels.hip)
+long long potential_block_count(long long n);
+hipError_t launch_potentials(const View& v, const Program& prog, double* partials, double* out, hipStream_t st);
+
 // gr_full launchers implemented in grfull_kernels.hip
 // pass: 0 = potential sums, 1 = acceleration-independent part, 2 = one substitution sweep
 size_t grfull_partial_bytes(long long n, long long nrows);

@@ -1,0 +1,113 @@
+// potential_kernels.hip -- potential energies of the position-dependent forces, the diagnostics
+// the reference's conservation tests are built on (reboundx/test/test_conservation.py:38-96):
+//   gravitational_harmonics.c:142-231, central_force.c:97-141, tides_precession.c:132-202,
+//   gr_potential.c:100-132.
+// One pass over the particles: every thread forms its particle's term for each op in the
+// reference's expression order (no FMA contraction), workgroups reduce per op, and a second
+// kernel adds the workgroup sums in a fixed order.  The reference adds the terms sequentially;
+// the results agree to rounding of a sum of that many terms.
+#include "internal.h"
+#include <float.h>
+
+namespace rebxamd {
+
+static constexpr int PB = 256;
+
+__device__ __forceinline__ double potential_term(const DevOp& op, const View& v, long long i, double G) {
+#pragma clang fp contract(off)
+    const int s = op.src;
+    if (i == s) return 0.;
+    if (op.kind == REBXAMD_OP_GR_POTENTIAL && i < 1) return 0.;
+    const double dx = v.x[i] - v.x[s], dy = v.y[i] - v.y[s], dz = v.z[i] - v.z[s];
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    const double mi = v.m[i], ms = v.m[s];
+    switch (op.kind) {
+    case REBXAMD_OP_J2: {
+        const double r = sqrt(r2);
+        const double costheta2 = dz * dz / r2;
+        const double prefac = G * mi * ms * op.b * op.b / r2 / r * op.a;
+        const double P2 = 0.5 * (3. * costheta2 - 1.);
+        return prefac * P2;
+    }
+    case REBXAMD_OP_J4: {
+        const double r = sqrt(r2);
+        const double costheta2 = dz * dz / r2;
+        const double prefac = G * mi * ms * op.b * op.b * op.b * op.b / r2 / r2 / r * op.a;
+        const double P4 = (35. * costheta2 * costheta2 - 30. * costheta2 + 3.) / 8.;
+        return prefac * P4;
+    }
+    case REBXAMD_OP_CENTRAL: {
+        const double A = op.a, gamma = op.b;
+        if (fabs(gamma + 1.) < DBL_EPSILON) return -(mi * A * log(sqrt(r2)));
+        return -(mi * A * pow(r2, (gamma + 1.) / 2.) / (gamma + 1.));
+    }
+    case REBXAMD_OP_TIDES: {
+        const double mratio = mi / ms;
+        if (mratio < DBL_MIN) return 0.;
+        const double R0 = (v.Rt && v.Rt[s] == v.Rt[s]) ? v.Rt[s] : 0.;
+        const double k10 = (v.k1 && v.k1[s] == v.k1[s]) ? v.k1[s] : 0.;
+        const double fac0 = k10 * R0 * R0 * R0 * R0 * R0;
+        double fac = 0.;
+        fac += fac0 * mratio;
+        const double Rp = (v.Rt && v.Rt[i] == v.Rt[i]) ? v.Rt[i] : 0.;
+        const double k1p = (v.k1 && v.k1[i] == v.k1[i]) ? v.k1[i] : 0.;
+        fac += k1p * Rp * Rp * Rp * Rp * Rp / mratio;
+        return -3. / 6. * G * (ms + mi) * mi / (r2 * r2 * r2) * fac;
+    }
+    case REBXAMD_OP_GR_POTENTIAL: {
+        const double mu = G * ms;
+        const double prefac = 3. * mu * mu / op.c;      // op.c = c^2
+        return -(prefac * mi / r2);
+    }
+    default:
+        return 0.;
+    }
+}
+
+__global__ __launch_bounds__(PB) void potential_kernel(View v, Program prog, double* partials) {
+    __shared__ double red[PB / 64];
+    const long long i = (long long)blockIdx.x * PB + threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k = 0; k < prog.nops; k++) {
+        double t = i < v.n ? potential_term(prog.ops[k], v, i, prog.G) : 0.;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+        __syncthreads();
+        if (lane == 0) red[wave] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = 0.;
+            for (int w = 0; w < PB / 64; w++) s += red[w];
+            partials[(long long)k * gridDim.x + blockIdx.x] = s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void potential_sum_kernel(const double* partials, long long nb, double* out) {
+    __shared__ double red[16];
+    const double* p = partials + (long long)blockIdx.x * nb;
+    double a = 0.;
+    for (long long k = threadIdx.x; k < nb; k += 1024) a += p[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.;
+        for (int w = 0; w < 16; w++) s += red[w];
+        out[blockIdx.x] = s;
+    }
+}
+
+long long potential_block_count(long long n) { return (n + PB - 1) / PB; }
+
+// partials: nops * potential_block_count(n) doubles; out: nops doubles (device)
+hipError_t launch_potentials(const View& v, const Program& prog, double* partials, double* out, hipStream_t st) {
+    if (prog.nops <= 0) return hipSuccess;
+    const long long nb = potential_block_count(v.n);
+    if (nb > 0) hipLaunchKernelGGL(potential_kernel, dim3((unsigned)nb), dim3(PB), 0, st, v, prog, partials);
+    hipLaunchKernelGGL(potential_sum_kernel, dim3((unsigned)prog.nops), dim3(1024), 0, st, partials, nb, out);
+    return hipGetLastError();
+}
+
+}  // namespace rebxamd

@@ -71,6 +71,13 @@ class Context:
         arr = (Op * len(ops))(*ops)
         self._check(lib.rebxamd_add_pushes(self._h, ctypes.byref(view), arr, len(ops), sums.data_ptr(), self._stream()))
 
+    def potentials(self, view, ops):
+        """Potential energy of each op (J2, J4, central_force, tides_precession, gr_potential)."""
+        arr = (Op * max(len(ops), 1))(*ops)
+        out = (ctypes.c_double * max(len(ops), 1))()
+        self._check(lib.rebxamd_potentials(self._h, ctypes.byref(view), arr, len(ops), out, self._stream()))
+        return [out[k] for k in range(len(ops))]
+
     def integrate_force(self, view, ops, integrator, dt, mode=_lib.MODE_FAST):
         """rebx_integrate_force on device columns: velocities of `view` are updated in place.
         `integrator`: one of "euler", "rk2", "rk4", "implicit_midpoint", "none" (or the enum

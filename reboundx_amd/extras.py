@@ -282,6 +282,22 @@ class Extras(Structure):
         if not lib.rebx_remove_operator(byref(self), byref(operator)):
             raise AttributeError("REBOUNDx Error: Operator passed to rebx.remove_operator not found in simulation.")
 
+    def gravitational_harmonics_potential(self):
+        return self._potential(lib.rebx_gravitational_harmonics_potential(byref(self)))
+
+    def central_force_potential(self):
+        return self._potential(lib.rebx_central_force_potential(byref(self)))
+
+    def tides_precession_potential(self):
+        return self._potential(lib.rebx_tides_precession_potential(byref(self)))
+
+    def gr_potential_potential(self, force):
+        return self._potential(lib.rebx_gr_potential_potential(byref(self), byref(force)))
+
+    def _potential(self, value):
+        self.process_messages()
+        return value
+
     def rad_calc_beta(self, G, c, source_mass, source_luminosity, radius, density, Q_pr):
         return lib.rebx_rad_calc_beta(c_double(G), c_double(c), c_double(source_mass), c_double(source_luminosity),
                                       c_double(radius), c_double(density), c_double(Q_pr))
@@ -430,6 +446,11 @@ for _n in ("rebx_gr", "rebx_gr_full", "rebx_gr_potential", "rebx_radiation_force
     getattr(lib, _n).argtypes = [_P(Simulation), _P(Force), _P(Particle), c_int]
     getattr(lib, _n).restype = None
 
+for _n in ("rebx_gravitational_harmonics_potential", "rebx_central_force_potential", "rebx_tides_precession_potential"):
+    getattr(lib, _n).argtypes = [_P(Extras)]
+    getattr(lib, _n).restype = c_double
+lib.rebx_gr_potential_potential.argtypes = [_P(Extras), _P(Force)]
+lib.rebx_gr_potential_potential.restype = c_double
 lib.rebx_create_operator.argtypes = [_P(Extras), c_char_p]
 lib.rebx_create_operator.restype = _P(Operator)
 lib.rebx_load_operator.argtypes = [_P(Extras), c_char_p]
@@ -446,7 +467,8 @@ lib.rebx_remove_operator.restype = c_int
 PLUGIN_API_SYMBOLS = (
     "rebx_create_operator", "rebx_load_operator", "rebx_add_operator", "rebx_add_operator_step", "rebx_remove_operator",
     "rebx_get_operator", "rebx_pre_timestep_modifications", "rebx_post_timestep_modifications", "rebx_integrate_force",
-    "rebx_drift_step", "rebx_kick_step",
+    "rebx_drift_step", "rebx_kick_step", "rebx_gravitational_harmonics_potential", "rebx_central_force_potential",
+    "rebx_tides_precession_potential", "rebx_gr_potential_potential",
     "rebx_attach", "rebx_detach", "rebx_extras_cleanup", "rebx_free", "rebx_initialize", "rebx_register_default_params",
     "rebx_free_pointers", "rebx_free_particle_ap", "rebx_create_force", "rebx_load_force", "rebx_add_force", "rebx_remove_force",
     "rebx_get_force", "rebx_get_param", "rebx_get_param_struct", "rebx_set_param_pointer", "rebx_set_param_double",
