@@ -161,6 +161,8 @@ double rebx_gravitational_harmonics_potential(struct rebx_extras* const rebx);
 double rebx_central_force_potential(struct rebx_extras* const rebx);
 double rebx_tides_precession_potential(struct rebx_extras* const rebx);
 double rebx_gr_potential_potential(struct rebx_extras* const rebx, const struct rebx_force* const gr_potential);
+/* src/reboundx.h:467, src/gr.c:248-260 */
+double rebx_gr_hamiltonian(struct rebx_extras* const rebx, const struct rebx_force* const gr);
 
 /* Operators on the additional-force path: the "integrate a force across a timestep" operator and
  * the kick/drift steppers.  src/reboundx.h:331, :329, :327, :280; src/core.c:279-368, :411-510,
@@ -324,6 +326,11 @@ int rebxamd_reset_accelerations(rebxamd_ctx* ctx, const rebxamd_view* view, void
  * gr_potential.c:100-120).  For tides_precession the caller picks the source as the reference's
  * potential does (the last particle flagged "primary", else 0).  Synchronises the stream. */
 int rebxamd_potentials(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, double* out, void* stream);
+
+/* The Hamiltonian the gr force derives from, Newtonian part included (src/gr.c:190-246):
+ * kinetic + Newtonian pair potential + post-Newtonian term in Jacobi coordinates.  *H in host
+ * memory; synchronises the stream.  O(N * massive) for the pair potential. */
+int rebxamd_gr_hamiltonian(rebxamd_ctx* ctx, const rebxamd_view* view, double c, double* H, void* stream);
 
 /* Values of enum rebx_integrator, src/reboundx.h:157-163. */
 enum rebxamd_integrator {

@@ -1192,3 +1192,24 @@ extern "C" double rebx_gr_potential_potential(struct rebx_extras* const rebx, co
     }
     return host_potential(rebx, POT_GR, *c);
 }
+
+extern "C" double rebx_gr_hamiltonian(struct rebx_extras* const rebx, const struct rebx_force* const gr) {        // src/gr.c:248-260
+    const double* c = (const double*)rebx_get_param(rebx, gr->ap, "c");
+    if (c == NULL) { rebx_error(rebx, "Need to set speed of light in gr effect.  See examples in documentation.\n"); return 0; }
+    if (rebx->sim == NULL) { rebx_error(rebx, ""); return 0; }
+    struct reb_simulation* sim = rebx->sim;
+    const int N = sim->N - sim->N_var;
+    if (N <= 0) return 0.;
+    Bridge* b = bridge_of(rebx, true);
+    rebxamd_view v;
+    double t[3];
+    if (!stage_in(sim, rebx, b, sim->particles, N, v, t)) return 0.;
+    double H = 0.;
+    if (rebxamd_gr_hamiltonian(b->ctx, &v, *c, &H, nullptr) != REBXAMD_OK) {
+        char str[400];
+        snprintf(str, sizeof(str), "REBOUNDx (MI355X) Error: %s.\n", rebxamd_last_error(b->ctx));
+        reb_error(sim, str);
+        return 0.;
+    }
+    return H;
+}

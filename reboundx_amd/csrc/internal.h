@@ -77,6 +77,7 @@ int stream_block_count(long long lo, long long n, bool vec2);
 
 // gr and Jacobi/barycentric modify_orbits_forces for arbitrary mass layouts (scan_kernels.hip)
 size_t scan_workspace_doubles(long long n);
+hipError_t launch_gr_hamiltonian(const View& v, double G, double c, double* ws, double* out, hipStream_t st);
 hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, double* ws, unsigned* status, hipStream_t st);
 
 // velocity/position updates of the force integrators and steppers (step_kernels.hip)

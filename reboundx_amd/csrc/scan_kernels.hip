@@ -76,7 +76,7 @@ __device__ __forceinline__ void weighted_state(const View& v, const double* nax,
     q[0] = m;
     q[1] = m * v.x[i]; q[2] = m * v.y[i]; q[3] = m * v.z[i];
     q[4] = m * v.vx[i]; q[5] = m * v.vy[i]; q[6] = m * v.vz[i];
-    if (C == 10) { q[7] = m * nax[i]; q[8] = m * nay[i]; q[9] = m * naz[i]; }
+    if constexpr (C == 10) { q[7] = m * nax[i]; q[8] = m * nay[i]; q[9] = m * naz[i]; }
 }
 
 // pass 1: workgroup totals of the weighted state
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, cons
         p.x = v.x[i]; p.y = v.y[i]; p.z = v.z[i]; p.vx = v.vx[i]; p.vy = v.vy[i]; p.vz = v.vz[i]; p.m = mi;
         p.beta = p.Rt = p.k1 = __builtin_nan("");
         p.ta = v.ta ? v.ta[i] : __builtin_nan(""); p.te = v.te ? v.te[i] : __builtin_nan(""); p.ti = v.ti ? v.ti[i] : __builtin_nan("");
-        if (KIND == SCAN_GR) {
+        if constexpr (KIND == SCAN_GR) {
             if (i >= 1) {
                 const double ei = 1. / eta;
                 Jac j;
@@ -278,6 +278,91 @@ __global__ __launch_bounds__(SB) void newton_from_compact(View v, const double* 
     if (live) { nax[i] = ax; nay[i] = ay; naz[i] = az; }
 }
 
+// ---- gr Hamiltonian (reference src/gr.c:190-246): Newtonian pair potential over the massive
+// bodies, Jacobi masses (src/rebxtools.c:27-35), kinetic and post-Newtonian terms per body.
+__global__ __launch_bounds__(SB) void newton_pot_from_compact(View v, const double* cx, const double* cy, const double* cz, const double* cgm,
+                                                              const long long* cidx, const double* count, double* pot) {
+    __shared__ double tx[SB], ty[SB], tz[SB], tg[SB];
+    __shared__ long long ti[SB];
+    const long long i = (long long)blockIdx.x * SB + threadIdx.x;
+    const bool live = i < v.n;
+    const long long M = (long long)count[0];
+    double xi = 0., yi = 0., zi = 0.;
+    if (live) { xi = v.x[i]; yi = v.y[i]; zi = v.z[i]; }
+    double phi = 0.;
+    for (long long j0 = 0; j0 < M; j0 += SB) {
+        const long long j = j0 + threadIdx.x;
+        __syncthreads();
+        if (j < M) { tx[threadIdx.x] = cx[j]; ty[threadIdx.x] = cy[j]; tz[threadIdx.x] = cz[j]; tg[threadIdx.x] = cgm[j]; ti[threadIdx.x] = cidx[j]; }
+        __syncthreads();
+        const int cnt = (int)((M - j0) < SB ? (M - j0) : SB);
+        for (int k = 0; k < cnt; k++) {
+            if (ti[k] == i) continue;
+            {
+#pragma clang fp contract(off)
+                const double dx = xi - tx[k], dy = yi - ty[k], dz = zi - tz[k];
+                phi += tg[k] / sqrt(dx * dx + dy * dy + dz * dz);
+            }
+        }
+    }
+    if (live) pot[i] = phi;
+}
+
+// per-workgroup sums of (kinetic, Newtonian potential, post-Newtonian potential * c^2)
+__global__ __launch_bounds__(SB) void gr_hamiltonian_main(View v, double G, double C2, const double* pot, const double* blocksums,
+                                                         const double* totals, double* partials) {
+    __shared__ double lds[SW][7];
+    __shared__ double lds3[SW][3];
+    const long long i = (long long)blockIdx.x * SB + threadIdx.x;
+    const bool live = i < v.n;
+    double q[7], own[7], tot[7];
+#pragma unroll
+    for (int c = 0; c < 7; c++) q[c] = 0.;
+    if (live) weighted_state<7>(v, nullptr, nullptr, nullptr, i, q);
+#pragma unroll
+    for (int c = 0; c < 7; c++) own[c] = q[c];
+    block_scan<7, false>(q, tot, lds);
+    double e[3] = {0., 0., 0.}, et[3];
+    if (live) {
+#pragma clang fp contract(off)
+        const double mi = own[0];
+        e[1] = -0.5 * mi * pot[i];                     // each pair is seen from both ends
+        if (i == 0) {
+            // Jacobi "body" 0 is the centre of mass carrying the total mass (gr.c:219)
+            const double M = totals[0], iM = 1. / M;
+            const double vx = totals[4] * iM, vy = totals[5] * iM, vz = totals[6] * iM;
+            e[0] = 0.5 * M * (vx * vx + vy * vy + vz * vz);
+        } else {
+            double S[7];
+#pragma unroll
+            for (int c = 0; c < 7; c++) S[c] = blocksums[(long long)blockIdx.x * 7 + c] + (q[c] - own[c]);
+            const double eta = S[0], ei = 1. / eta;
+            const double mj = mi * eta / (eta + mi);
+            const double x = v.x[i] - S[1] * ei, y = v.y[i] - S[2] * ei, z = v.z[i] - S[3] * ei;
+            const double vx = v.vx[i] - S[4] * ei, vy = v.vy[i] - S[5] * ei, vz = v.vz[i] - S[6] * ei;
+            const double mu = G * v.m[0];
+            const double rdoti2 = vx * vx + vy * vy + vz * vz;
+            double vt2 = rdoti2;
+            const double ri = sqrt(x * x + y * y + z * z);
+            const double vscale2 = mu / ri;
+            for (int it = 0; it < 10; it++) {
+                const double old = vt2;
+                const double A = (0.5 * vt2 + 3. * vscale2) / C2;
+                vt2 = rdoti2 / ((1. - A) * (1. - A));
+                if ((vt2 - old) / vt2 < 2.220446049250313e-16) break;
+            }
+            e[2] = mj * (0.5 * mu * mu / (ri * ri) - 0.125 * vt2 * vt2 - 1.5 * mu * vt2 / ri);
+            e[0] = 0.5 * mj * vt2;
+        }
+    }
+    block_scan<3, false>(e, et, lds3);
+    if (threadIdx.x == 0) {
+        partials[3 * (long long)blockIdx.x + 0] = et[0];
+        partials[3 * (long long)blockIdx.x + 1] = et[1];
+        partials[3 * (long long)blockIdx.x + 2] = et[2];
+    }
+}
+
 // ------------------------------------------------------------------ host driver
 size_t scan_workspace_doubles(long long n) {
     const long long nb = (n + SB - 1) / SB;
@@ -322,6 +407,35 @@ hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, 
     hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(1), dim3(1024), 0, st, wsum, nb, wtot);
     if (kind == SCAN_MOF_BARY) hipLaunchKernelGGL(scan_apply<true>, g, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, wsum, wtot);
     else hipLaunchKernelGGL(scan_apply<false>, g, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, wsum, wtot);
+    return hipGetLastError();
+}
+
+}  // namespace rebxamd
+
+namespace rebxamd {
+
+// out (device, 3 doubles): kinetic, Newtonian potential, post-Newtonian potential times c^2
+hipError_t launch_gr_hamiltonian(const View& v, double G, double c, double* ws, double* out, hipStream_t st) {
+    const long long n = v.n;
+    if (n <= 0) return hipSuccess;
+    const long long nb = (n + SB - 1) / SB;
+    double* pot = ws;
+    double* cx = ws + 9 * n; double* cy = cx + n; double* cz = cy + n; double* cgm = cz + n;
+    long long* cidx = reinterpret_cast<long long*>(cgm + n);
+    double* bs = reinterpret_cast<double*>(cidx + n);
+    double* part = bs + 10 * nb;                            // nb * 3
+    double* fl = part + 3 * nb;
+    double* totals = fl + nb;
+    double* count = totals + 16 + 3;
+    const dim3 g((unsigned)nb), b(SB);
+    hipLaunchKernelGGL(massive_flag_totals, g, b, 0, st, v, fl);
+    hipLaunchKernelGGL((scan_of_totals<1, false>), dim3(1), dim3(1024), 0, st, fl, nb, count);
+    hipLaunchKernelGGL(massive_compact, g, b, 0, st, v, fl, cx, cy, cz, cgm, cidx, G);
+    hipLaunchKernelGGL(newton_pot_from_compact, g, b, 0, st, v, cx, cy, cz, cgm, cidx, count, pot);
+    hipLaunchKernelGGL(scan_block_totals<7>, g, b, 0, st, v, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, bs);
+    hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(1024), 0, st, bs, nb, totals);
+    hipLaunchKernelGGL(gr_hamiltonian_main, g, b, 0, st, v, G, c * c, pot, bs, totals, part);
+    hipLaunchKernelGGL((scan_of_totals<3, false>), dim3(1), dim3(1024), 0, st, part, nb, out);
     return hipGetLastError();
 }
 

@@ -294,6 +294,9 @@ class Extras(Structure):
     def gr_potential_potential(self, force):
         return self._potential(lib.rebx_gr_potential_potential(byref(self), byref(force)))
 
+    def gr_hamiltonian(self, force):
+        return self._potential(lib.rebx_gr_hamiltonian(byref(self), byref(force)))
+
     def _potential(self, value):
         self.process_messages()
         return value
@@ -451,6 +454,8 @@ for _n in ("rebx_gravitational_harmonics_potential", "rebx_central_force_potenti
     getattr(lib, _n).restype = c_double
 lib.rebx_gr_potential_potential.argtypes = [_P(Extras), _P(Force)]
 lib.rebx_gr_potential_potential.restype = c_double
+lib.rebx_gr_hamiltonian.argtypes = [_P(Extras), _P(Force)]
+lib.rebx_gr_hamiltonian.restype = c_double
 lib.rebx_create_operator.argtypes = [_P(Extras), c_char_p]
 lib.rebx_create_operator.restype = _P(Operator)
 lib.rebx_load_operator.argtypes = [_P(Extras), c_char_p]
@@ -468,7 +473,7 @@ PLUGIN_API_SYMBOLS = (
     "rebx_create_operator", "rebx_load_operator", "rebx_add_operator", "rebx_add_operator_step", "rebx_remove_operator",
     "rebx_get_operator", "rebx_pre_timestep_modifications", "rebx_post_timestep_modifications", "rebx_integrate_force",
     "rebx_drift_step", "rebx_kick_step", "rebx_gravitational_harmonics_potential", "rebx_central_force_potential",
-    "rebx_tides_precession_potential", "rebx_gr_potential_potential",
+    "rebx_tides_precession_potential", "rebx_gr_potential_potential", "rebx_gr_hamiltonian",
     "rebx_attach", "rebx_detach", "rebx_extras_cleanup", "rebx_free", "rebx_initialize", "rebx_register_default_params",
     "rebx_free_pointers", "rebx_free_particle_ap", "rebx_create_force", "rebx_load_force", "rebx_add_force", "rebx_remove_force",
     "rebx_get_force", "rebx_get_param", "rebx_get_param_struct", "rebx_set_param_pointer", "rebx_set_param_double",

@@ -81,3 +81,39 @@ def test_potentials_through_the_plugin_api():
     assert rebx.tides_precession_potential() == pytest.approx(oracle.tides_potential(ref, Rt, k1, prim), rel=1e-13)
     assert rebx.gr_potential_potential(grp) == pytest.approx(oracle.gr_potential_potential(ref, 1e3), rel=1e-13)
     sim.free_particle_params()
+
+
+@pytest.mark.parametrize("layout", ["twoplanets", "disk_massless", "disk_massive", "scattered"])
+def test_gr_hamiltonian(ctx, layout):
+    """src/gr.c:190-246.  Kinetic, Newtonian and post-Newtonian parts are sums of many terms of
+    both signs; bar: 1e-12 relative to T + |V| (the size of what is summed)."""
+    if layout == "twoplanets":
+        cols = synthetic.twoplanets()
+    else:
+        n = 3000
+        cols, _, _ = synthetic.disk(n, 3, dust_mass=0.0 if layout == "disk_massless" else 1e-9)
+        if layout == "scattered":
+            perm = np.concatenate([[0], 1 + np.random.default_rng(4).permutation(n - 1)])
+            cols = {k: np.ascontiguousarray(v[perm]) for k, v in cols.items()}
+            cols["m"][7:] = np.where(np.arange(7, n) % 3 == 0, 0.0, cols["m"][7:])
+    c = 50.0
+    want = oracle.gr_hamiltonian(oracle.Sim(cols), c)
+    got = ctx.gr_hamiltonian(DeviceParticles.from_host(cols, device="cuda:0").view(), c)
+    m = cols["m"]
+    v2 = cols["vx"] ** 2 + cols["vy"] ** 2 + cols["vz"] ** 2
+    scale = 0.5 * np.sum(m * v2) + abs(oracle.newtonian_energy(oracle.Sim(cols)))
+    assert abs(got - want) <= 1e-12 * scale, (got, want, scale)
+
+
+def test_gr_hamiltonian_through_the_plugin_api():
+    from reboundx_amd.extras import Extras, Simulation
+    cols = synthetic.twoplanets()
+    sim = Simulation()
+    for i in range(3):
+        sim.add(m=cols["m"][i], x=cols["x"][i], y=cols["y"][i], z=cols["z"][i], vx=cols["vx"][i], vy=cols["vy"][i], vz=cols["vz"][i])
+    rebx = Extras(sim)
+    gr = rebx.load_force("gr")
+    with pytest.raises(RuntimeError, match="speed of light"):
+        rebx.gr_hamiltonian(gr)
+    gr.params["c"] = 1e4
+    assert rebx.gr_hamiltonian(gr) == pytest.approx(oracle.gr_hamiltonian(oracle.Sim(cols), 1e4), rel=1e-13)
