@@ -154,6 +154,34 @@ void rebx_error(struct rebx_extras* rebx, const char* const msg);
  * callbacks on the host in between. */
 void rebx_additional_forces(struct reb_simulation* sim);
 
+/* Binary parameter files (.rebx): src/reboundx.h:134-152 (messages), :287 and src/output.c:267-288
+ * (writer), :296-302 and src/input.c:627-702 (readers).  Same record format as the reference, so
+ * files written by either side load in the other; padding bytes in record headers are written as
+ * zero.  UINT32 parameter values are written with their 4 bytes (the reference's size table has no
+ * entry for the type and writes none). */
+enum rebx_input_binary_messages {
+    REBX_INPUT_BINARY_WARNING_NONE = 0,
+    REBX_INPUT_BINARY_ERROR_NOFILE = 1,
+    REBX_INPUT_BINARY_ERROR_CORRUPT = 2,
+    REBX_INPUT_BINARY_ERROR_NO_MEMORY = 4,
+    REBX_INPUT_BINARY_ERROR_REBX_NOT_LOADED = 8,
+    REBX_INPUT_BINARY_ERROR_REGISTERED_PARAM_NOT_LOADED = 16,
+    REBX_INPUT_BINARY_WARNING_PARAM_NOT_LOADED = 32,
+    REBX_INPUT_BINARY_WARNING_PARTICLE_PARAMS_NOT_LOADED = 64,
+    REBX_INPUT_BINARY_WARNING_FORCE_NOT_LOADED = 128,
+    REBX_INPUT_BINARY_WARNING_OPERATOR_NOT_LOADED = 256,
+    REBX_INPUT_BINARY_WARNING_STEP_NOT_LOADED = 512,
+    REBX_INPUT_BINARY_WARNING_ADDITIONAL_FORCE_NOT_LOADED = 1024,
+    REBX_INPUT_BINARY_WARNING_FIELD_UNKNOWN = 2048,
+    REBX_INPUT_BINARY_WARNING_LIST_UNKNOWN = 4096,
+    REBX_INPUT_BINARY_WARNING_PARAM_VALUE_NULL = 8192,
+    REBX_INPUT_BINARY_WARNING_VERSION = 16384,
+    REBX_INPUT_BINARY_WARNING_FORCE_PARAM_NOT_LOADED = 32768
+};
+void rebx_output_binary(struct rebx_extras* rebx, char* filename);
+void rebx_init_extras_from_binary(struct rebx_extras* rebx, const char* const filename, enum rebx_input_binary_messages* warnings);
+struct rebx_extras* rebx_create_extras_from_binary(struct reb_simulation* sim, const char* const filename);
+
 /* Potentials of the position-dependent forces, evaluated on the device from sim->particles
  * (src/reboundx.h:483-504; gravitational_harmonics.c:221-231, central_force.c:122-141,
  * tides_precession.c:182-202, gr_potential.c:122-132). */

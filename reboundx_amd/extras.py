@@ -163,6 +163,27 @@ Force._fields_ = [("name", c_char_p), ("ap", POINTER(Node)), ("_sim", POINTER(Si
 assert ctypes.sizeof(Force) == 40
 
 
+# (is an error, bit, text): reference reboundx/extras.py:13-29
+REBX_BINARY_WARNINGS = [
+    (True, 1, "REBOUNDx: Cannot open binary file. Check filename."),
+    (True, 2, "REBOUNDx: Binary file is unreadable."),
+    (True, 4, "REBOUNDx: Ran out of system memory."),
+    (True, 8, "REBOUNDx: REBOUNDx structure couldn't be loaded."),
+    (True, 16, "REBOUNDx: At least one registered parameter was not loaded."),
+    (False, 32, "REBOUNDx: At least one force or operator parameter was not loaded from the binary file."),
+    (False, 64, "REBOUNDx: At least one particle's parameters were not loaded from the binary file."),
+    (False, 128, "REBOUNDx: At least one force was not loaded from the binary file."),
+    (False, 256, "REBOUNDx: At least one operator was not loaded from the binary file."),
+    (False, 512, "REBOUNDx: At least one operator step was not loaded from the binary file."),
+    (False, 1024, "REBOUNDx: At least one force was not added to the simulation."),
+    (False, 2048, "REBOUNDx: Unknown field found in binary file."),
+    (False, 4096, "REBOUNDx: Unknown list in the REBOUNDx structure wasn't loaded."),
+    (False, 8192, "REBOUNDx: The value of at least one parameter was not loaded."),
+    (False, 16384, "REBOUNDx: Binary file was saved with a different version of REBOUNDx."),
+    (False, 32768, "REBOUNDx: A force parameter failed to load from the list of REBOUNDx implemented forces."),
+]
+
+
 class Operator(Structure):
     """struct rebx_operator (reference reboundx/extras.py:225-258)."""
 
@@ -201,11 +222,25 @@ assert ctypes.sizeof(Operator) == 40
 class Extras(Structure):
     """struct rebx_extras; allocated by Python, initialised by the library, like the reference wrapper."""
 
-    def __init__(self, sim):
+    def __init__(self, sim, filename=None):
         Structure.__init__(self)
         sim._extras_ref = self
         lib.rebx_initialize(byref(sim), byref(self))
-        lib.rebx_register_default_params(byref(self))
+        if filename is None:
+            lib.rebx_register_default_params(byref(self))
+        else:
+            # the file carries the registered parameters (reference reboundx/extras.py:50-60)
+            w = c_int(0)
+            lib.rebx_init_extras_from_binary(byref(self), filename.encode("ascii"), byref(w))
+            for major, value, message in REBX_BINARY_WARNINGS:
+                if w.value & value:
+                    if major:
+                        raise RuntimeError(message)
+                    warnings.warn(message, RuntimeWarning)
+        self.process_messages()
+
+    def save(self, filename):
+        lib.rebx_output_binary(byref(self), filename.encode("ascii"))
         self.process_messages()
 
     def __del__(self):
@@ -456,6 +491,12 @@ lib.rebx_gr_potential_potential.argtypes = [_P(Extras), _P(Force)]
 lib.rebx_gr_potential_potential.restype = c_double
 lib.rebx_gr_hamiltonian.argtypes = [_P(Extras), _P(Force)]
 lib.rebx_gr_hamiltonian.restype = c_double
+lib.rebx_output_binary.argtypes = [_P(Extras), c_char_p]
+lib.rebx_output_binary.restype = None
+lib.rebx_init_extras_from_binary.argtypes = [_P(Extras), c_char_p, _P(c_int)]
+lib.rebx_init_extras_from_binary.restype = None
+lib.rebx_create_extras_from_binary.argtypes = [_P(Simulation), c_char_p]
+lib.rebx_create_extras_from_binary.restype = _P(Extras)
 lib.rebx_create_operator.argtypes = [_P(Extras), c_char_p]
 lib.rebx_create_operator.restype = _P(Operator)
 lib.rebx_load_operator.argtypes = [_P(Extras), c_char_p]
@@ -472,6 +513,7 @@ lib.rebx_remove_operator.restype = c_int
 PLUGIN_API_SYMBOLS = (
     "rebx_create_operator", "rebx_load_operator", "rebx_add_operator", "rebx_add_operator_step", "rebx_remove_operator",
     "rebx_get_operator", "rebx_pre_timestep_modifications", "rebx_post_timestep_modifications", "rebx_integrate_force",
+    "rebx_output_binary", "rebx_init_extras_from_binary", "rebx_create_extras_from_binary",
     "rebx_drift_step", "rebx_kick_step", "rebx_gravitational_harmonics_potential", "rebx_central_force_potential",
     "rebx_tides_precession_potential", "rebx_gr_potential_potential", "rebx_gr_hamiltonian",
     "rebx_attach", "rebx_detach", "rebx_extras_cleanup", "rebx_free", "rebx_initialize", "rebx_register_default_params",
