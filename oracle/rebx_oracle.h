@@ -88,6 +88,11 @@ int orc_integrate_force(orc_sim* s, int integrator, double dt, orc_force_fn f, v
 void orc_drift_step(orc_sim* s, double dt);   /* src/steppers.c:112-121 */
 void orc_kick_step(orc_sim* s, double dt);    /* src/steppers.c:123-133 (acceleration columns as given) */
 
+/* Wisdom-Holman steps (Jacobi coordinates, REBOUND's WHFast defaults) used to replay the
+ * reference's trajectory archives; see rebx_whfast.c. */
+typedef void (*orc_step_fn)(orc_sim* state, double dt, void* user);
+int orc_whfast_steps(orc_sim* s, double dt, long nsteps, orc_force_fn f, orc_step_fn pre, orc_step_fn post, void* user);
+
 /* potentials used by the reference's conservation tests */
 double orc_gravitational_harmonics_potential(const orc_sim* s, const double* J2, const double* J4, const double* R_eq); /* gravitational_harmonics.c:142-231 */
 double orc_central_force_potential(const orc_sim* s, const double* Acentral, const double* gammacentral);               /* central_force.c:97-141 */

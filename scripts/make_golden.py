@@ -8,10 +8,11 @@ committed JSON files, never the reference tree.
       the reference's test_machine_independent.py replays: REBOUND SimulationArchive files
       (version 3.9.0) of the three-body `twoplanets` system integrated with WHFast,
       dt = P1/100, one force each.  Extracted: time and particle state (x y z vx vy vz m) of
-      the first two snapshots (t = 0 and t ~ 1000).  File format as found in the files: a
+      every snapshot.  File format as found in the files: a
       64-byte header, then records {uint32 type, uint32 pad, uint64 size, payload}; type 0 =
       time, type 85 = the particle array (128-byte records: x y z vx vy vz ax ay az m ...),
-      type 9999 ends a snapshot and is followed by an 8-byte index blob.
+      type 9999 ends a snapshot and is followed by an 8-byte index blob; type 1 = G, type 3 = dt.
+      All eleven snapshots (t = 0 ... 1e4) are extracted.
   notebook_kats.json -- numbers printed in the stored outputs of the reference's notebooks
       (ipython_examples/*.ipynb), with the cell they come from.
 
@@ -44,8 +45,10 @@ def read_sa(path, max_snapshots):
             off += 16 + s
         time = struct.unpack_from("<d", d, info[0][1])[0]
         p = np.frombuffer(d, dtype=np.float64, count=info[85][0] // 8, offset=info[85][1]).reshape(-1, 16)
+        if not out:
+            scalars = {"G": struct.unpack_from("<d", d, info[1][1])[0], "dt": struct.unpack_from("<d", d, info[3][1])[0]}
         out.append((time, p))
-    return header, out
+    return header, scalars, out
 
 
 def hexrow(a):
@@ -54,11 +57,12 @@ def hexrow(a):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    arch = {"source": "reboundx/test/binaries/<force>.sa (reference test fixtures), first two snapshots",
+    arch = {"source": "reboundx/test/binaries/<force>.sa (reference test fixtures), all snapshots",
             "columns": ["x", "y", "z", "vx", "vy", "vz", "m"], "forces": {}}
     for name in FORCES:
-        header, snaps = read_sa(os.path.join(REF, "reboundx", "test", "binaries", name + ".sa"), 2)
+        header, scalars, snaps = read_sa(os.path.join(REF, "reboundx", "test", "binaries", name + ".sa"), 99)
         arch["header"] = header
+        arch["G"], arch["dt"] = float(scalars["G"]).hex(), float(scalars["dt"]).hex()
         arch["forces"][name] = [{"t": float(t).hex(), "particles": [hexrow(np.concatenate([row[:6], row[9:10]])) for row in p]}
                                 for t, p in snaps]
     with open(os.path.join(OUT, "reference_archives.json"), "w") as f:

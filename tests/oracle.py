@@ -196,3 +196,25 @@ def drift_step(sim, dt):
 
 def kick_step(sim, dt):
     lib.orc_kick_step(ctypes.byref(sim.s), float(dt))
+
+
+_STEP_FN = ctypes.CFUNCTYPE(None, POINTER(OrcSim), c_double, c_void_p)
+lib.orc_whfast_steps.restype = c_int
+lib.orc_whfast_steps.argtypes = [POINTER(OrcSim), c_double, ctypes.c_long, _FORCE_FN, _STEP_FN, _STEP_FN, c_void_p]
+
+
+def whfast_steps(sim, dt, nsteps, forces=None, pp=None, pre=None, post=None):
+    """Wisdom-Holman steps (oracle/rebx_whfast.c) with `forces` (execution order) applied in
+    the kick.  pre/post: callables (state_view, dt) run before/after every step."""
+    def cb(ptr, _user):
+        # WHFast leaves the (0,1) pair out of the accelerations it hands to the forces
+        # (sim->gravity_ignore_terms == 1): gr_full adds it back (src/gr_full.c:150-171)
+        apply_forces(_StateView(ptr.contents), forces, pp or {}, gravity_ignore_terms=1)
+
+    def wrap(fn):
+        if fn is None:
+            return _STEP_FN(0)
+        return _STEP_FN(lambda ptr, h, _u: fn(_StateView(ptr.contents), h))
+    f = _FORCE_FN(cb) if forces else _FORCE_FN(0)
+    rc = lib.orc_whfast_steps(ctypes.byref(sim.s), float(dt), int(nsteps), f, wrap(pre), wrap(post), None)
+    assert rc == 0

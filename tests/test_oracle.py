@@ -10,10 +10,16 @@ What pins it:
     both integrate to ~1e-12, so the stored digits are reproduced to ~1e-9);
   * the trajectory archives the reference's own test suite replays
     (reboundx/test/binaries/<force>.sa, extracted to tests/golden/reference_archives.json by
-    scripts/make_golden.py): the displacement each force causes over ~159 inner orbits, taken
-    as the difference between the archive of that force and the archive of a force with no
-    measurable effect, is reproduced by the checker's force to ~1e-4 (the O(dt^2) splitting
-    error of the reference's WHFast run);
+    scripts/make_golden.py).  Two independent uses:
+      - replay: the checker's Wisdom-Holman restatement (oracle/rebx_whfast.c) with the
+        checker's force in the kick reproduces the stored states after 15 917 and 79 582 steps
+        to ~1e-10 (roundoff), for every force -- which pins each force, the Jacobi/centre-of-mass
+        helpers and gr_full's handling of the pair the integrator leaves out, to the
+        reference's own output at 1e-6 .. 1e-11 of the force;
+      - displacement: without trusting that integrator, the displacement each force causes
+        (archive of the force minus the force-free archive) agrees with an 8th-order
+        Runge-Kutta integration of gravity + the checker's force to ~1e-4, the O(dt^2)
+        splitting error of the reference's run;
   * force = -grad(potential) for every effect whose potential the reference's
     test_conservation.py relies on (reboundx/test/test_conservation.py:38-96).
 """
@@ -411,3 +417,66 @@ def test_integrate_force_none_only_clears_accelerations():
     assert oracle.integrate_force(s, "none", 0.1, [("gr_potential", {"c": 100.0})], pp) == 0
     assert not np.array(s.acc).any()
     assert all(np.array_equal(s.cols[k], cols[k]) for k in ("vx", "vy", "vz"))
+
+
+# ------------------------------------------------------------- archive replay (Wisdom-Holman)
+
+ARCHIVE_REPLAY = dict(ARCHIVE_FORCES)
+ARCHIVE_REPLAY["tides_precession"] = ([("tides_precession", {})], _params3(R_tides={0: 1e-3}, k1={0: .4}))
+
+
+def _replay(arch, name, snapshot, forces, pp):
+    dt = float.fromhex(arch["dt"])
+    _, c0, _ = _archive_state(arch["forces"][name][0])
+    t1, _, ref = _archive_state(arch["forces"][name][snapshot])
+    sim = oracle.Sim(c0, float.fromhex(arch["G"]))
+    oracle.whfast_steps(sim, dt, round(t1 / dt), forces, pp)
+    got = np.array([sim.cols[k] for k in ("x", "y", "z", "vx", "vy", "vz")]).T
+    return got, ref
+
+
+@pytest.fixture(scope="module")
+def archives():
+    return json.load(open(os.path.join(GOLDEN, "reference_archives.json")))
+
+
+def test_wisdom_holman_restatement_reproduces_the_force_free_archive(archives):
+    """Validates oracle/rebx_whfast.c against REBOUND's own output: tides_precession's archive is
+    the force-free run (the force is ~1e-20 of gravity here).  143 247 steps to 1e-9."""
+    for snapshot, tol in ((1, 2e-10), (4, 1e-9), (9, 2e-9)):
+        got, ref = _replay(archives, "tides_precession", snapshot, None, None)
+        assert np.abs(got - ref).max() <= tol
+
+
+@pytest.mark.parametrize("name", sorted(ARCHIVE_REPLAY))
+def test_archive_replay_pins_force_to_roundoff(archives, name):
+    forces, pp = ARCHIVE_REPLAY[name]
+    for snapshot in (1, 5):
+        got, ref = _replay(archives, name, snapshot, forces, pp)
+        scale = max(1.0, np.abs(ref).max())
+        assert np.abs(got - ref).max() <= (2e-10 if snapshot == 1 else 3e-9) * scale, (name, snapshot)
+
+
+def test_archive_replay_is_sensitive_to_the_force(archives):
+    """The pin has teeth: a 1e-8 relative change of one parameter, or leaving the force out,
+    moves the replay away from the archive by far more than the agreement above."""
+    forces, pp = ARCHIVE_REPLAY["modify_orbits_forces"]
+    good, ref = _replay(archives, "modify_orbits_forces", 1, forces, pp)
+    off = dict(pp)
+    off["tau_e"] = pp["tau_e"] * (1 + 1e-8)
+    bad, _ = _replay(archives, "modify_orbits_forces", 1, forces, off)
+    assert np.abs(bad - ref).max() > 20 * np.abs(good - ref).max()
+    for name in ("gr", "gr_full", "gravitational_harmonics"):
+        none, ref = _replay(archives, name, 1, None, None)
+        assert np.abs(none - ref).max() > 1e-6
+    # gr_full without adding back the pair the integrator leaves out of the accelerations
+    sim_forces = [("gr_full", {"c": 1e4})]
+    dt = float.fromhex(archives["dt"])
+    _, c0, _ = _archive_state(archives["forces"]["gr_full"][0])
+    t1, _, ref = _archive_state(archives["forces"]["gr_full"][1])
+    sim = oracle.Sim(c0)
+    import ctypes
+    cb = oracle._FORCE_FN(lambda ptr, _u: oracle.apply_forces(oracle._StateView(ptr.contents), sim_forces, {}, gravity_ignore_terms=0))
+    oracle.lib.orc_whfast_steps(ctypes.byref(sim.s), dt, round(t1 / dt), cb, oracle._STEP_FN(0), oracle._STEP_FN(0), None)
+    got = np.array([sim.cols[k] for k in ("x", "y", "z", "vx", "vy", "vz")]).T
+    assert np.abs(got - ref).max() > 1e-8
