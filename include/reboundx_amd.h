@@ -347,6 +347,19 @@ int rebxamd_add_pushes(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd
 /* src/core.c:860-866 on device columns. */
 int rebxamd_reset_accelerations(rebxamd_ctx* ctx, const rebxamd_view* view, void* stream);
 
+/* Device-resident Wisdom-Holman stepping for one dominant mass at index 0 followed by massless
+ * bodies (view->n_head = 1, view->tail_massless = 1), so that a many-step run with additional
+ * forces never leaves the GPU.  No counterpart in the reference: there REBOUND's WHFast owns
+ * the step and calls rebx_additional_forces from its kick (src/core.c:868-880).
+ * rebxamd_wh_drift: body 0 drifts linearly, every other body moves on its Kepler orbit about it
+ * (mass parameter G*m0) for dt.  rebxamd_wh_steps: nsteps times { drift dt/2; accelerations :=
+ * ops (the additional forces alone: the dominant mass is in the drift); v_i += dt*(a_i - a_0);
+ * drift dt/2 }, positions and velocities updated in place, asynchronous after one initial read
+ * of m0. */
+int rebxamd_wh_drift(rebxamd_ctx* ctx, const rebxamd_view* view, double dt, int mode, void* stream);
+int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, double dt, int64_t nsteps,
+                     int mode, void* stream);
+
 /* Potential energy of each op in `ops` (J2, J4, central_force, tides_precession, gr_potential),
  * summed over the particles of `view`: out[k] (host memory, nops doubles) is what the
  * reference's per-source potential routine returns for op k

@@ -22,6 +22,7 @@ struct rebxamd_ctx {
     size_t gf_cap = 0;
     unsigned* gf_flag = nullptr;
     double* chunk_sums = nullptr;       // second-stage scratch of the back-reaction reduction
+    double* star = nullptr;             // 16 doubles: state of body 0 around a Wisdom-Holman drift
     double* integ = nullptr;            // stage columns of the force integrators
     size_t integ_cap = 0;
     double* scan = nullptr;             // workspace of the prefix/suffix-sum passes (gr, Jacobi/barycentric mof, any layout)
@@ -78,6 +79,7 @@ extern "C" int rebxamd_create(int device, rebxamd_ctx** out) {
         hipMalloc((void**)&ctx->status, sizeof(unsigned)) != hipSuccess ||
         hipMalloc((void**)&ctx->ll, sizeof(long long)) != hipSuccess ||
         hipMalloc((void**)&ctx->gf_flag, sizeof(unsigned)) != hipSuccess ||
+        hipMalloc((void**)&ctx->star, 16 * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&ctx->chunk_sums, sizeof(double) * REBXAMD_MAX_OPS * 64 * 3) != hipSuccess ||
         hipMemset(ctx->hc, 0, sizeof(HeadConsts)) != hipSuccess ||
         hipMemset(ctx->status, 0, sizeof(unsigned)) != hipSuccess) {
@@ -98,6 +100,7 @@ extern "C" void rebxamd_destroy(rebxamd_ctx* ctx) {
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->gf) (void)hipFree(ctx->gf);
     if (ctx->gf_flag) (void)hipFree(ctx->gf_flag);
+    if (ctx->star) (void)hipFree(ctx->star);
     if (ctx->chunk_sums) (void)hipFree(ctx->chunk_sums);
     if (ctx->scan) (void)hipFree(ctx->scan);
     if (ctx->integ) (void)hipFree(ctx->integ);
@@ -512,6 +515,56 @@ extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* vie
     }
     for (int k = 0; k < 3; k++) HIP_TRY(hipMemcpyAsync(v[k], ckb[k], (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (iterations) *iterations = it;
+    return REBXAMD_OK;
+}
+
+// ------------------------------------------------------------------ Wisdom-Holman steps, one dominant mass + massless bodies
+
+extern "C" int rebxamd_wh_drift(rebxamd_ctx* ctx, const rebxamd_view* view, double dt, int mode, void* stream) {
+    const int rc = check_step_view(ctx, view, "rebxamd_wh_drift: bad argument", true, false);
+    if (rc != REBXAMD_OK || view->n == 0) return rc;
+    if (!view->m) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_drift: mass column missing");
+    if (!(view->n_head <= 1 && view->tail_massless)) return fail(ctx, REBXAMD_ERR_UNSUPPORTED, "rebxamd_wh_drift handles one massive body at index 0 followed by massless ones (n_head = 1, tail_massless = 1)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    double m0 = 0.;
+    HIP_TRY(hipMemcpyAsync(&m0, view->m, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    double* const x[3] = {const_cast<double*>(view->x), const_cast<double*>(view->y), const_cast<double*>(view->z)};
+    double* const v[3] = {const_cast<double*>(view->vx), const_cast<double*>(view->vy), const_cast<double*>(view->vz)};
+    HIP_TRY(launch_wh_drift(x, v, view->G * m0, dt, view->n, ctx->star, mode == REBXAMD_MODE_EXACT, st));
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, double dt, int64_t nsteps,
+                                int mode, void* stream) {
+    int rc = check_step_view(ctx, view, "rebxamd_wh_steps: bad argument", true, true);
+    if (rc != REBXAMD_OK) return rc;
+    if (nsteps < 0 || nops < 0 || (nops > 0 && !ops)) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_steps: bad argument");
+    if (view->n == 0 || nsteps == 0) return REBXAMD_OK;
+    if (!view->m) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_steps: mass column missing");
+    if (!(view->n_head <= 1 && view->tail_massless)) return fail(ctx, REBXAMD_ERR_UNSUPPORTED, "rebxamd_wh_steps handles one massive body at index 0 followed by massless ones (n_head = 1, tail_massless = 1)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const bool exact = mode == REBXAMD_MODE_EXACT;
+    double m0 = 0.;
+    HIP_TRY(hipMemcpyAsync(&m0, view->m, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const double mu = view->G * m0;
+    double* const x[3] = {const_cast<double*>(view->x), const_cast<double*>(view->y), const_cast<double*>(view->z)};
+    double* const v[3] = {const_cast<double*>(view->vx), const_cast<double*>(view->vy), const_cast<double*>(view->vz)};
+    const double* const a[3] = {view->ax, view->ay, view->az};
+    for (int64_t k = 0; k < nsteps; k++) {
+        HIP_TRY(launch_wh_drift(x, v, mu, 0.5 * dt, view->n, ctx->star, exact, st));
+        rc = rebxamd_reset_accelerations(ctx, view, stream);
+        if (rc != REBXAMD_OK) return rc;
+        if (nops > 0) {
+            rc = rebxamd_apply(ctx, view, ops, nops, mode, stream);
+            if (rc != REBXAMD_OK) return rc;
+        }
+        HIP_TRY(launch_wh_kick(v, a, dt, view->n, exact, st));
+        HIP_TRY(launch_wh_drift(x, v, mu, 0.5 * dt, view->n, ctx->star, exact, st));
+    }
     return REBXAMD_OK;
 }
 

@@ -129,6 +129,163 @@ __global__ __launch_bounds__(1024) void im_sum_kernel(const double* partials, lo
     }
 }
 
+// ---------------------------------------------------------------- Wisdom-Holman drift and kick
+// for one dominant mass at index 0 and massless bodies behind it (the layout of a debris-disk
+// run).  REBOUND owns this step in a host run; on the device it is what keeps a multi-step run
+// resident.  In Jacobi coordinates massless bodies do not move the interior centre of mass, so
+// body i >= 1 is propagated on a Kepler orbit about body 0 with mass parameter G*m0 (universal
+// variables, Stumpff series), and body 0 drifts linearly.
+
+template <bool EXACT>
+__device__ __forceinline__ void stumpff_dev(double z, double (&c)[4]) {
+    int n = 0;
+    while (fabs(z) > 0.1) { z *= 0.25; n++; }
+    const double a3[9] = {1. / 6., 1. / 120., 1. / 5040., 1. / 362880., 1. / 39916800., 1. / 6227020800., 1. / 1307674368000.,
+                          1. / 355687428096000., 1. / 121645100408832000.};
+    const double a2[9] = {1. / 2., 1. / 24., 1. / 720., 1. / 40320., 1. / 3628800., 1. / 479001600., 1. / 87178291200.,
+                          1. / 20922789888000., 1. / 6402373705728000.};
+    double c3 = 0., c2 = 0., c1, c0;
+    if (EXACT) {
+#pragma clang fp contract(off)
+        for (int k = 8; k >= 0; k--) { c3 = a3[k] - z * c3; c2 = a2[k] - z * c2; }
+        c1 = 1. - z * c3; c0 = 1. - z * c2;
+        for (; n > 0; n--) {
+            z *= 4.;
+            c3 = 0.25 * (c2 + c0 * c3);
+            c2 = 0.5 * c1 * c1;
+            c1 = c0 * c1;
+            c0 = 2. * c0 * c0 - 1.;
+        }
+    } else {
+        for (int k = 8; k >= 0; k--) { c3 = a3[k] - z * c3; c2 = a2[k] - z * c2; }
+        c1 = 1. - z * c3; c0 = 1. - z * c2;
+        for (; n > 0; n--) {
+            z *= 4.;
+            c3 = 0.25 * (c2 + c0 * c3);
+            c2 = 0.5 * c1 * c1;
+            c1 = c0 * c1;
+            c0 = 2. * c0 * c0 - 1.;
+        }
+    }
+    c[0] = c0; c[1] = c1; c[2] = c2; c[3] = c3;
+}
+
+template <bool EXACT>
+__device__ __forceinline__ void gfuncs_dev(double beta, double X, double (&G)[4]) {
+    double c[4];
+    const double X2 = X * X;
+    stumpff_dev<EXACT>(beta * X2, c);
+    if (EXACT) {
+#pragma clang fp contract(off)
+        G[0] = c[0]; G[1] = X * c[1]; G[2] = X2 * c[2]; G[3] = X2 * X * c[3];
+    } else {
+        G[0] = c[0]; G[1] = X * c[1]; G[2] = X2 * c[2]; G[3] = X2 * X * c[3];
+    }
+}
+
+// two-body propagation of the relative state (x, v) about mass parameter M over dt
+template <bool EXACT>
+__device__ __forceinline__ void kepler_dev(double (&q)[6], double M, double dt) {
+    const double x0 = q[0], y0 = q[1], z0 = q[2], vx0 = q[3], vy0 = q[4], vz0 = q[5];
+    double r0, r0i, beta, eta0, zeta0, X;
+    if (EXACT) {
+#pragma clang fp contract(off)
+        r0 = sqrt(x0 * x0 + y0 * y0 + z0 * z0);
+        r0i = 1. / r0;
+        const double v2 = vx0 * vx0 + vy0 * vy0 + vz0 * vz0;
+        beta = 2. * M * r0i - v2;
+        eta0 = x0 * vx0 + y0 * vy0 + z0 * vz0;
+        zeta0 = M - beta * r0;
+        X = dt * r0i * (1. - 0.5 * dt * eta0 * r0i * r0i);
+    } else {
+        r0 = sqrt(x0 * x0 + y0 * y0 + z0 * z0);
+        r0i = 1. / r0;
+        const double v2 = vx0 * vx0 + vy0 * vy0 + vz0 * vz0;
+        beta = 2. * M * r0i - v2;
+        eta0 = x0 * vx0 + y0 * vy0 + z0 * vz0;
+        zeta0 = M - beta * r0;
+        X = dt * r0i * (1. - 0.5 * dt * eta0 * r0i * r0i);
+    }
+    double G[4];
+    double lo = -HUGE_VAL, hi = HUGE_VAL, prev1 = __builtin_nan(""), prev2 = __builtin_nan("");
+    for (int it = 0; it < 60; it++) {
+        gfuncs_dev<EXACT>(beta, X, G);
+        double s, sp, Xn;
+        if (EXACT) {
+#pragma clang fp contract(off)
+            s = r0 * X + eta0 * G[2] + zeta0 * G[3] - dt;
+            sp = r0 + eta0 * G[1] + zeta0 * G[2];
+            Xn = X - s / sp;
+        } else {
+            s = r0 * X + eta0 * G[2] + zeta0 * G[3] - dt;
+            sp = r0 + eta0 * G[1] + zeta0 * G[2];
+            Xn = X - s / sp;
+        }
+        if (s > 0.) hi = X; else lo = X;
+        if (!(Xn > lo && Xn < hi)) Xn = (isfinite(lo) && isfinite(hi)) ? 0.5 * (lo + hi) : Xn;
+        if (Xn == X || Xn == prev1 || Xn == prev2) { X = Xn; break; }
+        prev2 = prev1; prev1 = X; X = Xn;
+    }
+    gfuncs_dev<EXACT>(beta, X, G);
+    if (EXACT) {
+#pragma clang fp contract(off)
+        const double r = r0 + eta0 * G[1] + zeta0 * G[2];
+        const double ri = 1. / r;
+        const double fm1 = -M * G[2] * r0i, g = dt - M * G[3], fd = -M * G[1] * r0i * ri, gdm1 = -M * G[2] * ri;
+        q[0] += fm1 * x0 + g * vx0; q[1] += fm1 * y0 + g * vy0; q[2] += fm1 * z0 + g * vz0;
+        q[3] += fd * x0 + gdm1 * vx0; q[4] += fd * y0 + gdm1 * vy0; q[5] += fd * z0 + gdm1 * vz0;
+    } else {
+        const double r = r0 + eta0 * G[1] + zeta0 * G[2];
+        const double ri = 1. / r;
+        const double fm1 = -M * G[2] * r0i, g = dt - M * G[3], fd = -M * G[1] * r0i * ri, gdm1 = -M * G[2] * ri;
+        q[0] += fm1 * x0 + g * vx0; q[1] += fm1 * y0 + g * vy0; q[2] += fm1 * z0 + g * vz0;
+        q[3] += fd * x0 + gdm1 * vx0; q[4] += fd * y0 + gdm1 * vy0; q[5] += fd * z0 + gdm1 * vz0;
+    }
+}
+
+// star[0..5] <- state of body 0 before the drift; body 0 drifts linearly; star[6..8] <- its new position
+__global__ void wh_star_drift_kernel(Cols3 x, CCols3 v, double h, double* star) {
+#pragma clang fp contract(off)
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double x0 = x.x[0], y0 = x.y[0], z0 = x.z[0], vx = v.x[0], vy = v.y[0], vz = v.z[0];
+    star[0] = x0; star[1] = y0; star[2] = z0; star[3] = vx; star[4] = vy; star[5] = vz;
+    const double nx = x0 + h * vx, ny = y0 + h * vy, nz = z0 + h * vz;
+    x.x[0] = nx; x.y[0] = ny; x.z[0] = nz;
+    star[6] = nx; star[7] = ny; star[8] = nz;
+}
+
+template <bool EXACT>
+__global__ __launch_bounds__(TB) void wh_drift_kernel(Cols3 x, Cols3 v, double mu, double h, long long n, const double* __restrict__ star) {
+    const long long i = (long long)blockIdx.x * TB + threadIdx.x + 1;
+    if (i >= n) return;
+    double q[6];
+    {
+#pragma clang fp contract(off)
+        q[0] = x.x[i] - star[0]; q[1] = x.y[i] - star[1]; q[2] = x.z[i] - star[2];
+        q[3] = v.x[i] - star[3]; q[4] = v.y[i] - star[4]; q[5] = v.z[i] - star[5];
+    }
+    kepler_dev<EXACT>(q, mu, h);
+    {
+#pragma clang fp contract(off)
+        x.x[i] = q[0] + star[6]; x.y[i] = q[1] + star[7]; x.z[i] = q[2] + star[8];
+        v.x[i] = q[3] + star[3]; v.y[i] = q[4] + star[4]; v.z[i] = q[5] + star[5];
+    }
+}
+
+// kick in Jacobi coordinates with massless bodies: v_i += dt*(a_i - a_0), i >= 1; body 0 (the centre of mass) is not kicked
+template <bool EXACT>
+__global__ __launch_bounds__(TB) void wh_kick_kernel(Cols3 v, CCols3 a, double dt, long long n) {
+    const long long i = (long long)blockIdx.x * TB + threadIdx.x + 1;
+    if (i >= n) return;
+    const double a0x = a.x[0], a0y = a.y[0], a0z = a.z[0];
+    if (EXACT) {
+#pragma clang fp contract(off)
+        v.x[i] += dt * (a.x[i] - a0x); v.y[i] += dt * (a.y[i] - a0y); v.z[i] += dt * (a.z[i] - a0z);
+    } else {
+        v.x[i] += dt * (a.x[i] - a0x); v.y[i] += dt * (a.y[i] - a0y); v.z[i] += dt * (a.z[i] - a0z);
+    }
+}
+
 static inline dim3 grid_for(long long n) { return dim3((unsigned)((n + TB - 1) / TB)); }
 
 hipError_t launch_lincomb(double* const out[3], const double* const v[3], const double* const a[3], double coef, long long n, bool exact, hipStream_t st) {
@@ -177,6 +334,27 @@ hipError_t launch_im_update(double* const fin[3], const double* const orig[3], d
     if (exact) hipLaunchKernelGGL(im_update_kernel<true>, grid_for(n), dim3(TB), 0, st, f, o, av, aa, dt, n, partials);
     else hipLaunchKernelGGL(im_update_kernel<false>, grid_for(n), dim3(TB), 0, st, f, o, av, aa, dt, n, partials);
     hipLaunchKernelGGL(im_sum_kernel, dim3(1), dim3(1024), 0, st, partials, im_partial_count(n), sums);
+    return hipGetLastError();
+}
+
+hipError_t launch_wh_drift(double* const x[3], double* const v[3], double mu, double h, long long n, double* star, bool exact, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const Cols3 cx = {x[0], x[1], x[2]}, cv = {v[0], v[1], v[2]};
+    const CCols3 ccv = {v[0], v[1], v[2]};
+    hipLaunchKernelGGL(wh_star_drift_kernel, dim3(1), dim3(64), 0, st, cx, ccv, h, star);
+    if (n > 1) {
+        if (exact) hipLaunchKernelGGL(wh_drift_kernel<true>, grid_for(n - 1), dim3(TB), 0, st, cx, cv, mu, h, n, star);
+        else hipLaunchKernelGGL(wh_drift_kernel<false>, grid_for(n - 1), dim3(TB), 0, st, cx, cv, mu, h, n, star);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_wh_kick(double* const v[3], const double* const a[3], double dt, long long n, bool exact, hipStream_t st) {
+    if (n <= 1) return hipSuccess;
+    const Cols3 cv = {v[0], v[1], v[2]};
+    const CCols3 ca = {a[0], a[1], a[2]};
+    if (exact) hipLaunchKernelGGL(wh_kick_kernel<true>, grid_for(n - 1), dim3(TB), 0, st, cv, ca, dt, n);
+    else hipLaunchKernelGGL(wh_kick_kernel<false>, grid_for(n - 1), dim3(TB), 0, st, cv, ca, dt, n);
     return hipGetLastError();
 }
 

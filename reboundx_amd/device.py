@@ -71,6 +71,14 @@ class Context:
         arr = (Op * len(ops))(*ops)
         self._check(lib.rebxamd_add_pushes(self._h, ctypes.byref(view), arr, len(ops), sums.data_ptr(), self._stream()))
 
+    def wh_drift(self, view, dt, mode=_lib.MODE_FAST):
+        self._check(lib.rebxamd_wh_drift(self._h, ctypes.byref(view), float(dt), mode, self._stream()))
+
+    def wh_steps(self, view, ops, dt, nsteps, mode=_lib.MODE_FAST):
+        """nsteps Wisdom-Holman steps (one dominant mass + massless bodies) with `ops` in the kick."""
+        arr = (Op * max(len(ops), 1))(*ops)
+        self._check(lib.rebxamd_wh_steps(self._h, ctypes.byref(view), arr, len(ops), float(dt), int(nsteps), mode, self._stream()))
+
     def potentials(self, view, ops):
         """Potential energy of each op (J2, J4, central_force, tides_precession, gr_potential)."""
         arr = (Op * max(len(ops), 1))(*ops)
