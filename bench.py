@@ -93,6 +93,44 @@ def grfull_section(ctx, n, mode=0, dist=None, device="cuda:0"):
                          "frac": flops / dt / 1e12 / peak}}
 
 
+def c5_section(ctx, n, steps, mode, device):
+    """Secondary metric: end-to-end device-resident run -- star + n massless grains, five stacked
+    effects in the kick of a Wisdom-Holman step, particle and parameter columns resident in HBM.
+    Reports the per-step latency with the host waiting for every step (one stream
+    synchronisation per step, as a host-driven integrator would) and with the steps queued."""
+    stack = [("radiation_forces", {"c": C}), ("gravitational_harmonics", {}), ("gr_potential", {"c": C}),
+             ("tides_precession", {}), ("modify_orbits_forces", {})]
+    cols, pp, _ = synthetic.disk(n + 1, 0)
+    host = dict(cols)
+    for k in ("beta", "R_tides", "k1", "tau_a", "tau_e", "tau_inc"):
+        host[k] = pp[k]
+    dp = DeviceParticles.from_host(host, device=device, n_head=1, tail_massless=True)
+    ops = build_ops(stack, {k: v[:1] for k, v in pp.items()})
+    view = dp.view()
+    dt = 2 * np.pi / 100.0
+    ctx.wh_steps(view, ops, dt, 20, mode)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.wh_steps(view, ops, dt, 1, mode)
+        torch.cuda.synchronize()
+    synced = (time.perf_counter() - t0) / steps
+    t0 = time.perf_counter()
+    ctx.wh_steps(view, ops, dt, steps, mode)
+    torch.cuda.synchronize()
+    queued = (time.perf_counter() - t0) / steps
+    x = dp.cols["x"]
+    finite = bool(torch.isfinite(x).all().item())
+    # per queued step: one Kepler drift (neighbouring half drifts merge; pos+vel read and written:
+    # 96 B), the fused force pass (152 B; 128 B with the accelerations written, not accumulated)
+    # and the kick (72 B)
+    bytes_per_step = (96 + 128 + 72) * n
+    return {"n": n, "steps": steps, "effects": 5, "us_per_step_host_synced": synced * 1e6, "us_per_step_queued": queued * 1e6,
+            "particle_steps_per_s": n / queued, "state_finite": finite,
+            "roofline": {"bound": "hbm", "achieved": bytes_per_step / queued / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": bytes_per_step / queued / 1e9 / HBM_PEAK_GBS}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,6 +141,8 @@ def main():
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--grfull-n", type=int, default=65536, help="0 disables the gr_full section")
+    ap.add_argument("--c5-n", type=int, default=1_000_000, help="0 disables the device-resident stepping section")
+    ap.add_argument("--c5-steps", type=int, default=10_000)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -193,6 +233,8 @@ def main():
     if args.grfull_n > 0:
         gr = grfull_section(ctx, args.grfull_n, mode, dist, "cuda:%d" % local_rank)     # collective: every rank takes part
     if rank == 0:
+        if args.c5_n > 0:
+            out["resident_run"] = c5_section(ctx, args.c5_n, args.c5_steps, mode, "cuda:%d" % local_rank)
         if gr is not None:
             out["gr_full"] = gr
         print(json.dumps(out), flush=True)

@@ -354,8 +354,9 @@ int rebxamd_reset_accelerations(rebxamd_ctx* ctx, const rebxamd_view* view, void
  * rebxamd_wh_drift: body 0 drifts linearly, every other body moves on its Kepler orbit about it
  * (mass parameter G*m0) for dt.  rebxamd_wh_steps: nsteps times { drift dt/2; accelerations :=
  * ops (the additional forces alone: the dominant mass is in the drift); v_i += dt*(a_i - a_0);
- * drift dt/2 }, positions and velocities updated in place, asynchronous after one initial read
- * of m0. */
+ * drift dt/2 }, with the two half drifts between consecutive steps merged into one Kepler drift of
+ * dt (the state is synchronised when the call returns, not in between).  Positions and velocities
+ * are updated in place; asynchronous after one initial read of m0. */
 int rebxamd_wh_drift(rebxamd_ctx* ctx, const rebxamd_view* view, double dt, int mode, void* stream);
 int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, double dt, int64_t nsteps,
                      int mode, void* stream);

@@ -554,8 +554,10 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
     double* const x[3] = {const_cast<double*>(view->x), const_cast<double*>(view->y), const_cast<double*>(view->z)};
     double* const v[3] = {const_cast<double*>(view->vx), const_cast<double*>(view->vy), const_cast<double*>(view->vz)};
     const double* const a[3] = {view->ax, view->ay, view->az};
+    // consecutive half drifts of neighbouring steps are one Kepler drift of a whole step (the
+    // flow of the two-body problem composes exactly); only the ends of the run are half steps
+    HIP_TRY(launch_wh_drift(x, v, mu, 0.5 * dt, view->n, ctx->star, exact, st));
     for (int64_t k = 0; k < nsteps; k++) {
-        HIP_TRY(launch_wh_drift(x, v, mu, 0.5 * dt, view->n, ctx->star, exact, st));
         rc = rebxamd_reset_accelerations(ctx, view, stream);
         if (rc != REBXAMD_OK) return rc;
         if (nops > 0) {
@@ -563,7 +565,7 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
             if (rc != REBXAMD_OK) return rc;
         }
         HIP_TRY(launch_wh_kick(v, a, dt, view->n, exact, st));
-        HIP_TRY(launch_wh_drift(x, v, mu, 0.5 * dt, view->n, ctx->star, exact, st));
+        HIP_TRY(launch_wh_drift(x, v, mu, k + 1 < nsteps ? dt : 0.5 * dt, view->n, ctx->star, exact, st));
     }
     return REBXAMD_OK;
 }

@@ -4,6 +4,7 @@
 // All are HBM-bound one-pass kernels over column triples.  EXACT keeps the reference's
 // expression order without FMA contraction (bitwise equal to a non-FMA CPU build).
 #include "internal.h"
+#include "effects.h"
 
 namespace rebxamd {
 
@@ -136,36 +137,37 @@ __global__ __launch_bounds__(1024) void im_sum_kernel(const double* partials, lo
 // body i >= 1 is propagated on a Kepler orbit about body 0 with mass parameter G*m0 (universal
 // variables, Stumpff series), and body 0 drifts linearly.
 
+// c_n(z) = sum_k (-z)^k / (2k+n)!  for n = 0..3: series after quartering the argument until
+// |z| <= 0.1 (nine terms leave < 1e-23), then the duplication formulas.
+#define REBXAMD_STUMPFF_BODY                                                                         \
+    c3 = 1. / 121645100408832000.; c2 = 1. / 6402373705728000.;                                      \
+    c3 = 1. / 355687428096000. - z * c3; c2 = 1. / 20922789888000. - z * c2;                         \
+    c3 = 1. / 1307674368000. - z * c3;   c2 = 1. / 87178291200. - z * c2;                            \
+    c3 = 1. / 6227020800. - z * c3;      c2 = 1. / 479001600. - z * c2;                              \
+    c3 = 1. / 39916800. - z * c3;        c2 = 1. / 3628800. - z * c2;                                \
+    c3 = 1. / 362880. - z * c3;          c2 = 1. / 40320. - z * c2;                                  \
+    c3 = 1. / 5040. - z * c3;            c2 = 1. / 720. - z * c2;                                    \
+    c3 = 1. / 120. - z * c3;             c2 = 1. / 24. - z * c2;                                     \
+    c3 = 1. / 6. - z * c3;               c2 = 1. / 2. - z * c2;                                      \
+    c1 = 1. - z * c3; c0 = 1. - z * c2;                                                              \
+    for (; n > 0; n--) {                                                                             \
+        z *= 4.;                                                                                     \
+        c3 = 0.25 * (c2 + c0 * c3);                                                                  \
+        c2 = 0.5 * c1 * c1;                                                                          \
+        c1 = c0 * c1;                                                                                \
+        c0 = 2. * c0 * c0 - 1.;                                                                      \
+    }
+
 template <bool EXACT>
 __device__ __forceinline__ void stumpff_dev(double z, double (&c)[4]) {
     int n = 0;
     while (fabs(z) > 0.1) { z *= 0.25; n++; }
-    const double a3[9] = {1. / 6., 1. / 120., 1. / 5040., 1. / 362880., 1. / 39916800., 1. / 6227020800., 1. / 1307674368000.,
-                          1. / 355687428096000., 1. / 121645100408832000.};
-    const double a2[9] = {1. / 2., 1. / 24., 1. / 720., 1. / 40320., 1. / 3628800., 1. / 479001600., 1. / 87178291200.,
-                          1. / 20922789888000., 1. / 6402373705728000.};
-    double c3 = 0., c2 = 0., c1, c0;
+    double c3, c2, c1, c0;
     if (EXACT) {
 #pragma clang fp contract(off)
-        for (int k = 8; k >= 0; k--) { c3 = a3[k] - z * c3; c2 = a2[k] - z * c2; }
-        c1 = 1. - z * c3; c0 = 1. - z * c2;
-        for (; n > 0; n--) {
-            z *= 4.;
-            c3 = 0.25 * (c2 + c0 * c3);
-            c2 = 0.5 * c1 * c1;
-            c1 = c0 * c1;
-            c0 = 2. * c0 * c0 - 1.;
-        }
+        REBXAMD_STUMPFF_BODY
     } else {
-        for (int k = 8; k >= 0; k--) { c3 = a3[k] - z * c3; c2 = a2[k] - z * c2; }
-        c1 = 1. - z * c3; c0 = 1. - z * c2;
-        for (; n > 0; n--) {
-            z *= 4.;
-            c3 = 0.25 * (c2 + c0 * c3);
-            c2 = 0.5 * c1 * c1;
-            c1 = c0 * c1;
-            c0 = 2. * c0 * c0 - 1.;
-        }
+        REBXAMD_STUMPFF_BODY
     }
     c[0] = c0; c[1] = c1; c[2] = c2; c[3] = c3;
 }
@@ -183,64 +185,84 @@ __device__ __forceinline__ void gfuncs_dev(double beta, double X, double (&G)[4]
     }
 }
 
-// two-body propagation of the relative state (x, v) about mass parameter M over dt
-template <bool EXACT>
-__device__ __forceinline__ void kepler_dev(double (&q)[6], double M, double dt) {
-    const double x0 = q[0], y0 = q[1], z0 = q[2], vx0 = q[3], vy0 = q[4], vz0 = q[5];
-    double r0, r0i, beta, eta0, zeta0, X;
-    if (EXACT) {
+// two-body propagation of the relative state (x, v) about mass parameter M over dt.
+// Reference-order arithmetic: Newton on the universal Kepler equation from the second-order
+// guess, IEEE division and square root, iterated to a fixed point (the checker's algorithm).
+__device__ __forceinline__ void kepler_exact(double (&q)[6], double M, double dt) {
 #pragma clang fp contract(off)
-        r0 = sqrt(x0 * x0 + y0 * y0 + z0 * z0);
-        r0i = 1. / r0;
-        const double v2 = vx0 * vx0 + vy0 * vy0 + vz0 * vz0;
-        beta = 2. * M * r0i - v2;
-        eta0 = x0 * vx0 + y0 * vy0 + z0 * vz0;
-        zeta0 = M - beta * r0;
-        X = dt * r0i * (1. - 0.5 * dt * eta0 * r0i * r0i);
-    } else {
-        r0 = sqrt(x0 * x0 + y0 * y0 + z0 * z0);
-        r0i = 1. / r0;
-        const double v2 = vx0 * vx0 + vy0 * vy0 + vz0 * vz0;
-        beta = 2. * M * r0i - v2;
-        eta0 = x0 * vx0 + y0 * vy0 + z0 * vz0;
-        zeta0 = M - beta * r0;
-        X = dt * r0i * (1. - 0.5 * dt * eta0 * r0i * r0i);
-    }
+    const double x0 = q[0], y0 = q[1], z0 = q[2], vx0 = q[3], vy0 = q[4], vz0 = q[5];
+    const double r0 = sqrt(x0 * x0 + y0 * y0 + z0 * z0);
+    const double r0i = 1. / r0;
+    const double v2 = vx0 * vx0 + vy0 * vy0 + vz0 * vz0;
+    const double beta = 2. * M * r0i - v2;
+    const double eta0 = x0 * vx0 + y0 * vy0 + z0 * vz0;
+    const double zeta0 = M - beta * r0;
+    double X = dt * r0i * (1. - 0.5 * dt * eta0 * r0i * r0i);
     double G[4];
     double lo = -HUGE_VAL, hi = HUGE_VAL, prev1 = __builtin_nan(""), prev2 = __builtin_nan("");
     for (int it = 0; it < 60; it++) {
-        gfuncs_dev<EXACT>(beta, X, G);
-        double s, sp, Xn;
-        if (EXACT) {
-#pragma clang fp contract(off)
-            s = r0 * X + eta0 * G[2] + zeta0 * G[3] - dt;
-            sp = r0 + eta0 * G[1] + zeta0 * G[2];
-            Xn = X - s / sp;
-        } else {
-            s = r0 * X + eta0 * G[2] + zeta0 * G[3] - dt;
-            sp = r0 + eta0 * G[1] + zeta0 * G[2];
-            Xn = X - s / sp;
-        }
+        gfuncs_dev<true>(beta, X, G);
+        const double s = r0 * X + eta0 * G[2] + zeta0 * G[3] - dt;
+        const double sp = r0 + eta0 * G[1] + zeta0 * G[2];
+        double Xn = X - s / sp;
         if (s > 0.) hi = X; else lo = X;
         if (!(Xn > lo && Xn < hi)) Xn = (isfinite(lo) && isfinite(hi)) ? 0.5 * (lo + hi) : Xn;
         if (Xn == X || Xn == prev1 || Xn == prev2) { X = Xn; break; }
         prev2 = prev1; prev1 = X; X = Xn;
     }
-    gfuncs_dev<EXACT>(beta, X, G);
-    if (EXACT) {
-#pragma clang fp contract(off)
-        const double r = r0 + eta0 * G[1] + zeta0 * G[2];
-        const double ri = 1. / r;
-        const double fm1 = -M * G[2] * r0i, g = dt - M * G[3], fd = -M * G[1] * r0i * ri, gdm1 = -M * G[2] * ri;
-        q[0] += fm1 * x0 + g * vx0; q[1] += fm1 * y0 + g * vy0; q[2] += fm1 * z0 + g * vz0;
-        q[3] += fd * x0 + gdm1 * vx0; q[4] += fd * y0 + gdm1 * vy0; q[5] += fd * z0 + gdm1 * vz0;
-    } else {
-        const double r = r0 + eta0 * G[1] + zeta0 * G[2];
-        const double ri = 1. / r;
-        const double fm1 = -M * G[2] * r0i, g = dt - M * G[3], fd = -M * G[1] * r0i * ri, gdm1 = -M * G[2] * ri;
-        q[0] += fm1 * x0 + g * vx0; q[1] += fm1 * y0 + g * vy0; q[2] += fm1 * z0 + g * vz0;
-        q[3] += fd * x0 + gdm1 * vx0; q[4] += fd * y0 + gdm1 * vy0; q[5] += fd * z0 + gdm1 * vz0;
+    gfuncs_dev<true>(beta, X, G);
+    const double r = r0 + eta0 * G[1] + zeta0 * G[2];
+    const double ri = 1. / r;
+    const double fm1 = -M * G[2] * r0i, g = dt - M * G[3], fd = -M * G[1] * r0i * ri, gdm1 = -M * G[2] * ri;
+    q[0] += fm1 * x0 + g * vx0; q[1] += fm1 * y0 + g * vy0; q[2] += fm1 * z0 + g * vz0;
+    q[3] += fd * x0 + gdm1 * vx0; q[4] += fd * y0 + gdm1 * vy0; q[5] += fd * z0 + gdm1 * vz0;
+}
+
+// Default arithmetic: refined hardware reciprocals, third-order starting guess and Halley's
+// method (cubic convergence): a step shorter than 1e-6 of X leaves an error below rounding, so
+// the usual cost is two evaluations of the G functions plus the final one.  The bracket of the
+// root (the residual is monotonic in X: its derivative is r > 0) guards every step.
+__device__ __forceinline__ void kepler_fast(double (&q)[6], double M, double dt) {
+    const double x0 = q[0], y0 = q[1], z0 = q[2], vx0 = q[3], vy0 = q[4], vz0 = q[5];
+    const double r2 = x0 * x0 + y0 * y0 + z0 * z0;
+    const double r0i = fast_rsqrt(r2);
+    const double r0 = r2 * r0i;
+    const double v2 = vx0 * vx0 + vy0 * vy0 + vz0 * vz0;
+    const double beta = 2. * M * r0i - v2;
+    const double eta0 = x0 * vx0 + y0 * vy0 + z0 * vz0;
+    const double zeta0 = M - beta * r0;
+    // series inversion of r0 X + eta0 X^2/2 + zeta0 X^3/6 = dt
+    const double u = dt * r0i, a = 0.5 * eta0 * r0i, b = zeta0 * r0i * (1. / 6.);
+    double X = u * (1. - u * (a - u * (2. * a * a - b)));
+    double G[4];
+    double lo = -HUGE_VAL, hi = HUGE_VAL, prev = __builtin_nan("");
+    for (int it = 0; it < 60; it++) {
+        gfuncs_dev<false>(beta, X, G);
+        const double s = r0 * X + eta0 * G[2] + zeta0 * G[3] - dt;
+        const double sp = r0 + eta0 * G[1] + zeta0 * G[2];
+        const double spp = eta0 * G[0] + zeta0 * G[1];
+        if (s > 0.) hi = X; else lo = X;
+        // Halley: dX = -s / (s' - s s'' / (2 s'))
+        const double spi = fast_rcp(sp);
+        const double dX = -s * fast_rcp(sp - 0.5 * s * spp * spi);
+        double Xn = X + dX;
+        const bool inside = Xn > lo && Xn < hi;
+        if (!inside) Xn = (isfinite(lo) && isfinite(hi)) ? 0.5 * (lo + hi) : X - s * spi;
+        const bool done = (inside && fabs(dX) <= 1e-6 * fabs(Xn)) || Xn == X || Xn == prev;
+        prev = X; X = Xn;
+        if (done) break;
     }
+    gfuncs_dev<false>(beta, X, G);
+    const double r = r0 + eta0 * G[1] + zeta0 * G[2];
+    const double ri = fast_rcp(r);
+    const double fm1 = -M * G[2] * r0i, g = dt - M * G[3], fd = -M * G[1] * r0i * ri, gdm1 = -M * G[2] * ri;
+    q[0] += fm1 * x0 + g * vx0; q[1] += fm1 * y0 + g * vy0; q[2] += fm1 * z0 + g * vz0;
+    q[3] += fd * x0 + gdm1 * vx0; q[4] += fd * y0 + gdm1 * vy0; q[5] += fd * z0 + gdm1 * vz0;
+}
+
+template <bool EXACT>
+__device__ __forceinline__ void kepler_dev(double (&q)[6], double M, double dt) {
+    if (EXACT) kepler_exact(q, M, dt); else kepler_fast(q, M, dt);
 }
 
 // star[0..5] <- state of body 0 before the drift; body 0 drifts linearly; star[6..8] <- its new position
