@@ -46,70 +46,90 @@ __device__ __forceinline__ double rsq_refined(double x) {
     return fma(y * e, fma(0.375, e, 0.5), y);
 }
 
-// One 256-body tile against this thread's row.  DIAG: the tile contains the row itself, so the
-// self pair has to be masked (only one tile per row block pays for the compare).
-template <int PASS, bool DIAG>
-__device__ __forceinline__ void grfull_tile(const TileA* __restrict__ ta, const TileB* __restrict__ tb, int self,
-                                            double xi, double yi, double zi, double vxi, double vyi, double vzi, double vi2, double p4,
-                                            double& s0, double& s1, double& s2) {
+// State of one row i while it sweeps over the bodies j.
+struct Row {
+    double xi, yi, zi, vxi, vyi, vzi, p4;
+    double s0, s1, s2;
+    int self;           // index of the row inside the current tile, -1 if it is not in it
+};
+
+// One 256-body tile against this thread's R rows: every body fetched from LDS is used R times.
+// DIAG: the tile contains rows of this workgroup, so the self pair has to be masked (only the
+// tiles that overlap the workgroup's own rows pay for the compare).
+// sweep: the tile holds B = 3.5 (a_newton_j + a_old_j):  term = G m_j/r ( (d.B) d /(7 r^2) + B )
+template <int PASS, bool DIAG, int R>
+__device__ __forceinline__ void grfull_tile(const TileA* __restrict__ ta, const TileB* __restrict__ tb, Row (&row)[R]) {
 #pragma unroll 4
     for (int jj = 0; jj < GB; jj++) {
         const TileA A = ta[jj];
-        const double dx = xi - A.x, dy = yi - A.y, dz = zi - A.z;
-        double r2 = dx * dx + dy * dy + dz * dz;
-        double gm = A.gm;
-        if (DIAG && jj == self) { gm = 0.; r2 = 1.; }
-        const double ri = rsq_refined(r2);
-        if (PASS == PASS_POT) {
-            s0 = fma(gm, ri, s0);
-        } else if (PASS == PASS_CONST) {
-            // B = (v_j, phi_j - 2 v_j^2); ci = 4 phi_i - v_i^2 (passed in p4)
-            const TileB B = tb[jj];
-            const double ri2 = ri * ri;
-            const double g3 = gm * ri2 * ri;
-            const double vivj = vxi * B.a + vyi * B.b + vzi * B.c;
-            const double dvj = dx * B.a + dy * B.b + dz * B.c;
-            const double dvi = dx * vxi + dy * vyi + dz * vzi;
-            const double f1 = fma(1.5 * ri2, dvj * dvj, fma(4., vivj, p4 + B.d));
-            const double f2 = fma(4., dvi, -3. * dvj);
-            s0 = fma(g3, fma(f1, dx, f2 * (vxi - B.a)), s0);
-            s1 = fma(g3, fma(f1, dy, f2 * (vyi - B.b)), s1);
-            s2 = fma(g3, fma(f1, dz, f2 * (vzi - B.c)), s2);
-        } else {
-            // B = 3.5 (a_newton_j + a_old_j); term = G m_j/r ( (d.B) d /(7 r^2) + B )
-            const TileB B = tb[jj];
-            const double h = (ri * ri) * ((dx * B.a + dy * B.b + dz * B.c) * (1. / 7.));
-            const double g1 = gm * ri;
-            s0 = fma(g1, fma(h, dx, B.a), s0);
-            s1 = fma(g1, fma(h, dy, B.b), s1);
-            s2 = fma(g1, fma(h, dz, B.c), s2);
+        TileB B;
+        if (PASS != PASS_POT) B = tb[jj];
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            Row& w = row[q];
+            const double dx = w.xi - A.x, dy = w.yi - A.y, dz = w.zi - A.z;
+            double r2 = dx * dx + dy * dy + dz * dz;
+            double gm = A.gm;
+            if (DIAG && jj == w.self) { gm = 0.; r2 = 1.; }
+            const double ri = rsq_refined(r2);
+            if (PASS == PASS_POT) {
+                w.s0 = fma(gm, ri, w.s0);
+            } else if (PASS == PASS_CONST) {
+                // B = (v_j, phi_j - 2 v_j^2); p4 = 4 phi_i - v_i^2
+                const double ri2 = ri * ri;
+                const double g3 = gm * ri2 * ri;
+                const double vivj = w.vxi * B.a + w.vyi * B.b + w.vzi * B.c;
+                const double dvj = dx * B.a + dy * B.b + dz * B.c;
+                const double dvi = dx * w.vxi + dy * w.vyi + dz * w.vzi;
+                const double f1 = fma(1.5 * ri2, dvj * dvj, fma(4., vivj, w.p4 + B.d));
+                const double f2 = fma(4., dvi, -3. * dvj);
+                w.s0 = fma(g3, fma(f1, dx, f2 * (w.vxi - B.a)), w.s0);
+                w.s1 = fma(g3, fma(f1, dy, f2 * (w.vyi - B.b)), w.s1);
+                w.s2 = fma(g3, fma(f1, dz, f2 * (w.vzi - B.c)), w.s2);
+            } else {
+                const double h = (ri * ri) * ((dx * B.a + dy * B.b + dz * B.c) * (1. / 7.));
+                const double g1 = gm * ri;
+                w.s0 = fma(g1, fma(h, dx, B.a), w.s0);
+                w.s1 = fma(g1, fma(h, dy, B.b), w.s1);
+                w.s2 = fma(g1, fma(h, dz, B.c), w.s2);
+            }
         }
     }
 }
 
-template <int PASS>
+// Workgroup = 256 threads, GB*R rows: thread t owns rows t, t + 256, ... of the workgroup's block.
+template <int PASS, int R>
 __global__ __launch_bounds__(GB) void grfull_fast_kernel(GrFullArgs a) {
     __shared__ TileA ta[GB];
     __shared__ TileB tb[GB];
     const int tid = threadIdx.x;
     const long long nrows = a.row1 - a.row0;
-    const long long r = (long long)blockIdx.x * GB + tid;
-    const long long i = a.row0 + r;
-    const bool live = r < nrows;
     const long long j0 = (long long)blockIdx.y * a.jchunk;
     long long j1 = j0 + a.jchunk; if (j1 > a.n) j1 = a.n;
-    const long long blk_lo = a.row0 + (long long)blockIdx.x * GB, blk_hi = blk_lo + GB;   // rows of this workgroup
+    const long long blk_lo = a.row0 + (long long)blockIdx.x * (GB * R), blk_hi = blk_lo + GB * R;   // rows of this workgroup
 
-    double xi = 0., yi = 0., zi = 0., vxi = 0., vyi = 0., vzi = 0., vi2 = 0., p4 = 0.;
-    if (live) {
-        xi = a.x[i]; yi = a.y[i]; zi = a.z[i];
-        if (PASS == PASS_CONST) {
-            vxi = a.vx[i]; vyi = a.vy[i]; vzi = a.vz[i];
-            vi2 = vxi * vxi + vyi * vyi + vzi * vzi;
-            p4 = 4. * a.pot[i] * a.C2 - vi2;    // work in units where 1/c^2 is applied once at the end
+    Row row[R];
+    long long ri_[R];
+    bool live[R];
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+        const long long r = (long long)blockIdx.x * (GB * R) + q * GB + tid;
+        ri_[q] = r;
+        live[q] = r < nrows;
+        Row& w = row[q];
+        w.xi = w.yi = w.zi = w.vxi = w.vyi = w.vzi = w.p4 = 0.;
+        w.s0 = w.s1 = w.s2 = 0.;
+        w.self = -1;
+        if (live[q]) {
+            const long long i = a.row0 + r;
+            w.xi = a.x[i]; w.yi = a.y[i]; w.zi = a.z[i];
+            if (PASS == PASS_CONST) {
+                w.vxi = a.vx[i]; w.vyi = a.vy[i]; w.vzi = a.vz[i];
+                const double vi2 = w.vxi * w.vxi + w.vyi * w.vyi + w.vzi * w.vzi;
+                w.p4 = 4. * a.pot[i] * a.C2 - vi2;      // work in units where 1/c^2 is applied once at the end
+            }
         }
     }
-    double s0 = 0., s1 = 0., s2 = 0.;
 
     for (long long jt = j0; jt < j1; jt += GB) {
         const long long j = jt + tid;
@@ -134,18 +154,25 @@ __global__ __launch_bounds__(GB) void grfull_fast_kernel(GrFullArgs a) {
         }
         __syncthreads();
         if (jt < blk_hi && jt + GB > blk_lo) {      // workgroup-uniform: this tile overlaps our own rows
-            const int self = (live && i >= jt && i < jt + GB) ? (int)(i - jt) : -1;
-            grfull_tile<PASS, true>(ta, tb, self, xi, yi, zi, vxi, vyi, vzi, vi2, p4, s0, s1, s2);
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const long long i = a.row0 + ri_[q];
+                row[q].self = (live[q] && i >= jt && i < jt + GB) ? (int)(i - jt) : -1;
+            }
+            grfull_tile<PASS, true, R>(ta, tb, row);
         } else {
-            grfull_tile<PASS, false>(ta, tb, -1, xi, yi, zi, vxi, vyi, vzi, vi2, p4, s0, s1, s2);
+            grfull_tile<PASS, false, R>(ta, tb, row);
         }
     }
-    if (live) {
+    const double scale = a.invC2;
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+        if (!live[q]) continue;
         if (PASS == PASS_POT) {
-            a.part[(long long)blockIdx.y * nrows + r] = s0 * a.invC2;
+            a.part[(long long)blockIdx.y * nrows + ri_[q]] = row[q].s0 * scale;
         } else {
-            double* q = a.part + ((long long)blockIdx.y * nrows + r) * 3;
-            q[0] = s0 * a.invC2; q[1] = s1 * a.invC2; q[2] = s2 * a.invC2;
+            double* o = a.part + ((long long)blockIdx.y * nrows + ri_[q]) * 3;
+            o[0] = row[q].s0 * scale; o[1] = row[q].s1 * scale; o[2] = row[q].s2 * scale;
         }
     }
 }
@@ -291,11 +318,14 @@ __global__ __launch_bounds__(256) void grfull_finish_kernel(View v, const double
 
 // ------------------------------------------------------------------ launchers
 // scratch for the j-chunk partials is owned by device_api.hip and handed in through `part`
-struct GrFullPlan { int rowblocks; int nchunks; long long jchunk; };
+struct GrFullPlan { int rowblocks; int nchunks; long long jchunk; int rows_per_thread; };
 
 static GrFullPlan plan(long long n, long long nrows) {
     GrFullPlan p;
-    p.rowblocks = (int)((nrows + GB - 1) / GB);
+    // two rows per thread halve the LDS traffic per pair; worth it once there are enough rows to
+    // keep every CU busy with half as many workgroups
+    p.rows_per_thread = nrows >= 8192 ? 2 : 1;
+    p.rowblocks = (int)((nrows + GB * p.rows_per_thread - 1) / (GB * p.rows_per_thread));
     long long want = (2048 + p.rowblocks - 1) / p.rowblocks;     // aim at >= 2048 workgroups (8 per CU)
     const long long tiles = (n + GB - 1) / GB;
     if (want > tiles) want = tiles;
@@ -341,14 +371,18 @@ hipError_t launch_grfull_pass(int pass, const View& v, double G, double c, long 
     a.jchunk = p.jchunk; a.part = part;
     const dim3 g((unsigned)p.rowblocks, (unsigned)p.nchunks), b(GB);
     const dim3 g2((unsigned)((nrows + 255) / 256)), b2(256);
+    const bool two = p.rows_per_thread == 2;
     if (pass == PASS_POT) {
-        hipLaunchKernelGGL(grfull_fast_kernel<PASS_POT>, g, b, 0, st, a);
+        if (two) hipLaunchKernelGGL((grfull_fast_kernel<PASS_POT, 2>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((grfull_fast_kernel<PASS_POT, 1>), g, b, 0, st, a);
         hipLaunchKernelGGL(grfull_combine_kernel<PASS_POT>, g2, b2, 0, st, part, p.nchunks, row0, row1, acx, acy, acz, aox, aoy, aoz, o0, o1, o2, flag);
     } else if (pass == PASS_CONST) {
-        hipLaunchKernelGGL(grfull_fast_kernel<PASS_CONST>, g, b, 0, st, a);
+        if (two) hipLaunchKernelGGL((grfull_fast_kernel<PASS_CONST, 2>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((grfull_fast_kernel<PASS_CONST, 1>), g, b, 0, st, a);
         hipLaunchKernelGGL(grfull_combine_kernel<PASS_CONST>, g2, b2, 0, st, part, p.nchunks, row0, row1, acx, acy, acz, aox, aoy, aoz, o0, o1, o2, flag);
     } else {
-        hipLaunchKernelGGL(grfull_fast_kernel<PASS_SWEEP>, g, b, 0, st, a);
+        if (two) hipLaunchKernelGGL((grfull_fast_kernel<PASS_SWEEP, 2>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((grfull_fast_kernel<PASS_SWEEP, 1>), g, b, 0, st, a);
         hipLaunchKernelGGL(grfull_combine_kernel<PASS_SWEEP>, g2, b2, 0, st, part, p.nchunks, row0, row1, acx, acy, acz, aox, aoy, aoz, o0, o1, o2, flag);
     }
     return hipGetLastError();
