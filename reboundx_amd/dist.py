@@ -80,7 +80,12 @@ class HipGrFullEngine:
 def grfull_sharded(engine, c, gravity_ignore_10=0, group=None):
     """One gr_full evaluation (reference src/gr_full.c:61-231) with rows sharded over the
     ranks of `group`.  Adds the result to the engine's particle accelerations on every rank
-    and returns the number of sweeps run.  With no process group it runs all rows locally."""
+    and returns the number of sweeps run.  With no process group it runs all rows locally.
+
+    Communication per evaluation: one all-gather of the potential sums (8 B per body) and ONE
+    all-gather per sweep that carries the rank's rows of the three new acceleration columns and
+    its "not yet converged" vote in a single message (24 B per body + 8 B): xGMI transfers of this
+    size are latency-bound, so the number of collectives is what matters."""
     import torch.distributed as dist
     use_dist = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if use_dist else 1
@@ -89,34 +94,35 @@ def grfull_sharded(engine, c, gravity_ignore_10=0, group=None):
     r0, r1, per = row_shard(n, world, rank)
     npad = per * world
 
-    def gather_rows(full):
-        """every rank contributes full[rank*per:(rank+1)*per]"""
-        if world == 1:
-            return
-        send = full[rank * per:(rank + 1) * per].clone()
-        dist.all_gather_into_tensor(full, send, group=group)
-
     an = [engine.zeros(npad) for _ in range(3)]
-    ao = [engine.zeros(npad) for _ in range(3)]
-    out = [engine.zeros(npad) for _ in range(3)]
     ac = [engine.zeros(npad) for _ in range(3)]
+    ao3, out3 = engine.zeros(3, npad), engine.zeros(3, npad)       # rows of one tensor, so that one copy packs them
     pot = engine.zeros(npad)
     flag = engine.flag()
-    engine.newton(gravity_ignore_10, an, ao)        # replicated: every rank holds the full incoming field
+    if world > 1:
+        send = engine.zeros(3 * per + 1)
+        recv_flat = engine.zeros(world * (3 * per + 1))
+        recv = recv_flat.view(world, 3 * per + 1)
+    engine.newton(gravity_ignore_10, an, [ao3[0], ao3[1], ao3[2]])   # replicated: every rank holds the full incoming field
     engine.pot(c, r0, r1, pot)
-    gather_rows(pot)
+    if world > 1:
+        dist.all_gather_into_tensor(pot, pot[rank * per:(rank + 1) * per].clone(), group=group)
     engine.const(c, r0, r1, pot, ac)
     sweeps = 0
     for k in range(10):                             # reference loop bound (gr_full.c:173)
         sweeps = k + 1
         flag.zero_()
-        engine.sweep(c, r0, r1, an, ao, ac, out, flag)
-        for comp in out:
-            gather_rows(comp)
+        engine.sweep(c, r0, r1, an, [ao3[0], ao3[1], ao3[2]], ac, [out3[0], out3[1], out3[2]], flag)
         if world > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-        ao, out = out, ao
-        if int(flag.item()) == 0:
+            send[:3 * per].view(3, per).copy_(out3.view(3, world, per)[:, rank, :])
+            send[3 * per:].copy_(flag)
+            dist.all_gather_into_tensor(recv_flat, send, group=group)
+            out3.view(3, world, per).copy_(recv[:, :3 * per].view(world, 3, per).permute(1, 0, 2))
+            unconverged = float(recv[:, 3 * per].max().item()) != 0.0
+        else:
+            unconverged = int(flag.item()) != 0
+        ao3, out3 = out3, ao3
+        if not unconverged:
             break
-    engine.finish(ao)
+    engine.finish([ao3[0], ao3[1], ao3[2]])
     return sweeps
