@@ -894,3 +894,171 @@ void orc_newtonian_gravity(const orc_sim* s) {
     }
     free(massive);
 }
+
+/* ------------------------------------------------------------------------
+ * Operators modify_mass (src/modify_mass.c:63-73) and modify_orbits_direct
+ * (src/modify_orbits_direct.c:81-132 through rebxtools_com_ptm, src/rebxtools.c:137-215).
+ * They call REBOUND for the centre-of-mass shift and the orbit <-> Cartesian conversions
+ * (reb_move_to_com, reb_tools_particle_to_orbit_err, reb_tools_orbit_to_particle), restated
+ * here from REBOUND 3.x's published algorithm (Murray & Dermott eqs. 2.122, 2.36) and pinned by
+ * replaying the reference's archives modify_mass.sa / modify_orbits_direct.sa.
+ * ---------------------------------------------------------------------- */
+
+static void scatter_state(const orc_sim* s, const body* p) {
+    for (int i = 0; i < s->N; i++) {
+        s->x[i] = p[i].x; s->y[i] = p[i].y; s->z[i] = p[i].z;
+        s->vx[i] = p[i].vx; s->vy[i] = p[i].vy; s->vz[i] = p[i].vz;
+        s->m[i] = p[i].m;
+    }
+}
+
+/* modify_mass.c:63-73 followed by reb_move_to_com */
+void orc_modify_mass(const orc_sim* s, const double* tau_mass, double dt) {
+    const int N = s->N;
+    if (N <= 0) return;
+    body* p = gather(s);
+    for (int i = 0; i < N; i++)
+        if (has(tau_mass, i)) p[i].m += p[i].m * dt / tau_mass[i];
+    const body com = com_of_all(p, N);
+    for (int i = 0; i < N; i++) {
+        p[i].x -= com.x; p[i].y -= com.y; p[i].z -= com.z;
+        p[i].vx -= com.vx; p[i].vy -= com.vy; p[i].vz -= com.vz;
+    }
+    scatter_state(s, p);
+    free(p);
+}
+
+typedef struct { double d, a, e, inc, Omega, omega, f; } orbit;
+
+/* angle in [-pi, pi] from its cosine num/denom and the sign of `disambiguator` */
+static double acos2(double num, double denom, double disambiguator) {
+    const double cosine = num / denom;
+    if (cosine > -1. && cosine < 1.) {
+        const double val = acos(cosine);
+        return disambiguator < 0. ? -val : val;
+    }
+    return (cosine <= -1.) ? ORC_PI : 0.;
+}
+
+/* reb_tools_particle_to_orbit_err: returns nonzero when the orbit is undefined */
+static int particle_to_orbit(double G, body p, body primary, orbit* o) {
+    const double TINY = 1.E-308, MIN_INC = 1.e-8;
+    if (primary.m <= TINY) return 1;
+    const double mu = G * (p.m + primary.m);
+    const double dx = p.x - primary.x, dy = p.y - primary.y, dz = p.z - primary.z;
+    const double dvx = p.vx - primary.vx, dvy = p.vy - primary.vy, dvz = p.vz - primary.vz;
+    o->d = sqrt(dx * dx + dy * dy + dz * dz);
+    const double vsquared = dvx * dvx + dvy * dvy + dvz * dvz;
+    const double vcircsquared = mu / o->d;
+    o->a = -mu / (vsquared - 2. * vcircsquared);
+    const double hx = (dy * dvz - dz * dvy), hy = (dz * dvx - dx * dvz), hz = (dx * dvy - dy * dvx);
+    const double h = sqrt(hx * hx + hy * hy + hz * hz);
+    const double vdiffsquared = vsquared - vcircsquared;
+    if (o->d <= TINY) return 2;
+    const double vr = (dx * dvx + dy * dvy + dz * dvz) / o->d;
+    const double rvr = o->d * vr;
+    const double muinv = 1. / mu;
+    const double ex = muinv * (vdiffsquared * dx - rvr * dvx);
+    const double ey = muinv * (vdiffsquared * dy - rvr * dvy);
+    const double ez = muinv * (vdiffsquared * dz - rvr * dvz);
+    o->e = sqrt(ex * ex + ey * ey + ez * ez);
+    o->inc = acos2(hz, h, 1.);
+    const double nx = -hy, ny = hx;
+    const double n = sqrt(nx * nx + ny * ny);
+    o->Omega = acos2(nx, n, ny);
+    if (o->inc < MIN_INC || o->inc > ORC_PI - MIN_INC) {
+        /* nearly planar: longitudes are well defined, node-referenced angles are not */
+        const double theta = acos2(dx, o->d, dy);
+        const double pomega = acos2(ex, o->e, ey);
+        if (o->inc < ORC_PI / 2.) { o->omega = pomega - o->Omega; o->f = theta - pomega; }
+        else { o->omega = o->Omega - pomega; o->f = pomega - theta; }
+    } else {
+        const double wpf = acos2(nx * dx + ny * dy, n * o->d, dz);
+        o->omega = acos2(nx * ex + ny * ey, n * o->e, ez);
+        o->f = wpf - o->omega;
+    }
+    return 0;
+}
+
+/* reb_tools_orbit_to_particle: Murray & Dermott eq. 2.122 (positions), 2.36 rotated (velocities) */
+static body orbit_to_particle(double G, body primary, double m, double a, double e, double inc, double Omega, double omega, double f) {
+    body p;
+    memset(&p, 0, sizeof(p));
+    p.m = m;
+    const double r = a * (1 - e * e) / (1 + e * cos(f));
+    const double v0 = sqrt(G * (m + primary.m) / a / (1. - e * e));
+    const double cO = cos(Omega), sO = sin(Omega), co = cos(omega), so = sin(omega), cf = cos(f), sf = sin(f), ci = cos(inc), si = sin(inc);
+    p.x = primary.x + r * (cO * (co * cf - so * sf) - sO * (so * cf + co * sf) * ci);
+    p.y = primary.y + r * (sO * (co * cf - so * sf) + cO * (so * cf + co * sf) * ci);
+    p.z = primary.z + r * (so * cf + co * sf) * si;
+    p.vx = primary.vx + v0 * ((e + cf) * (-ci * co * sO - cO * so) - sf * (co * cO - ci * so * sO));
+    p.vy = primary.vy + v0 * ((e + cf) * (ci * co * cO - sO * so) - sf * (co * sO + ci * so * cO));
+    p.vz = primary.vz + v0 * ((e + cf) * co * si - sf * si * so);
+    return p;
+}
+
+/* modify_orbits_direct.c:81-119: one body's new state relative to `primary` */
+static body mod_direct_step(double G, body p, body primary, double dt, double p_param, int has_p,
+                            const double* tau_a, const double* tau_e, const double* tau_inc, const double* tau_omega, const double* tau_Omega, int i) {
+    orbit o;
+    if (particle_to_orbit(G, p, primary, &o)) return p;
+    const double a0 = o.a, e0 = o.e, inc0 = o.inc;
+    if (has(tau_a, i)) o.a += a0 * dt / tau_a[i];
+    if (has(tau_e, i)) o.e += e0 * dt / tau_e[i];
+    if (has(tau_inc, i)) o.inc += inc0 * dt / tau_inc[i];
+    if (has(tau_omega, i)) o.omega += 2. * ORC_PI * dt / tau_omega[i];
+    if (has(tau_Omega, i)) o.Omega += 2. * ORC_PI * dt / tau_Omega[i];
+    if (has(tau_e, i) && has_p) o.a += 2. * a0 * e0 * e0 * p_param * dt / tau_e[i];
+    body out = orbit_to_particle(G, primary, p.m, o.a, o.e, o.inc, o.Omega, o.omega, o.f);
+    out.ax = p.ax; out.ay = p.ay; out.az = p.az;
+    return out;
+}
+
+static void subtract_posvel(body* p, const body* diff, double massratio) {
+    p->x -= massratio * diff->x; p->y -= massratio * diff->y; p->z -= massratio * diff->z;
+    p->vx -= massratio * diff->vx; p->vy -= massratio * diff->vy; p->vz -= massratio * diff->vz;
+}
+
+/* rebxtools_com_ptm (rebxtools.c:137-215) with modify_orbits_direct's step; p_param = NaN when unset */
+int orc_modify_orbits_direct(const orc_sim* s, int coordinates, double p_param, const double* tau_a, const double* tau_e, const double* tau_inc,
+                             const double* tau_omega, const double* tau_Omega, const uint8_t* primary, double dt) {
+    const int N = s->N;
+    if (N <= 0) return 0;
+    body* p = gather(s);
+    body com = com_of_all(p, N);
+    int refindex = -1;
+    if (coordinates == ORC_COORD_JACOBI) refindex = 0;
+    else if (coordinates == ORC_COORD_PARTICLE) {
+        for (int i = 0; i < N; i++) if (flagged(primary, i)) { com = p[i]; refindex = i; break; }
+        if (refindex < 0) { free(p); return -1; }
+    } else if (coordinates != ORC_COORD_BARYCENTRIC) { free(p); return -2; }
+    const int has_p = !isnan(p_param);
+    for (int i = N - 1; i >= 0; i--) {
+        if (i == refindex) continue;
+        if (coordinates == ORC_COORD_JACOBI) com = com_without(com, p[i]);
+        const body mod = mod_direct_step(s->G, p[i], com, dt, p_param, has_p, tau_a, tau_e, tau_inc, tau_omega, tau_Omega, i);
+        body diff;
+        diff.x = mod.x - p[i].x; diff.y = mod.y - p[i].y; diff.z = mod.z - p[i].z;
+        diff.vx = mod.vx - p[i].vx; diff.vy = mod.vy - p[i].vy; diff.vz = mod.vz - p[i].vz;
+        p[i].x = mod.x; p[i].y = mod.y; p[i].z = mod.z; p[i].vx = mod.vx; p[i].vy = mod.vy; p[i].vz = mod.vz;
+        double massratio;
+        switch (coordinates) {
+        case ORC_COORD_BARYCENTRIC:
+            massratio = p[i].m / com.m;
+            for (int j = 0; j < N; j++) subtract_posvel(&p[j], &diff, massratio);
+            break;
+        case ORC_COORD_JACOBI:
+            massratio = p[i].m / (com.m + p[i].m);
+            for (int j = 0; j < i + 1; j++) subtract_posvel(&p[j], &diff, massratio);
+            break;
+        default:
+            massratio = p[i].m / (com.m + p[i].m);
+            subtract_posvel(&p[i], &diff, massratio);
+            subtract_posvel(&p[refindex], &diff, massratio);
+            break;
+        }
+    }
+    scatter_state(s, p);
+    free(p);
+    return 0;
+}

@@ -88,6 +88,13 @@ int orc_integrate_force(orc_sim* s, int integrator, double dt, orc_force_fn f, v
 void orc_drift_step(orc_sim* s, double dt);   /* src/steppers.c:112-121 */
 void orc_kick_step(orc_sim* s, double dt);    /* src/steppers.c:123-133 (acceleration columns as given) */
 
+/* operators: src/modify_mass.c:63-73 (+ reb_move_to_com) and src/modify_orbits_direct.c:81-132 with
+ * src/rebxtools.c:137-215.  They change positions, velocities and masses in place.  p_param = NaN
+ * when the operator's "p" parameter is unset. */
+void orc_modify_mass(const orc_sim* s, const double* tau_mass, double dt);
+int orc_modify_orbits_direct(const orc_sim* s, int coordinates, double p_param, const double* tau_a, const double* tau_e, const double* tau_inc,
+                             const double* tau_omega, const double* tau_Omega, const uint8_t* primary, double dt);
+
 /* Wisdom-Holman steps (Jacobi coordinates, REBOUND's WHFast defaults) used to replay the
  * reference's trajectory archives; see rebx_whfast.c. */
 typedef void (*orc_step_fn)(orc_sim* state, double dt, void* user);

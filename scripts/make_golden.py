@@ -27,7 +27,7 @@ import numpy as np
 REF = "/root/reference"
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 FORCES = ["tides_precession", "gr", "gr_potential", "gr_full", "radiation_forces", "central_force",
-          "gravitational_harmonics", "modify_orbits_forces"]
+          "gravitational_harmonics", "modify_orbits_forces", "modify_mass", "modify_orbits_direct"]
 
 
 def read_sa(path, max_snapshots):

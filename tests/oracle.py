@@ -218,3 +218,21 @@ def whfast_steps(sim, dt, nsteps, forces=None, pp=None, pre=None, post=None):
     f = _FORCE_FN(cb) if forces else _FORCE_FN(0)
     rc = lib.orc_whfast_steps(ctypes.byref(sim.s), float(dt), int(nsteps), f, wrap(pre), wrap(post), None)
     assert rc == 0
+
+
+lib.orc_modify_mass.restype = None
+lib.orc_modify_mass.argtypes = [POINTER(OrcSim), c_void_p, c_double]
+lib.orc_modify_orbits_direct.restype = c_int
+lib.orc_modify_orbits_direct.argtypes = [POINTER(OrcSim), c_int, c_double] + [c_void_p] * 6 + [c_double]
+
+
+def modify_mass(sim, dt, tau_mass=None):
+    a = _col(tau_mass, sim.N)
+    lib.orc_modify_mass(ctypes.byref(sim.s), _d(a), float(dt))
+
+
+def modify_orbits_direct(sim, dt, coordinates=0, p=None, tau_a=None, tau_e=None, tau_inc=None, tau_omega=None, tau_Omega=None, primary=None):
+    cols = [_col(c, sim.N) for c in (tau_a, tau_e, tau_inc, tau_omega, tau_Omega)]
+    f = _flag(primary, sim.N)
+    return lib.orc_modify_orbits_direct(ctypes.byref(sim.s), int(coordinates), float("nan") if p is None else float(p),
+                                        *[_d(c) for c in cols], _d(f), float(dt))

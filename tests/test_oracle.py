@@ -480,3 +480,32 @@ def test_archive_replay_is_sensitive_to_the_force(archives):
     oracle.lib.orc_whfast_steps(ctypes.byref(sim.s), dt, round(t1 / dt), cb, oracle._STEP_FN(0), oracle._STEP_FN(0), None)
     got = np.array([sim.cols[k] for k in ("x", "y", "z", "vx", "vy", "vz")]).T
     assert np.abs(got - ref).max() > 1e-8
+
+
+def test_operator_archives_replay_to_roundoff(archives):
+    """modify_mass.sa and modify_orbits_direct.sa: the operator runs for half a step before and
+    half a step after every Wisdom-Holman step (rebx_add_operator with WHFast, src/core.c:489-496;
+    parameters as stored in tests/golden/rebx/<name>.rebx).  Pins the checker's restatement of the
+    two operators and of the REBOUND routines they lean on (centre-of-mass shift, orbital
+    elements <-> Cartesian) to the reference's stored trajectories."""
+    tau_mass = np.array([-1e4, np.nan, np.nan])
+    pp = _params3(tau_a={1: -1e4}, tau_e={1: -1e3, 2: -1e3}, tau_inc={2: -1e3}, tau_omega={1: 100.})
+    ops = {
+        "modify_mass": lambda v, h: oracle.modify_mass(v, 0.5 * h, tau_mass),
+        "modify_orbits_direct": lambda v, h: oracle.modify_orbits_direct(v, 0.5 * h, 0, None, pp["tau_a"], pp["tau_e"], pp["tau_inc"],
+                                                                         pp["tau_omega"], None, None),
+    }
+    dt = float.fromhex(archives["dt"])
+    for name, op in ops.items():
+        entries = archives["forces"][name]
+        start = np.array([[float.fromhex(v) for v in row] for row in entries[0]["particles"]])
+        ref = np.array([[float.fromhex(v) for v in row] for row in entries[1]["particles"]])
+        cols = {k: start[:, j].copy() for j, k in enumerate(("x", "y", "z", "vx", "vy", "vz", "m"))}
+        for k in ("ax", "ay", "az"):
+            cols[k] = np.zeros(3)
+        sim = oracle.Sim(cols)
+        oracle.whfast_steps(sim, dt, round(float.fromhex(entries[1]["t"]) / dt), None, None, pre=op, post=op)
+        got = np.array([sim.cols[k] for k in ("x", "y", "z", "vx", "vy", "vz", "m")]).T
+        assert np.abs(got - ref).max() <= 1e-9, name
+        assert np.abs(ref[:, :6] - start[:, :6]).max() > 0.1
+    assert abs(ref[0, 6] - 1.0) < 1e-12          # modify_orbits_direct leaves the masses alone
