@@ -361,6 +361,20 @@ int rebxamd_wh_drift(rebxamd_ctx* ctx, const rebxamd_view* view, double dt, int 
 int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, double dt, int64_t nsteps,
                      int mode, void* stream);
 
+/* Operators on device columns.  Positions, velocities (and masses) of `view` are UPDATED IN PLACE.
+ * rebxamd_modify_mass: m_i += m_i*dt/tau_mass_i where tau_mass_i is set (device column, NaN = not
+ * set), then positions and velocities are shifted to the centre-of-mass frame
+ * (src/modify_mass.c:63-73, which ends with reb_move_to_com).
+ * rebxamd_modify_orbits_direct: a, e, inc, omega, Omega of every body's orbit change by
+ * dt/tau_* (view->tau_a/tau_e/tau_inc and the two extra columns, NaN = not set; *p_param = the
+ * operator's "p", NULL = unset) in the given coordinates with the reference's back-reactions
+ * (src/modify_orbits_direct.c:81-132, src/rebxtools.c:137-215).  `primary` = reference particle
+ * for REBX_COORDINATES_PARTICLE.  The massive bodies must be a prefix of at most 64 particles
+ * followed by massless ones (the reference's chain over massive bodies is sequential). */
+int rebxamd_modify_mass(rebxamd_ctx* ctx, const rebxamd_view* view, const double* tau_mass, double dt, void* stream);
+int rebxamd_modify_orbits_direct(rebxamd_ctx* ctx, const rebxamd_view* view, int coordinates, int primary, const double* p_param,
+                                 const double* tau_omega, const double* tau_Omega, double dt, void* stream);
+
 /* Potential energy of each op in `ops` (J2, J4, central_force, tides_precession, gr_potential),
  * summed over the particles of `view`: out[k] (host memory, nops doubles) is what the
  * reference's per-source potential routine returns for op k

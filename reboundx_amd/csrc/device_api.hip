@@ -570,6 +570,38 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
     return REBXAMD_OK;
 }
 
+// ------------------------------------------------------------------ operators
+
+extern "C" int rebxamd_modify_mass(rebxamd_ctx* ctx, const rebxamd_view* view, const double* tau_mass, double dt, void* stream) {
+    const int rc = check_step_view(ctx, view, "rebxamd_modify_mass: bad argument", true, false);
+    if (rc != REBXAMD_OK || view->n == 0) return rc;
+    if (!view->m || !tau_mass) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_modify_mass: mass or tau_mass column missing");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int rc2 = ensure(ctx, &ctx->partials, &ctx->partials_cap, (size_t)operator_partial_doubles(view->n) * sizeof(double), st);
+    if (rc2 != REBXAMD_OK) return rc2;
+    HIP_TRY(launch_modify_mass(make_view(view), tau_mass, dt, ctx->partials, st));
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_modify_orbits_direct(rebxamd_ctx* ctx, const rebxamd_view* view, int coordinates, int primary, const double* p_param,
+                                            const double* tau_omega, const double* tau_Omega, double dt, void* stream) {
+    const int rc = check_step_view(ctx, view, "rebxamd_modify_orbits_direct: bad argument", true, false);
+    if (rc != REBXAMD_OK || view->n == 0) return rc;
+    if (!view->m) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_modify_orbits_direct: mass column missing");
+    if (coordinates != REBX_COORDINATES_JACOBI && coordinates != REBX_COORDINATES_BARYCENTRIC && coordinates != REBX_COORDINATES_PARTICLE)
+        return fail(ctx, REBXAMD_ERR_ARG, "modify_orbits_direct: unknown coordinates");
+    const long long K = view->n_head < view->n ? view->n_head : view->n;
+    if (!((view->tail_massless != 0 || K == view->n) && K >= 1 && K <= REBXAMD_MAX_HEAD))
+        return fail(ctx, REBXAMD_ERR_UNSUPPORTED, "modify_orbits_direct walks the massive bodies sequentially: they must form a prefix of at most 64 particles followed by massless ones");
+    if (coordinates == REBX_COORDINATES_PARTICLE && (primary < 0 || primary >= K))
+        return fail(ctx, REBXAMD_ERR_PARAM, "modify_orbits_direct: PARTICLE coordinates need a primary inside the massive prefix");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(launch_modify_orbits_direct(make_view(view), K, coordinates, primary, p_param ? *p_param : 0., p_param ? 1 : 0, tau_omega, tau_Omega, dt,
+                                        view->G, ctx->star, (hipStream_t)stream));
+    return REBXAMD_OK;
+}
+
 // ------------------------------------------------------------------ potentials
 
 extern "C" int rebxamd_potentials(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, double* out, void* stream) {

@@ -91,6 +91,12 @@ long long im_partial_count(long long n);
 hipError_t launch_im_update(double* const fin[3], const double* const orig[3], double* const avgv[3], double* const avga[3], double dt,
                             long long n, double* partials, double* sums, bool exact, hipStream_t st);
 
+// operators modify_mass and modify_orbits_direct (operator_kernels.hip)
+long long operator_partial_doubles(long long n);
+hipError_t launch_modify_mass(const View& v, const double* tau_mass, double dt, double* ws, hipStream_t st);
+hipError_t launch_modify_orbits_direct(const View& v, long long K, int coordinates, int refindex, double p_param, int has_p,
+                                       const double* tau_omega, const double* tau_Omega, double dt, double G, double* hc16, hipStream_t st);
+
 // potential energies of the position-dependent forces (potential_kernels.hip)
 long long potential_block_count(long long n);
 hipError_t launch_potentials(const View& v, const Program& prog, double* partials, double* out, hipStream_t st);

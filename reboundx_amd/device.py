@@ -79,6 +79,16 @@ class Context:
         arr = (Op * max(len(ops), 1))(*ops)
         self._check(lib.rebxamd_wh_steps(self._h, ctypes.byref(view), arr, len(ops), float(dt), int(nsteps), mode, self._stream()))
 
+    def modify_mass(self, view, tau_mass, dt):
+        """tau_mass: float64 device tensor, NaN = not set.  Masses, positions, velocities change in place."""
+        self._check(lib.rebxamd_modify_mass(self._h, ctypes.byref(view), tau_mass.data_ptr(), float(dt), self._stream()))
+
+    def modify_orbits_direct(self, view, dt, coordinates=0, primary=-1, p=None, tau_omega=None, tau_Omega=None):
+        pp = ctypes.byref(ctypes.c_double(p)) if p is not None else None
+        self._check(lib.rebxamd_modify_orbits_direct(self._h, ctypes.byref(view), int(coordinates), int(primary), pp,
+                                                     tau_omega.data_ptr() if tau_omega is not None else None,
+                                                     tau_Omega.data_ptr() if tau_Omega is not None else None, float(dt), self._stream()))
+
     def potentials(self, view, ops):
         """Potential energy of each op (J2, J4, central_force, tides_precession, gr_potential)."""
         arr = (Op * max(len(ops), 1))(*ops)
