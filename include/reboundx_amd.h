@@ -194,9 +194,10 @@ double rebx_gr_hamiltonian(struct rebx_extras* const rebx, const struct rebx_for
 
 /* Operators on the additional-force path: the "integrate a force across a timestep" operator and
  * the kick/drift steppers.  src/reboundx.h:331, :329, :327, :280; src/core.c:279-368, :411-510,
- * :637-648, :697-728.  rebx_load_operator knows "integrate_force", "kick" and "drift"; the
- * reference's other operators (modify_mass, modify_orbits_direct, track_min_distance, kepler,
- * jump, interaction, ias15) are not part of this library and report "not found". */
+ * :637-648, :697-728.  rebx_load_operator knows "integrate_force", "kick", "drift", "modify_mass" and
+ * "modify_orbits_direct"; the reference's other operators (track_min_distance, and kepler, jump,
+ * interaction, ias15, which wrap REBOUND internals) are not part of this library and report
+ * "not found". */
 struct rebx_operator* rebx_create_operator(struct rebx_extras* const rebx, const char* name);
 struct rebx_operator* rebx_load_operator(struct rebx_extras* const rebx, const char* name);
 int rebx_add_operator(struct rebx_extras* rebx, struct rebx_operator* op);
@@ -215,6 +216,11 @@ void rebx_integrate_force(struct reb_simulation* const sim, struct rebx_operator
  * built against REBOUND (REBXAMD_WITH_REBOUND) it first calls reb_update_acceleration as the
  * reference does. */
 void rebx_drift_step(struct reb_simulation* const sim, struct rebx_operator* const op, const double dt);
+/* src/modify_mass.c:63-73 (per-particle "tau_mass") and src/modify_orbits_direct.c:121-132
+ * (per-particle "tau_a", "tau_e", "tau_inc", "tau_omega", "tau_Omega"; operator parameters
+ * "coordinates" and "p"): one device round trip each. */
+void rebx_modify_mass(struct reb_simulation* const sim, struct rebx_operator* const op, const double dt);
+void rebx_modify_orbits_direct(struct reb_simulation* const sim, struct rebx_operator* const op, const double dt);
 void rebx_kick_step(struct reb_simulation* const sim, struct rebx_operator* const op, const double dt);
 /* src/core.h:61, src/core.c:860-866 */
 void rebx_reset_accelerations(struct reb_particle* const ps, const int N);

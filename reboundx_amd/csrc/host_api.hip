@@ -78,8 +78,8 @@ using rebxamd::WARN_IM_ITER;
 namespace {
 
 enum { H_X, H_Y, H_Z, H_VX, H_VY, H_VZ, H_M, H_AX, H_AY, H_AZ, H_NDYN };
-enum { P_BETA, P_RT, P_K1, P_TA, P_TE, P_TI, P_NPAR };
-static const char* const kParamName[P_NPAR] = {"beta", "R_tides", "k1", "tau_a", "tau_e", "tau_inc"};
+enum { P_BETA, P_RT, P_K1, P_TA, P_TE, P_TI, P_TM, P_TOM, P_TON, P_NPAR };
+static const char* const kParamName[P_NPAR] = {"beta", "R_tides", "k1", "tau_a", "tau_e", "tau_inc", "tau_mass", "tau_omega", "tau_Omega"};
 
 struct SourceJ { int idx; double J, Req; };
 struct SourceC { int idx; double A, gamma; };
@@ -869,6 +869,8 @@ extern "C" struct rebx_operator* rebx_load_operator(struct rebx_extras* const re
     struct rebx_operator* op = rebx_create_operator(rebx, name);
     if (!op) return NULL;
     if (strcmp(name, "integrate_force") == 0) op->step_function = rebx_integrate_force;
+    else if (strcmp(name, "modify_mass") == 0) op->step_function = rebx_modify_mass;
+    else if (strcmp(name, "modify_orbits_direct") == 0) op->step_function = rebx_modify_orbits_direct;
     else if (strcmp(name, "drift") == 0) op->step_function = rebx_drift_step;
     else if (strcmp(name, "kick") == 0) op->step_function = rebx_kick_step;
     else {
@@ -1212,4 +1214,74 @@ extern "C" double rebx_gr_hamiltonian(struct rebx_extras* const rebx, const stru
         return 0.;
     }
     return H;
+}
+
+// ------------------------------------------------------------------ operators that change the state
+namespace {
+// device -> host for the listed dynamic columns, then columns -> array-of-structs
+bool state_back(struct rebx_extras* rebx, Bridge* b, struct reb_particle* ps, int N, bool with_mass) {
+    hipStream_t st = nullptr;
+    const size_t bytes = (size_t)N * sizeof(double);
+    bool ok = true;
+    for (int k = H_X; k <= (with_mass ? H_M : H_VZ) && ok; k++) ok = hipMemcpyAsync(b->h_dyn[k], b->d_dyn[k], bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok = ok && hipStreamSynchronize(st) == hipSuccess;
+    if (!ok) { rebx_error(rebx, "REBOUNDx (MI355X) Error: device to host copy failed.\n"); return false; }
+    double* const* h = b->h_dyn;
+    for (int i = 0; i < N; i++) {
+        ps[i].x = h[H_X][i]; ps[i].y = h[H_Y][i]; ps[i].z = h[H_Z][i];
+        ps[i].vx = h[H_VX][i]; ps[i].vy = h[H_VY][i]; ps[i].vz = h[H_VZ][i];
+        if (with_mass) ps[i].m = h[H_M][i];
+    }
+    return true;
+}
+// a parameter column nobody set was not uploaded: operators that take it unconditionally get the NaN column
+const double* column_or_nan(Bridge* b, int k, int N) {
+    if (!b->par_used[k]) (void)hipMemcpy(b->d_par[k], b->h_par[k], (size_t)N * sizeof(double), hipMemcpyHostToDevice);
+    return b->d_par[k];
+}
+void report_device_error(struct reb_simulation* sim, Bridge* b, const char* what) {
+    char str[400];
+    snprintf(str, sizeof(str), "REBOUNDx (MI355X) Error: %s. %s\n", rebxamd_last_error(b->ctx), what);
+    (void)hipDeviceSynchronize();
+    reb_error(sim, str);
+}
+}  // namespace
+
+extern "C" void rebx_modify_mass(struct reb_simulation* const sim, struct rebx_operator* const, const double dt) {      // src/modify_mass.c:63-73
+    struct rebx_extras* rebx = (struct rebx_extras*)sim->extras;
+    const int N = sim->N - sim->N_var;
+    if (!rebx || N <= 0) return;
+    Bridge* b = bridge_of(rebx, true);
+    rebxamd_view v;
+    double t[3];
+    if (!stage_in(sim, rebx, b, sim->particles, N, v, t)) return;
+    if (rebxamd_modify_mass(b->ctx, &v, column_or_nan(b, P_TM, N), dt, nullptr) != REBXAMD_OK) { report_device_error(sim, b, "Masses were not updated."); return; }
+    state_back(rebx, b, sim->particles, N, true);
+}
+
+extern "C" void rebx_modify_orbits_direct(struct reb_simulation* const sim, struct rebx_operator* const op, const double dt) {   // src/modify_orbits_direct.c:121-132
+    struct rebx_extras* rebx = (struct rebx_extras*)sim->extras;
+    const int N = sim->N - sim->N_var;
+    if (!rebx || N <= 0) return;
+    const int* cp = (const int*)rebx_get_param(rebx, op->ap, "coordinates");
+    const int coordinates = cp ? *cp : REBX_COORDINATES_JACOBI;
+    const double* p_param = (const double*)rebx_get_param(rebx, op->ap, "p");
+    Bridge* b = bridge_of(rebx, true);
+    rebxamd_view v;
+    double t[3];
+    if (!stage_in(sim, rebx, b, sim->particles, N, v, t)) return;
+    if (coordinates == REBX_COORDINATES_PARTICLE && b->first_primary < 0) {
+        reb_error(sim, "Coordinates set to REBX_COORDINATES_PARTICLE, but primary param was not found in any particle.  Need to set parameter.\n");
+        return;
+    }
+    if (coordinates != REBX_COORDINATES_JACOBI && coordinates != REBX_COORDINATES_BARYCENTRIC && coordinates != REBX_COORDINATES_PARTICLE) {
+        reb_error(sim, "Coordinates not supported in REBOUNDx.\n");
+        return;
+    }
+    if (rebxamd_modify_orbits_direct(b->ctx, &v, coordinates, b->first_primary, p_param, b->par_used[P_TOM] ? b->d_par[P_TOM] : nullptr,
+                                     b->par_used[P_TON] ? b->d_par[P_TON] : nullptr, dt, nullptr) != REBXAMD_OK) {
+        report_device_error(sim, b, "Orbits were not updated.");
+        return;
+    }
+    state_back(rebx, b, sim->particles, N, false);
 }

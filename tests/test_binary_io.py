@@ -64,7 +64,7 @@ def test_reference_fixture_loads_with_its_force_and_parameters(name):
     sim.free_particle_params()
 
 
-@pytest.mark.parametrize("name", FORCE_FILES + ["test"])
+@pytest.mark.parametrize("name", FORCE_FILES + ["test", "modify_mass", "modify_orbits_direct"])
 def test_reading_then_writing_a_reference_fixture_reproduces_its_bytes(name, tmp_path):
     """Everything after the 64-byte header (which names the writing version) must come back
     byte for byte: record order, sizes, list order, values.  test.rebx (two particles) holds an
@@ -93,10 +93,17 @@ def test_fixture_whose_step_names_a_missing_operator_loads_the_rest():
     assert lib.rebx_len(rebx._post_timestep_modifications) == 0
 
 
-@pytest.mark.parametrize("name", ["modify_mass", "modify_orbits_direct"])
-def test_fixture_with_an_operator_outside_this_library_reports_it(name):
-    with pytest.raises(RuntimeError, match="Operator '%s' not found" % name):
-        load(name)
+def test_operator_fixtures_load_with_their_steps_and_parameters():
+    """modify_mass.rebx / modify_orbits_direct.rebx: the operator, half a step before and half a
+    step after (written by rebx_add_operator under WHFast), and the particles' timescales."""
+    sim, rebx, _ = load("modify_mass")
+    assert rebx.get_operator("modify_mass").operator_type == 1
+    assert lib.rebx_len(rebx._pre_timestep_modifications) == 1 and lib.rebx_len(rebx._post_timestep_modifications) == 1
+    assert sim.particles[0].params["tau_mass"] == -1e4
+    sim2, rebx2, _ = load("modify_orbits_direct")
+    assert rebx2.get_operator("modify_orbits_direct").name == b"modify_orbits_direct"
+    assert sim2.particles[1].params["tau_omega"] == 100.0 and sim2.particles[2].params["tau_inc"] == -1e3
+    assert sim2.pre_timestep_modifications and sim2.post_timestep_modifications
 
 
 def test_missing_and_truncated_files_are_errors(tmp_path):

@@ -319,3 +319,40 @@ def test_integrate_force_operator_with_a_builtin_force_runs_on_the_device(integr
         assert ulp_diff(got, want).max() == 0
         assert ulp_diff(acc_of(sim.particles, n), np.array(ref.acc)).max() == 0
     sim.free_particle_params()
+
+
+@pytest.mark.parametrize("name", ["modify_mass", "modify_orbits_direct"])
+def test_operator_fixture_of_the_reference_runs_through_the_timestep_hooks(name):
+    """Load the reference's own .rebx fixture (operator + steps + particle timescales) into its
+    three-body system and let the pre-timestep hook run the operator for half a step on the
+    device; compare with the checker's operator, which reproduces the reference's archive."""
+    import json
+    import os
+    import warnings as _w
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    arch = json.load(open(os.path.join(golden, "reference_archives.json")))
+    start = np.array([[float.fromhex(v) for v in row] for row in arch["forces"][name][0]["particles"]])
+    cols = {k: start[:, j].copy() for j, k in enumerate(("x", "y", "z", "vx", "vy", "vz", "m"))}
+    for k in ("ax", "ay", "az"):
+        cols[k] = np.zeros(3)
+    sim = sim_from(cols)
+    sim.integrator = 1                       # whfast
+    sim.dt = float.fromhex(arch["dt"])
+    with _w.catch_warnings():
+        _w.simplefilter("ignore")            # written by an older version
+        rebx = Extras(sim, os.path.join(golden, "rebx", name + ".rebx"))
+    sim.pre_timestep_modifications(ctypes.byref(sim))
+    sim.process_messages()
+    ref = oracle.Sim(cols)
+    nan = lambda **kw: np.array([kw.get(i, np.nan) for i in (0, 1, 2)])
+    if name == "modify_mass":
+        oracle.modify_mass(ref, 0.5 * sim.dt, np.array([-1e4, np.nan, np.nan]))
+    else:
+        oracle.modify_orbits_direct(ref, 0.5 * sim.dt, 0, None, np.array([np.nan, -1e4, np.nan]), np.array([np.nan, -1e3, -1e3]),
+                                    np.array([np.nan, np.nan, -1e3]), np.array([np.nan, 100., np.nan]), None, None)
+    got = np.array([[getattr(sim.particles[i], k) for i in range(3)] for k in ("x", "y", "z", "vx", "vy", "vz", "m")])
+    want = np.array([ref.cols[k] for k in ("x", "y", "z", "vx", "vy", "vz", "m")])
+    assert np.abs(got - want).max() <= 1e-13
+    assert np.abs(want - start.T).max() > 1e-7
+    sim.free_particle_params()
+    del rebx

@@ -200,8 +200,8 @@ def test_operator_factory_and_step_lists():
     sim.add(m=1e-3, x=1., vy=1.)
     sim.dt = 0.5
     rebx = Extras(sim)
-    with pytest.raises(RuntimeError, match="Operator 'modify_mass' not found"):
-        rebx.load_operator("modify_mass")
+    with pytest.raises(RuntimeError, match="Operator 'track_min_distance' not found"):
+        rebx.load_operator("track_min_distance")
     assert lib.rebx_len(rebx._allocated_operators) == 0
     drift = rebx.load_operator("drift")
     assert isinstance(drift, Operator) and drift.name == b"drift" and drift.operator_type == 1
