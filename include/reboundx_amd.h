@@ -191,6 +191,8 @@ double rebx_tides_precession_potential(struct rebx_extras* const rebx);
 double rebx_gr_potential_potential(struct rebx_extras* const rebx, const struct rebx_force* const gr_potential);
 /* src/reboundx.h:467, src/gr.c:248-260 */
 double rebx_gr_hamiltonian(struct rebx_extras* const rebx, const struct rebx_force* const gr);
+/* src/reboundx.h:475, src/gr_full.c:251-377 */
+double rebx_gr_full_hamiltonian(struct rebx_extras* const rebx, const struct rebx_force* const gr_full);
 
 /* Operators on the additional-force path: the "integrate a force across a timestep" operator and
  * the kick/drift steppers.  src/reboundx.h:331, :329, :327, :280; src/core.c:279-368, :411-510,
@@ -393,6 +395,12 @@ int rebxamd_potentials(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd
  * kinetic + Newtonian pair potential + post-Newtonian term in Jacobi coordinates.  *H in host
  * memory; synchronises the stream.  O(N * massive) for the pair potential. */
 int rebxamd_gr_hamiltonian(rebxamd_ctx* ctx, const rebxamd_view* view, double c, double* H, void* stream);
+
+/* The Hamiltonian the gr_full force derives from (src/gr_full.c:251-377): canonical velocities by
+ * ten fixed-point sweeps over all pairs, then kinetic + Newtonian + post-Newtonian energy.  The
+ * sweeps read the previous iterate (the reference updates in place); both converge to the same
+ * fixed point.  *H in host memory; synchronises the stream.  O(N^2) per sweep. */
+int rebxamd_gr_full_hamiltonian(rebxamd_ctx* ctx, const rebxamd_view* view, double c, double* H, void* stream);
 
 /* Values of enum rebx_integrator, src/reboundx.h:157-163. */
 enum rebxamd_integrator {

@@ -1062,3 +1062,72 @@ int orc_modify_orbits_direct(const orc_sim* s, int coordinates, double p_param, 
     free(p);
     return 0;
 }
+
+/* gr_full.c:251-377 -- the Hamiltonian gr_full derives from.  The canonical velocities vtilde
+ * are found by ten Gauss-Seidel sweeps (each body is updated in place and the next body already
+ * sees the new value), then kinetic, Newtonian and post-Newtonian parts are summed. */
+double orc_gr_full_hamiltonian(const orc_sim* s, double c) {
+    const int N = s->N;
+    const double G = s->G, C2 = c * c;
+    body* p = gather(s);
+    double* vt = (double*)malloc((size_t)(N > 0 ? N : 1) * 3 * sizeof(double));
+    for (int j = 0; j < N; j++) { vt[3 * j] = p[j].vx; vt[3 * j + 1] = p[j].vy; vt[3 * j + 2] = p[j].vz; }
+    for (int q = 0; q < 10; q++) {
+        for (int i = 0; i < N; i++) {
+            const body pi = p[i];
+            const double vt2 = vt[3 * i] * vt[3 * i] + vt[3 * i + 1] * vt[3 * i + 1] + vt[3 * i + 2] * vt[3 * i + 2];
+            const double A = (1. - 0.5 * vt2 / C2);
+            double dx = 0., dy = 0., dz = 0.;
+            for (int j = 0; j < N; j++) {
+                if (j == i) continue;
+                const body pj = p[j];
+                const double xij = pj.x - pi.x, yij = pj.y - pi.y, zij = pj.z - pi.z;
+                const double rij2 = xij * xij + yij * yij + zij * zij;
+                const double rij = sqrt(rij2);
+                const double rijdotvj = vt[3 * j] * xij + vt[3 * j + 1] * yij + vt[3 * j + 2] * zij;
+                const double pfac = pj.m / rij;
+                dx += pfac * (6. * vt[3 * i] - 7. * vt[3 * j] - rijdotvj * xij / rij2);
+                dy += pfac * (6. * vt[3 * i + 1] - 7. * vt[3 * j + 1] - rijdotvj * yij / rij2);
+                dz += pfac * (6. * vt[3 * i + 2] - 7. * vt[3 * j + 2] - rijdotvj * zij / rij2);
+            }
+            dx *= G / (2. * C2); dy *= G / (2. * C2); dz *= G / (2. * C2);
+            vt[3 * i] = (pi.vx + dx) / A;
+            vt[3 * i + 1] = (pi.vy + dy) / A;
+            vt[3 * i + 2] = (pi.vz + dz) / A;
+        }
+    }
+    double e_kin = 0., e_pot = 0., e_pn = 0.;
+    for (int i = 0; i < N; i++) {
+        const double vt2 = vt[3 * i] * vt[3 * i] + vt[3 * i + 1] * vt[3 * i + 1] + vt[3 * i + 2] * vt[3 * i + 2];
+        e_kin += 0.5 * p[i].m * vt2;
+    }
+    for (int i = 0; i < N; i++) {
+        const body pi = p[i];
+        double sumk = 0.;
+        for (int k = 0; k < N; k++) {
+            if (k == i) continue;
+            const double xik = p[k].x - pi.x, yik = p[k].y - pi.y, zik = p[k].z - pi.z;
+            sumk -= 2. * G * p[k].m / sqrt(xik * xik + yik * yik + zik * zik);
+        }
+        const double vt2 = vt[3 * i] * vt[3 * i] + vt[3 * i + 1] * vt[3 * i + 1] + vt[3 * i + 2] * vt[3 * i + 2];
+        for (int j = 0; j < N; j++) {
+            if (j == i) continue;
+            const body pj = p[j];
+            const double xij = pj.x - pi.x, yij = pj.y - pi.y, zij = pj.z - pi.z;
+            const double rij2 = xij * xij + yij * yij + zij * zij;
+            const double rij = sqrt(rij2);
+            const double rijdotvj = vt[3 * j] * xij + vt[3 * j + 1] * yij + vt[3 * j + 2] * zij;
+            const double rijdotvi = vt[3 * i] * xij + vt[3 * i + 1] * yij + vt[3 * i + 2] * zij;
+            const double vidotvj = vt[3 * i] * vt[3 * j] + vt[3 * i + 1] * vt[3 * j + 1] + vt[3 * i + 2] * vt[3 * j + 2];
+            e_pn -= G / (4. * C2) * pi.m * pj.m / rij * (6. * vt2 - 7 * vidotvj - rijdotvi * rijdotvj / rij2 + sumk);
+        }
+        e_pn -= pi.m / (8. * C2) * vt2 * vt2;
+        for (int j = i + 1; j < N; j++) {
+            const double dx = pi.x - p[j].x, dy = pi.y - p[j].y, dz = pi.z - p[j].z;
+            e_pot -= G * pi.m * p[j].m / sqrt(dx * dx + dy * dy + dz * dz);
+        }
+    }
+    free(vt);
+    free(p);
+    return e_kin + e_pot + e_pn;
+}

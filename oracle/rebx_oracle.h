@@ -106,6 +106,7 @@ double orc_central_force_potential(const orc_sim* s, const double* Acentral, con
 double orc_tides_precession_potential(const orc_sim* s, const double* R_tides, const double* k1, const uint8_t* primary); /* tides_precession.c:132-202 */
 double orc_gr_potential_potential(const orc_sim* s, double c);                                                          /* gr_potential.c:100-132 */
 double orc_gr_hamiltonian(const orc_sim* s, double c);                                                                  /* gr.c:190-260 */
+double orc_gr_full_hamiltonian(const orc_sim* s, double c);                                                             /* gr_full.c:251-377 */
 double orc_newtonian_energy(const orc_sim* s);
 
 /* src/radiation_forces.c:119-124 */

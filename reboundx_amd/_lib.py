@@ -56,6 +56,7 @@ _sig = {
     "rebxamd_modify_orbits_direct": (c_int, [c_void_p, POINTER(View), c_int, c_int, POINTER(c_double), c_void_p, c_void_p, c_double, c_void_p]),
     "rebxamd_potentials": (c_int, [c_void_p, POINTER(View), POINTER(Op), c_int, POINTER(c_double), c_void_p]),
     "rebxamd_gr_hamiltonian": (c_int, [c_void_p, POINTER(View), c_double, POINTER(c_double), c_void_p]),
+    "rebxamd_gr_full_hamiltonian": (c_int, [c_void_p, POINTER(View), c_double, POINTER(c_double), c_void_p]),
     "rebxamd_integrate_force": (c_int, [c_void_p, POINTER(View), POINTER(Op), c_int, c_int, c_double, c_int, POINTER(c_int), c_void_p]),
     "rebxamd_kick": (c_int, [c_void_p, POINTER(View), c_double, c_int, c_void_p]),
     "rebxamd_drift": (c_int, [c_void_p, POINTER(View), c_double, c_int, c_void_p]),

@@ -659,6 +659,26 @@ extern "C" int rebxamd_gr_hamiltonian(rebxamd_ctx* ctx, const rebxamd_view* view
     return REBXAMD_OK;
 }
 
+extern "C" int rebxamd_gr_full_hamiltonian(rebxamd_ctx* ctx, const rebxamd_view* view, double c, double* H, void* stream) {
+    if (!ctx) return REBXAMD_ERR_ARG;
+    if (!view || view->n < 0 || !H) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_gr_full_hamiltonian: bad argument");
+    *H = 0.;
+    if (view->n == 0) return REBXAMD_OK;
+    const View v = make_view(view);
+    if (!v.x || !v.y || !v.z || !v.vx || !v.vy || !v.vz || !v.m) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_gr_full_hamiltonian: position/velocity/mass columns missing");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int rc = ensure(ctx, &ctx->gf, &ctx->gf_cap, grfull_hamiltonian_doubles(v.n) * sizeof(double), st);
+    if (rc != REBXAMD_OK) return rc;
+    double* dout = nullptr;
+    HIP_TRY(launch_grfull_hamiltonian(v, view->G, c, ctx->gf, &dout, st));
+    double h[3] = {0., 0., 0.};
+    HIP_TRY(hipMemcpyAsync(h, dout, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *H = h[0] + h[1] + h[2];
+    return REBXAMD_OK;
+}
+
 // ------------------------------------------------------------------ gr_full
 
 static int grfull_check(rebxamd_ctx* ctx, const rebxamd_view* u, int64_t row0, int64_t row1) {

@@ -316,6 +316,152 @@ __global__ __launch_bounds__(256) void grfull_finish_kernel(View v, const double
     }
 }
 
+// ------------------------------------------------------------------ Hamiltonian (gr_full.c:251-377)
+// Canonical velocities vtilde by fixed-point sweeps, then kinetic + Newtonian + post-Newtonian
+// energy.  The reference sweeps in place (Gauss-Seidel: body i sees the new values of bodies
+// before it); here every sweep reads the previous iterate (Jacobi), which parallelises over i.
+// Both contract with ratio ~ (v/c)^2 per sweep to the same fixed point, so after the reference's
+// ten sweeps they agree to rounding unless the system is strongly relativistic.
+struct __align__(16) TileH { double x, y, z, m, vx, vy, vz, pad; };
+
+__global__ __launch_bounds__(GB) void grfull_h_sweep_kernel(View v, double G, double C2, const double* vtx, const double* vty, const double* vtz,
+                                                          double* ox, double* oy, double* oz) {
+#pragma clang fp contract(off)
+    __shared__ TileH t[GB];
+    const long long i = (long long)blockIdx.x * GB + threadIdx.x;
+    const bool live = i < v.n;
+    double xi = 0., yi = 0., zi = 0., vix = 0., viy = 0., viz = 0.;
+    if (live) { xi = v.x[i]; yi = v.y[i]; zi = v.z[i]; vix = vtx[i]; viy = vty[i]; viz = vtz[i]; }
+    double dx = 0., dy = 0., dz = 0.;
+    for (long long jt = 0; jt < v.n; jt += GB) {
+        const long long j = jt + threadIdx.x;
+        __syncthreads();
+        TileH h;
+        if (j < v.n) { h.x = v.x[j]; h.y = v.y[j]; h.z = v.z[j]; h.m = v.m[j]; h.vx = vtx[j]; h.vy = vty[j]; h.vz = vtz[j]; }
+        else { h.x = h.y = h.z = 1.e100; h.m = 0.; h.vx = h.vy = h.vz = 0.; }
+        h.pad = 0.;
+        t[threadIdx.x] = h;
+        __syncthreads();
+        const int cnt = (int)((v.n - jt) < GB ? (v.n - jt) : GB);
+        for (int k = 0; k < cnt; k++) {
+            if (jt + k == i) continue;
+            const TileH b = t[k];
+            const double xij = b.x - xi, yij = b.y - yi, zij = b.z - zi;
+            const double rij2 = xij * xij + yij * yij + zij * zij;
+            const double rij = sqrt(rij2);
+            const double rijdotvj = b.vx * xij + b.vy * yij + b.vz * zij;
+            const double pfac = b.m / rij;
+            dx += pfac * (6. * vix - 7. * b.vx - rijdotvj * xij / rij2);
+            dy += pfac * (6. * viy - 7. * b.vy - rijdotvj * yij / rij2);
+            dz += pfac * (6. * viz - 7. * b.vz - rijdotvj * zij / rij2);
+        }
+    }
+    if (live) {
+        const double A = (1. - 0.5 * (vix * vix + viy * viy + viz * viz) / C2);
+        dx *= G / (2. * C2); dy *= G / (2. * C2); dz *= G / (2. * C2);
+        ox[i] = (v.vx[i] + dx) / A; oy[i] = (v.vy[i] + dy) / A; oz[i] = (v.vz[i] + dz) / A;
+    }
+}
+
+// per-workgroup sums of (kinetic, Newtonian potential, post-Newtonian) -> partials[3*block + c]
+__global__ __launch_bounds__(GB) void grfull_h_energy_kernel(View v, double G, double C2, const double* vtx, const double* vty, const double* vtz, double* partials) {
+#pragma clang fp contract(off)
+    __shared__ TileH t[GB];
+    __shared__ double red[GB / 64][3];
+    const long long i = (long long)blockIdx.x * GB + threadIdx.x;
+    const bool live = i < v.n;
+    double xi = 0., yi = 0., zi = 0., mi = 0., vix = 0., viy = 0., viz = 0.;
+    if (live) { xi = v.x[i]; yi = v.y[i]; zi = v.z[i]; mi = v.m[i]; vix = vtx[i]; viy = vty[i]; viz = vtz[i]; }
+    const double vt2 = vix * vix + viy * viy + viz * viz;
+    double sumk = 0., e_pot = 0., s_a = 0., s_b = 0.;
+    // e_pn_i = -G/(4 C2) m_i sum_j m_j/r (6 vt2 - 7 vi.vj - (r.vi)(r.vj)/r^2 + sumk): the sumk part factors out
+    for (long long jt = 0; jt < v.n; jt += GB) {
+        const long long j = jt + threadIdx.x;
+        __syncthreads();
+        TileH h;
+        if (j < v.n) { h.x = v.x[j]; h.y = v.y[j]; h.z = v.z[j]; h.m = v.m[j]; h.vx = vtx[j]; h.vy = vty[j]; h.vz = vtz[j]; }
+        else { h.x = h.y = h.z = 1.e100; h.m = 0.; h.vx = h.vy = h.vz = 0.; }
+        h.pad = 0.;
+        t[threadIdx.x] = h;
+        __syncthreads();
+        const int cnt = (int)((v.n - jt) < GB ? (v.n - jt) : GB);
+        for (int k = 0; k < cnt; k++) {
+            if (jt + k == i) continue;
+            const TileH b = t[k];
+            const double xij = b.x - xi, yij = b.y - yi, zij = b.z - zi;
+            const double rij2 = xij * xij + yij * yij + zij * zij;
+            const double rij = sqrt(rij2);
+            const double w = b.m / rij;
+            sumk -= 2. * G * w;
+            const double rijdotvj = b.vx * xij + b.vy * yij + b.vz * zij;
+            const double rijdotvi = vix * xij + viy * yij + viz * zij;
+            const double vidotvj = vix * b.vx + viy * b.vy + viz * b.vz;
+            s_a += w * (6. * vt2 - 7 * vidotvj - rijdotvi * rijdotvj / rij2);
+            s_b += w;
+            if (jt + k > i) e_pot -= G * mi * w;
+        }
+    }
+    double e[3] = {0., 0., 0.};
+    if (live) {
+        e[0] = 0.5 * mi * vt2;
+        e[1] = e_pot;
+        e[2] = -(G / (4. * C2)) * mi * (s_a + sumk * s_b) - mi / (8. * C2) * vt2 * vt2;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) e[c] += __shfl_down(e[c], off, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) for (int c = 0; c < 3; c++) red[wave][c] = e[c];
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double ssum = 0.;
+        for (int w = 0; w < GB / 64; w++) ssum += red[w][threadIdx.x];
+        partials[3 * (long long)blockIdx.x + threadIdx.x] = ssum;
+    }
+}
+
+__global__ __launch_bounds__(1024) void grfull_h_sum_kernel(const double* partials, long long nb, double* out) {
+    __shared__ double red[16][3];
+    double q[3] = {0., 0., 0.};
+    for (long long k = threadIdx.x; k < nb; k += 1024) for (int c = 0; c < 3; c++) q[c] += partials[3 * k + c];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) q[c] += __shfl_down(q[c], off, 64);
+    if ((threadIdx.x & 63) == 0) for (int c = 0; c < 3; c++) red[threadIdx.x >> 6][c] = q[c];
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double ssum = 0.;
+        for (int w = 0; w < 16; w++) ssum += red[w][threadIdx.x];
+        out[threadIdx.x] = ssum;
+    }
+}
+
+size_t grfull_hamiltonian_doubles(long long n) { return (size_t)(6 * n + 3 * ((n + GB - 1) / GB) + 8); }
+
+// ws: grfull_hamiltonian_doubles(n); out = ws + (that) - 8: kinetic, Newtonian, post-Newtonian
+hipError_t launch_grfull_hamiltonian(const View& v, double G, double c, double* ws, double** out, hipStream_t st) {
+    const long long n = v.n, nb = (n + GB - 1) / GB;
+    double* a[3] = {ws, ws + n, ws + 2 * n};
+    double* b[3] = {ws + 3 * n, ws + 4 * n, ws + 5 * n};
+    double* part = ws + 6 * n;
+    *out = part + 3 * nb;
+    const size_t bytes = (size_t)n * sizeof(double);
+    const double* src[3] = {v.vx, v.vy, v.vz};
+    for (int k = 0; k < 3; k++) {
+        const hipError_t e = hipMemcpyAsync(a[k], src[k], bytes, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return e;
+    }
+    for (int q = 0; q < 10; q++) {                  // the reference's loop bound (gr_full.c:279)
+        hipLaunchKernelGGL(grfull_h_sweep_kernel, dim3((unsigned)nb), dim3(GB), 0, st, v, G, c * c, a[0], a[1], a[2], b[0], b[1], b[2]);
+        for (int k = 0; k < 3; k++) { double* tmp = a[k]; a[k] = b[k]; b[k] = tmp; }
+    }
+    hipLaunchKernelGGL(grfull_h_energy_kernel, dim3((unsigned)nb), dim3(GB), 0, st, v, G, c * c, a[0], a[1], a[2], part);
+    hipLaunchKernelGGL(grfull_h_sum_kernel, dim3(1), dim3(1024), 0, st, part, nb, *out);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ launchers
 // scratch for the j-chunk partials is owned by device_api.hip and handed in through `part`
 struct GrFullPlan { int rowblocks; int nchunks; long long jchunk; int rows_per_thread; };

@@ -1285,3 +1285,19 @@ extern "C" void rebx_modify_orbits_direct(struct reb_simulation* const sim, stru
     }
     state_back(rebx, b, sim->particles, N, false);
 }
+
+extern "C" double rebx_gr_full_hamiltonian(struct rebx_extras* const rebx, const struct rebx_force* const force) {      // src/gr_full.c:251-377
+    if (rebx->sim == NULL) { rebx_error(rebx, ""); return 0; }
+    struct reb_simulation* sim = rebx->sim;
+    const double* c = (const double*)rebx_get_param(rebx, force->ap, "c");
+    if (c == NULL) { reb_error(sim, "Need to set speed of light in gr effect.  See examples in documentation.\n"); return 0; }
+    const int N = sim->N - sim->N_var;
+    if (N <= 0) return 0.;
+    Bridge* b = bridge_of(rebx, true);
+    rebxamd_view v;
+    double t[3];
+    if (!stage_in(sim, rebx, b, sim->particles, N, v, t)) return 0.;
+    double H = 0.;
+    if (rebxamd_gr_full_hamiltonian(b->ctx, &v, *c, &H, nullptr) != REBXAMD_OK) { report_device_error(sim, b, ""); return 0.; }
+    return H;
+}

@@ -109,6 +109,8 @@ hipError_t launch_grfull_pass(int pass, const View& v, double G, double c, long 
                               const double* aox, const double* aoy, const double* aoz,
                               const double* acx, const double* acy, const double* acz,
                               double* o0, double* o1, double* o2, unsigned* flag, double* part, bool exact, hipStream_t st);
+size_t grfull_hamiltonian_doubles(long long n);
+hipError_t launch_grfull_hamiltonian(const View& v, double G, double c, double* ws, double** out, hipStream_t st);
 hipError_t launch_grfull_prepare(const View& v, double G, int gravity_ignore_10, double* anx, double* any_, double* anz,
                                  double* a0x, double* a0y, double* a0z, hipStream_t st);
 hipError_t launch_grfull_finish(const View& v, const double* ax, const double* ay, const double* az, hipStream_t st);

@@ -101,6 +101,11 @@ class Context:
         self._check(lib.rebxamd_gr_hamiltonian(self._h, ctypes.byref(view), float(c), ctypes.byref(out), self._stream()))
         return out.value
 
+    def gr_full_hamiltonian(self, view, c):
+        out = ctypes.c_double(0.)
+        self._check(lib.rebxamd_gr_full_hamiltonian(self._h, ctypes.byref(view), float(c), ctypes.byref(out), self._stream()))
+        return out.value
+
     def integrate_force(self, view, ops, integrator, dt, mode=_lib.MODE_FAST):
         """rebx_integrate_force on device columns: velocities of `view` are updated in place.
         `integrator`: one of "euler", "rk2", "rk4", "implicit_midpoint", "none" (or the enum

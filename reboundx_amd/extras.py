@@ -332,6 +332,9 @@ class Extras(Structure):
     def gr_hamiltonian(self, force):
         return self._potential(lib.rebx_gr_hamiltonian(byref(self), byref(force)))
 
+    def gr_full_hamiltonian(self, force):
+        return self._potential(lib.rebx_gr_full_hamiltonian(byref(self), byref(force)))
+
     def _potential(self, value):
         self.process_messages()
         return value
@@ -491,6 +494,8 @@ lib.rebx_gr_potential_potential.argtypes = [_P(Extras), _P(Force)]
 lib.rebx_gr_potential_potential.restype = c_double
 lib.rebx_gr_hamiltonian.argtypes = [_P(Extras), _P(Force)]
 lib.rebx_gr_hamiltonian.restype = c_double
+lib.rebx_gr_full_hamiltonian.argtypes = [_P(Extras), _P(Force)]
+lib.rebx_gr_full_hamiltonian.restype = c_double
 lib.rebx_output_binary.argtypes = [_P(Extras), c_char_p]
 lib.rebx_output_binary.restype = None
 lib.rebx_init_extras_from_binary.argtypes = [_P(Extras), c_char_p, _P(c_int)]
@@ -515,7 +520,7 @@ PLUGIN_API_SYMBOLS = (
     "rebx_get_operator", "rebx_pre_timestep_modifications", "rebx_post_timestep_modifications", "rebx_integrate_force",
     "rebx_output_binary", "rebx_init_extras_from_binary", "rebx_create_extras_from_binary",
     "rebx_drift_step", "rebx_kick_step", "rebx_modify_mass", "rebx_modify_orbits_direct", "rebx_gravitational_harmonics_potential", "rebx_central_force_potential",
-    "rebx_tides_precession_potential", "rebx_gr_potential_potential", "rebx_gr_hamiltonian",
+    "rebx_tides_precession_potential", "rebx_gr_potential_potential", "rebx_gr_hamiltonian", "rebx_gr_full_hamiltonian",
     "rebx_attach", "rebx_detach", "rebx_extras_cleanup", "rebx_free", "rebx_initialize", "rebx_register_default_params",
     "rebx_free_pointers", "rebx_free_particle_ap", "rebx_create_force", "rebx_load_force", "rebx_add_force", "rebx_remove_force",
     "rebx_get_force", "rebx_get_param", "rebx_get_param_struct", "rebx_set_param_pointer", "rebx_set_param_double",

@@ -136,6 +136,13 @@ def gr_hamiltonian(sim, c):
     return lib.orc_gr_hamiltonian(ctypes.byref(sim.s), c_double(c))
 
 
+lib.orc_gr_full_hamiltonian.restype = c_double
+
+
+def gr_full_hamiltonian(sim, c):
+    return lib.orc_gr_full_hamiltonian(ctypes.byref(sim.s), c_double(c))
+
+
 def newtonian_energy(sim):
     return lib.orc_newtonian_energy(ctypes.byref(sim.s))
 

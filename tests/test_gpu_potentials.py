@@ -117,3 +117,28 @@ def test_gr_hamiltonian_through_the_plugin_api():
         rebx.gr_hamiltonian(gr)
     gr.params["c"] = 1e4
     assert rebx.gr_hamiltonian(gr) == pytest.approx(oracle.gr_hamiltonian(oracle.Sim(cols), 1e4), rel=1e-13)
+
+
+@pytest.mark.parametrize("n,c", [(2, 1e4), (3, 1e2), (64, 50.0), (700, 1e3)])
+def test_gr_full_hamiltonian(ctx, n, c):
+    """src/gr_full.c:251-377.  Jacobi sweeps on the device, Gauss-Seidel in the checker: same
+    fixed point.  Bar: 1e-12 relative to kinetic + |potential| energy."""
+    cl = synthetic.twoplanets() if n == 3 else synthetic.cluster(n)
+    want = oracle.gr_full_hamiltonian(oracle.Sim(cl), c)
+    got = ctx.gr_full_hamiltonian(DeviceParticles.from_host(cl, device="cuda:0").view(), c)
+    v2 = cl["vx"] ** 2 + cl["vy"] ** 2 + cl["vz"] ** 2
+    scale = 0.5 * np.sum(cl["m"] * v2) + abs(oracle.newtonian_energy(oracle.Sim(cl)))
+    assert abs(got - want) <= 1e-12 * scale, (got, want)
+    assert abs(got - (0.5 * np.sum(cl["m"] * v2) + oracle.newtonian_energy(oracle.Sim(cl)))) > 1e-14 * scale   # the PN part is there
+
+
+def test_gr_full_hamiltonian_through_the_plugin_api():
+    from reboundx_amd.extras import Extras, Simulation
+    cols = synthetic.twoplanets()
+    sim = Simulation()
+    for i in range(3):
+        sim.add(m=cols["m"][i], x=cols["x"][i], y=cols["y"][i], z=cols["z"][i], vx=cols["vx"][i], vy=cols["vy"][i], vz=cols["vz"][i])
+    rebx = Extras(sim)
+    f = rebx.load_force("gr_full")
+    f.params["c"] = 1e4
+    assert rebx.gr_full_hamiltonian(f) == pytest.approx(oracle.gr_full_hamiltonian(oracle.Sim(cols), 1e4), rel=1e-13)
