@@ -121,10 +121,9 @@ def c5_section(ctx, n, steps, mode, device):
     queued = (time.perf_counter() - t0) / steps
     x = dp.cols["x"]
     finite = bool(torch.isfinite(x).all().item())
-    # per queued step: one Kepler drift (neighbouring half drifts merge; pos+vel read and written:
-    # 96 B), the fused force pass (152 B; 128 B with the accelerations written, not accumulated)
-    # and the kick (72 B)
-    bytes_per_step = (96 + 128 + 72) * n
+    # per queued step: the fused force pass (152 B) and one kick+drift pass (neighbouring half
+    # drifts merge; pos, vel, acc read, pos, vel written, acc cleared: 144 B)
+    bytes_per_step = (152 + 144) * n
     return {"n": n, "steps": steps, "effects": 5, "us_per_step_host_synced": synced * 1e6, "us_per_step_queued": queued * 1e6,
             "particle_steps_per_s": n / queued, "state_finite": finite,
             "roofline": {"bound": "hbm", "achieved": bytes_per_step / queued / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

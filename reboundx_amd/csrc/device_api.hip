@@ -532,7 +532,7 @@ extern "C" int rebxamd_wh_drift(rebxamd_ctx* ctx, const rebxamd_view* view, doub
     HIP_TRY(hipStreamSynchronize(st));
     double* const x[3] = {const_cast<double*>(view->x), const_cast<double*>(view->y), const_cast<double*>(view->z)};
     double* const v[3] = {const_cast<double*>(view->vx), const_cast<double*>(view->vy), const_cast<double*>(view->vz)};
-    HIP_TRY(launch_wh_drift(x, v, view->G * m0, dt, view->n, ctx->star, mode == REBXAMD_MODE_EXACT, st));
+    HIP_TRY(launch_wh_drift(x, v, nullptr, view->G * m0, dt, 0., view->n, ctx->star, mode == REBXAMD_MODE_EXACT, st));
     return REBXAMD_OK;
 }
 
@@ -553,19 +553,20 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
     const double mu = view->G * m0;
     double* const x[3] = {const_cast<double*>(view->x), const_cast<double*>(view->y), const_cast<double*>(view->z)};
     double* const v[3] = {const_cast<double*>(view->vx), const_cast<double*>(view->vy), const_cast<double*>(view->vz)};
-    const double* const a[3] = {view->ax, view->ay, view->az};
-    // consecutive half drifts of neighbouring steps are one Kepler drift of a whole step (the
-    // flow of the two-body problem composes exactly); only the ends of the run are half steps
-    HIP_TRY(launch_wh_drift(x, v, mu, 0.5 * dt, view->n, ctx->star, exact, st));
+    double* const a[3] = {view->ax, view->ay, view->az};
+    // Consecutive half drifts of neighbouring steps are one Kepler drift of a whole step (the
+    // flow of the two-body problem composes exactly); only the ends of the run are half steps.
+    // The kick rides in the drift kernel that follows it, which also clears the accelerations
+    // for the next force pass.
+    HIP_TRY(launch_wh_drift(x, v, nullptr, mu, 0.5 * dt, 0., view->n, ctx->star, exact, st));
+    rc = rebxamd_reset_accelerations(ctx, view, stream);
+    if (rc != REBXAMD_OK) return rc;
     for (int64_t k = 0; k < nsteps; k++) {
-        rc = rebxamd_reset_accelerations(ctx, view, stream);
-        if (rc != REBXAMD_OK) return rc;
         if (nops > 0) {
             rc = rebxamd_apply(ctx, view, ops, nops, mode, stream);
             if (rc != REBXAMD_OK) return rc;
         }
-        HIP_TRY(launch_wh_kick(v, a, dt, view->n, exact, st));
-        HIP_TRY(launch_wh_drift(x, v, mu, k + 1 < nsteps ? dt : 0.5 * dt, view->n, ctx->star, exact, st));
+        HIP_TRY(launch_wh_drift(x, v, a, mu, k + 1 < nsteps ? dt : 0.5 * dt, dt, view->n, ctx->star, exact, st));
     }
     return REBXAMD_OK;
 }

@@ -85,8 +85,8 @@ hipError_t launch_lincomb(double* const out[3], const double* const v[3], const 
 hipError_t launch_rk2_final(double* const v[3], const double* const a1[3], const double* const a2[3], double b1, double b2, long long n, bool exact, hipStream_t st);
 hipError_t launch_rk4_mid(double* const sv[3], const double* const v[3], double* const k2a[3], double* const k3a[3], double dt, long long n, bool exact, hipStream_t st);
 hipError_t launch_rk4_final(double* const v[3], const double* const a1[3], const double* const a4[3], const double* const k23[3], double dt6, long long n, bool exact, hipStream_t st);
-hipError_t launch_wh_drift(double* const x[3], double* const v[3], double mu, double h, long long n, double* star, bool exact, hipStream_t st);
-hipError_t launch_wh_kick(double* const v[3], const double* const a[3], double dt, long long n, bool exact, hipStream_t st);
+hipError_t launch_wh_drift(double* const x[3], double* const v[3], double* const a[3], double mu, double h, double dtk, long long n,
+                           double* star, bool exact, hipStream_t st);
 long long im_partial_count(long long n);
 hipError_t launch_im_update(double* const fin[3], const double* const orig[3], double* const avgv[3], double* const avga[3], double dt,
                             long long n, double* partials, double* sums, bool exact, hipStream_t st);

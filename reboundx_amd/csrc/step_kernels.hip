@@ -265,8 +265,9 @@ __device__ __forceinline__ void kepler_dev(double (&q)[6], double M, double dt) 
     if (EXACT) kepler_exact(q, M, dt); else kepler_fast(q, M, dt);
 }
 
-// star[0..5] <- state of body 0 before the drift; body 0 drifts linearly; star[6..8] <- its new position
-__global__ void wh_star_drift_kernel(Cols3 x, CCols3 v, double h, double* star) {
+// star[0..5] <- state of body 0 before the drift; body 0 drifts linearly; star[6..8] <- its new
+// position.  With accelerations given: star[9..11] <- a_0, and a_0 is cleared for the next force pass.
+__global__ void wh_star_drift_kernel(Cols3 x, CCols3 v, Cols3 a, double h, double* star) {
 #pragma clang fp contract(off)
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const double x0 = x.x[0], y0 = x.y[0], z0 = x.z[0], vx = v.x[0], vy = v.y[0], vz = v.z[0];
@@ -274,37 +275,39 @@ __global__ void wh_star_drift_kernel(Cols3 x, CCols3 v, double h, double* star) 
     const double nx = x0 + h * vx, ny = y0 + h * vy, nz = z0 + h * vz;
     x.x[0] = nx; x.y[0] = ny; x.z[0] = nz;
     star[6] = nx; star[7] = ny; star[8] = nz;
+    if (a.x != nullptr) {
+        star[9] = a.x[0]; star[10] = a.y[0]; star[11] = a.z[0];
+        a.x[0] = 0.; a.y[0] = 0.; a.z[0] = 0.;
+    }
 }
 
-template <bool EXACT>
-__global__ __launch_bounds__(TB) void wh_drift_kernel(Cols3 x, Cols3 v, double mu, double h, long long n, const double* __restrict__ star) {
+// KICK: v_i += dtk*(a_i - a_0) first (Jacobi kick with massless bodies; a_i is cleared afterwards so
+// that the next force pass accumulates onto zero), then the Kepler drift over h.
+template <bool EXACT, bool KICK>
+__global__ __launch_bounds__(TB) void wh_drift_kernel(Cols3 x, Cols3 v, Cols3 a, double mu, double h, double dtk, long long n, const double* __restrict__ star) {
     const long long i = (long long)blockIdx.x * TB + threadIdx.x + 1;
     if (i >= n) return;
     double q[6];
     {
 #pragma clang fp contract(off)
+        double vx = v.x[i], vy = v.y[i], vz = v.z[i];
+        if (KICK) {
+            const double ax = a.x[i], ay = a.y[i], az = a.z[i];
+            a.x[i] = 0.; a.y[i] = 0.; a.z[i] = 0.;
+            if (EXACT) {
+                vx += dtk * (ax - star[9]); vy += dtk * (ay - star[10]); vz += dtk * (az - star[11]);
+            } else {
+                vx = fma(dtk, ax - star[9], vx); vy = fma(dtk, ay - star[10], vy); vz = fma(dtk, az - star[11], vz);
+            }
+        }
         q[0] = x.x[i] - star[0]; q[1] = x.y[i] - star[1]; q[2] = x.z[i] - star[2];
-        q[3] = v.x[i] - star[3]; q[4] = v.y[i] - star[4]; q[5] = v.z[i] - star[5];
+        q[3] = vx - star[3]; q[4] = vy - star[4]; q[5] = vz - star[5];
     }
     kepler_dev<EXACT>(q, mu, h);
     {
 #pragma clang fp contract(off)
         x.x[i] = q[0] + star[6]; x.y[i] = q[1] + star[7]; x.z[i] = q[2] + star[8];
         v.x[i] = q[3] + star[3]; v.y[i] = q[4] + star[4]; v.z[i] = q[5] + star[5];
-    }
-}
-
-// kick in Jacobi coordinates with massless bodies: v_i += dt*(a_i - a_0), i >= 1; body 0 (the centre of mass) is not kicked
-template <bool EXACT>
-__global__ __launch_bounds__(TB) void wh_kick_kernel(Cols3 v, CCols3 a, double dt, long long n) {
-    const long long i = (long long)blockIdx.x * TB + threadIdx.x + 1;
-    if (i >= n) return;
-    const double a0x = a.x[0], a0y = a.y[0], a0z = a.z[0];
-    if (EXACT) {
-#pragma clang fp contract(off)
-        v.x[i] += dt * (a.x[i] - a0x); v.y[i] += dt * (a.y[i] - a0y); v.z[i] += dt * (a.z[i] - a0z);
-    } else {
-        v.x[i] += dt * (a.x[i] - a0x); v.y[i] += dt * (a.y[i] - a0y); v.z[i] += dt * (a.z[i] - a0z);
     }
 }
 
@@ -359,24 +362,23 @@ hipError_t launch_im_update(double* const fin[3], const double* const orig[3], d
     return hipGetLastError();
 }
 
-hipError_t launch_wh_drift(double* const x[3], double* const v[3], double mu, double h, long long n, double* star, bool exact, hipStream_t st) {
+// a == nullptr: drift only.  Otherwise kick by dtk with the accelerations in `a` (which are cleared), then drift.
+hipError_t launch_wh_drift(double* const x[3], double* const v[3], double* const a[3], double mu, double h, double dtk, long long n,
+                           double* star, bool exact, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     const Cols3 cx = {x[0], x[1], x[2]}, cv = {v[0], v[1], v[2]};
+    const Cols3 ca = a ? Cols3{a[0], a[1], a[2]} : Cols3{nullptr, nullptr, nullptr};
     const CCols3 ccv = {v[0], v[1], v[2]};
-    hipLaunchKernelGGL(wh_star_drift_kernel, dim3(1), dim3(64), 0, st, cx, ccv, h, star);
+    hipLaunchKernelGGL(wh_star_drift_kernel, dim3(1), dim3(64), 0, st, cx, ccv, ca, h, star);
     if (n > 1) {
-        if (exact) hipLaunchKernelGGL(wh_drift_kernel<true>, grid_for(n - 1), dim3(TB), 0, st, cx, cv, mu, h, n, star);
-        else hipLaunchKernelGGL(wh_drift_kernel<false>, grid_for(n - 1), dim3(TB), 0, st, cx, cv, mu, h, n, star);
+        if (a) {
+            if (exact) hipLaunchKernelGGL((wh_drift_kernel<true, true>), grid_for(n - 1), dim3(TB), 0, st, cx, cv, ca, mu, h, dtk, n, star);
+            else hipLaunchKernelGGL((wh_drift_kernel<false, true>), grid_for(n - 1), dim3(TB), 0, st, cx, cv, ca, mu, h, dtk, n, star);
+        } else {
+            if (exact) hipLaunchKernelGGL((wh_drift_kernel<true, false>), grid_for(n - 1), dim3(TB), 0, st, cx, cv, ca, mu, h, dtk, n, star);
+            else hipLaunchKernelGGL((wh_drift_kernel<false, false>), grid_for(n - 1), dim3(TB), 0, st, cx, cv, ca, mu, h, dtk, n, star);
+        }
     }
-    return hipGetLastError();
-}
-
-hipError_t launch_wh_kick(double* const v[3], const double* const a[3], double dt, long long n, bool exact, hipStream_t st) {
-    if (n <= 1) return hipSuccess;
-    const Cols3 cv = {v[0], v[1], v[2]};
-    const CCols3 ca = {a[0], a[1], a[2]};
-    if (exact) hipLaunchKernelGGL(wh_kick_kernel<true>, grid_for(n - 1), dim3(TB), 0, st, cv, ca, dt, n);
-    else hipLaunchKernelGGL(wh_kick_kernel<false>, grid_for(n - 1), dim3(TB), 0, st, cv, ca, dt, n);
     return hipGetLastError();
 }
 
