@@ -120,8 +120,11 @@ Bridge* bridge_of(const rebx_extras* rebx, bool create) {
     return b;
 }
 
+// A bridge that does not exist yet has nothing cached: it is created, with everything stale, by
+// the first call that needs the device.  (Creating one here would also leak it when a particle's
+// list is freed after its extras object.)
 void touch(const rebx_extras* rebx) {
-    if (Bridge* b = bridge_of(rebx, true)) b->generation++;
+    if (Bridge* b = bridge_of(rebx, false)) b->generation++;
 }
 
 void release_buffers(Bridge* b) {

@@ -283,3 +283,15 @@ def test_integrate_force_without_force_parameter_is_an_error():
     op = rebx.load_operator("integrate_force")
     with pytest.raises(RuntimeError, match="Force parameter not set"):
         op.step(sim, 0.1)
+
+
+def test_host_code_is_clean_under_address_sanitizer():
+    """Builds the library's host side with AddressSanitizer + LeakSanitizer (device code as is) with
+    tests/native/host_lifecycle.cpp -- attach, parameters, forces, operators and steps, binary
+    write/read, truncated files, teardown in REBOUND's order -- and runs it.  No GPU involved."""
+    import shutil
+    import subprocess
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc")
+    r = subprocess.run(["bash", os.path.join(ROOT, "scripts", "asan_check.sh")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "host lifecycle ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
