@@ -352,6 +352,27 @@ int rebxamd_apply_targets(rebxamd_ctx* ctx, const rebxamd_view* view, const rebx
                           int64_t target_lo, double* sums, void* stream);
 int rebxamd_add_pushes(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, const double* sums, void* stream);
 
+/* modify_orbits_forces in Jacobi or barycentric coordinates when the particles are sharded over
+ * devices and the slices hold massive bodies (no counterpart in the reference, which is one
+ * sequential loop: src/rebxtools.c:45-126).  Global order = [head | slice of rank 0 | slice of
+ * rank 1 | ...]; every device holds [head | its slice] and calls, for the range of the head
+ * [0, n_head) and for the range of its slice [n_head, n):
+ *   1. rebxamd_shard_sums        sums7 <- (m, m x, m y, m z, m vx, m vy, m vz) over the range
+ *      -> all-gather the slice sums;
+ *   2. rebxamd_shard_mof_forces  before7 = sums of every body that precedes the range in global
+ *      order (NULL = none) for Jacobi, sums of ALL bodies for barycentric; push3 <- summed
+ *      back-reaction of the range -> all-gather the slice pushes;
+ *   3. rebxamd_shard_mof_apply   after3 = pushes of every body that follows the range (NULL =
+ *      none) for Jacobi, pushes of ALL bodies for barycentric; adds to ax/ay/az of the range.
+ * All vectors live in device memory.  Steps 2 and 3 of one range must not be separated by other
+ * calls on the same context with a different view (the per-body terms are kept in between).
+ * reboundx_amd/dist.py (mof_com_sharded) is the driver. */
+int rebxamd_shard_sums(rebxamd_ctx* ctx, const rebxamd_view* view, int64_t lo, int64_t hi, double* sums7, void* stream);
+int rebxamd_shard_mof_forces(rebxamd_ctx* ctx, const rebxamd_view* view, int coordinates, int64_t lo, int64_t hi,
+                             const double* before7, double* push3, void* stream);
+int rebxamd_shard_mof_apply(rebxamd_ctx* ctx, const rebxamd_view* view, int coordinates, int64_t lo, int64_t hi, const double* after3,
+                            void* stream);
+
 /* src/core.c:860-866 on device columns. */
 int rebxamd_reset_accelerations(rebxamd_ctx* ctx, const rebxamd_view* view, void* stream);
 

@@ -25,6 +25,8 @@ struct rebxamd_ctx {
     double* star = nullptr;             // 16 doubles: state of body 0 around a Wisdom-Holman drift
     double* integ = nullptr;            // stage columns of the force integrators
     size_t integ_cap = 0;
+    double* shard = nullptr;            // per-range forces and reactions of the sharded Jacobi/barycentric modify_orbits_forces
+    size_t shard_cap = 0;
     double* scan = nullptr;             // workspace of the prefix/suffix-sum passes (gr, Jacobi/barycentric mof, any layout)
     size_t scan_cap = 0;
     // optional timing of the dominant kernels with HIP events on the launch stream
@@ -103,6 +105,7 @@ extern "C" void rebxamd_destroy(rebxamd_ctx* ctx) {
     if (ctx->star) (void)hipFree(ctx->star);
     if (ctx->chunk_sums) (void)hipFree(ctx->chunk_sums);
     if (ctx->scan) (void)hipFree(ctx->scan);
+    if (ctx->shard) (void)hipFree(ctx->shard);
     if (ctx->integ) (void)hipFree(ctx->integ);
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     delete ctx;
@@ -568,6 +571,82 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
         }
         HIP_TRY(launch_wh_drift(x, v, a, mu, k + 1 < nsteps ? dt : 0.5 * dt, dt, view->n, ctx->star, exact, st));
     }
+    return REBXAMD_OK;
+}
+
+// ------------------------------------------------------------------ Jacobi/barycentric modify_orbits_forces on particle shards
+
+static View sub_view(const rebxamd_view* u, long long lo, long long hi) {
+    View v = make_view(u);
+    auto off = [lo](const double* p) { return p ? p + lo : p; };
+    v.n = hi - lo; v.n_head = 0;
+    v.x = off(v.x); v.y = off(v.y); v.z = off(v.z); v.vx = off(v.vx); v.vy = off(v.vy); v.vz = off(v.vz); v.m = off(v.m);
+    v.ax = v.ax ? v.ax + lo : nullptr; v.ay = v.ay ? v.ay + lo : nullptr; v.az = v.az ? v.az + lo : nullptr;
+    v.beta = off(v.beta); v.Rt = off(v.Rt); v.k1 = off(v.k1); v.ta = off(v.ta); v.te = off(v.te); v.ti = off(v.ti);
+    return v;
+}
+
+static int shard_check(rebxamd_ctx* ctx, const rebxamd_view* view, int64_t lo, int64_t hi, const char* who) {
+    if (!ctx) return REBXAMD_ERR_ARG;
+    if (!view || lo < 0 || hi < lo || hi > view->n) return fail(ctx, REBXAMD_ERR_ARG, who);
+    if (view->n > 0 && (!view->x || !view->y || !view->z || !view->vx || !view->vy || !view->vz || !view->m))
+        return fail(ctx, REBXAMD_ERR_ARG, "position/velocity/mass columns missing");
+    return REBXAMD_OK;
+}
+
+// the range that starts at 0 and the range behind it keep separate halves of the workspace
+static int shard_workspace(rebxamd_ctx* ctx, const rebxamd_view* view, int64_t lo, hipStream_t st, double** ws) {
+    const size_t half = scan_range_doubles(view->n);
+    const int rc = ensure(ctx, &ctx->shard, &ctx->shard_cap, 2 * half * sizeof(double), st);
+    if (rc != REBXAMD_OK) return rc;
+    *ws = ctx->shard + (lo == 0 ? 0 : half);
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_shard_sums(rebxamd_ctx* ctx, const rebxamd_view* view, int64_t lo, int64_t hi, double* sums7, void* stream) {
+    int rc = shard_check(ctx, view, lo, hi, "rebxamd_shard_sums: bad argument");
+    if (rc != REBXAMD_OK) return rc;
+    if (!sums7) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_shard_sums: no output");
+    HIP_TRY(hipSetDevice(ctx->device));
+    double* ws = nullptr;
+    rc = shard_workspace(ctx, view, lo, (hipStream_t)stream, &ws);
+    if (rc != REBXAMD_OK) return rc;
+    HIP_TRY(launch_range_sums(sub_view(view, lo, hi), ws, sums7, (hipStream_t)stream));
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_shard_mof_forces(rebxamd_ctx* ctx, const rebxamd_view* view, int coordinates, int64_t lo, int64_t hi,
+                                        const double* before7, double* push3, void* stream) {
+    int rc = shard_check(ctx, view, lo, hi, "rebxamd_shard_mof_forces: bad argument");
+    if (rc != REBXAMD_OK) return rc;
+    if (coordinates != REBX_COORDINATES_JACOBI && coordinates != REBX_COORDINATES_BARYCENTRIC)
+        return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_shard_mof_forces: Jacobi or barycentric coordinates only");
+    if (!push3 || (coordinates == REBX_COORDINATES_BARYCENTRIC && !before7)) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_shard_mof_forces: missing vector");
+    HIP_TRY(hipSetDevice(ctx->device));
+    double* ws = nullptr;
+    rc = shard_workspace(ctx, view, lo, (hipStream_t)stream, &ws);
+    if (rc != REBXAMD_OK) return rc;
+    DevOp op;
+    memset(&op, 0, sizeof(op));
+    op.kind = REBXAMD_OP_MOF; op.src = -1; op.iarg = coordinates; op.slot = -1;
+    HIP_TRY(launch_range_mof_forces(sub_view(view, lo, hi), op, view->G, coordinates == REBX_COORDINATES_BARYCENTRIC, lo == 0, before7, ws, push3,
+                                    (hipStream_t)stream));
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_shard_mof_apply(rebxamd_ctx* ctx, const rebxamd_view* view, int coordinates, int64_t lo, int64_t hi, const double* after3,
+                                       void* stream) {
+    int rc = shard_check(ctx, view, lo, hi, "rebxamd_shard_mof_apply: bad argument");
+    if (rc != REBXAMD_OK) return rc;
+    if (coordinates != REBX_COORDINATES_JACOBI && coordinates != REBX_COORDINATES_BARYCENTRIC)
+        return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_shard_mof_apply: Jacobi or barycentric coordinates only");
+    if (view->n > 0 && (!view->ax || !view->ay || !view->az)) return fail(ctx, REBXAMD_ERR_ARG, "acceleration columns missing");
+    if (coordinates == REBX_COORDINATES_BARYCENTRIC && !after3) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_shard_mof_apply: missing vector");
+    HIP_TRY(hipSetDevice(ctx->device));
+    double* ws = nullptr;
+    rc = shard_workspace(ctx, view, lo, (hipStream_t)stream, &ws);
+    if (rc != REBXAMD_OK) return rc;
+    HIP_TRY(launch_range_mof_apply(sub_view(view, lo, hi), coordinates == REBX_COORDINATES_BARYCENTRIC, after3, ws, (hipStream_t)stream));
     return REBXAMD_OK;
 }
 

@@ -144,7 +144,7 @@ template <int KIND, bool EXACT>
 __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, const double* nax, const double* nay, const double* naz,
                                                 const double* blocksums, const double* totals,
                                                 double* ajx, double* ajy, double* ajz, double* wx, double* wy, double* wz,
-                                                double* wsums, unsigned* status) {
+                                                double* wsums, unsigned* status, const double* pre, long long first_acting) {
     constexpr int C = (KIND == SCAN_GR) ? 10 : 7;
     __shared__ double lds[SW][C];
     __shared__ double lds3[SW][3];
@@ -162,14 +162,17 @@ __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, cons
     if (live) {
         double S[C];        // exclusive prefix (bodies before i), or the grand total for barycentric
 #pragma unroll
-        for (int c = 0; c < C; c++) S[c] = (KIND == SCAN_MOF_BARY) ? totals[c] : blocksums[(long long)blockIdx.x * C + c] + (q[c] - own[c]);
+        for (int c = 0; c < C; c++) {
+            S[c] = (KIND == SCAN_MOF_BARY) ? totals[c] : blocksums[(long long)blockIdx.x * C + c] + (q[c] - own[c]);
+            if (KIND != SCAN_MOF_BARY && pre != nullptr) S[c] += pre[c];      // bodies that precede this view (other shards, the head)
+        }
         const double eta = S[0], mi = own[0];
         Part p;
         p.x = v.x[i]; p.y = v.y[i]; p.z = v.z[i]; p.vx = v.vx[i]; p.vy = v.vy[i]; p.vz = v.vz[i]; p.m = mi;
         p.beta = p.Rt = p.k1 = __builtin_nan("");
         p.ta = v.ta ? v.ta[i] : __builtin_nan(""); p.te = v.te ? v.te[i] : __builtin_nan(""); p.ti = v.ti ? v.ti[i] : __builtin_nan("");
         if constexpr (KIND == SCAN_GR) {
-            if (i >= 1) {
+            if (i >= first_acting) {
                 const double ei = 1. / eta;
                 Jac j;
                 j.x = p.x - S[1] * ei; j.y = p.y - S[2] * ei; j.z = p.z - S[3] * ei;
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, cons
                 w[0] = f * a.x; w[1] = f * a.y; w[2] = f * a.z;
             }
         } else {
-            const bool acts = (KIND == SCAN_MOF_BARY) || i >= 1;
+            const bool acts = (KIND == SCAN_MOF_BARY) || i >= first_acting;
             if (acts) {
                 Src ref;
                 const double inv = eta > 0. ? 1. / eta : 1.;
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, cons
 template <bool TOTAL>
 __global__ __launch_bounds__(SB) void scan_apply(View v, const double* ajx, const double* ajy, const double* ajz,
                                                  const double* wx, const double* wy, const double* wz,
-                                                 const double* wsums_excl, const double* wtotals) {
+                                                 const double* wsums_excl, const double* wtotals, const double* suf) {
     __shared__ double lds3[SW][3];
     const long long i = (long long)blockIdx.x * SB + threadIdx.x;
     const bool live = i < v.n;
@@ -219,6 +222,7 @@ __global__ __launch_bounds__(SB) void scan_apply(View v, const double* ajx, cons
             s0 = w[0] + wsums_excl[(long long)blockIdx.x * 3 + 0];
             s1 = w[1] + wsums_excl[(long long)blockIdx.x * 3 + 1];
             s2 = w[2] + wsums_excl[(long long)blockIdx.x * 3 + 2];
+            if (suf != nullptr) { s0 += suf[0]; s1 += suf[1]; s2 += suf[2]; }     // bodies that follow this view
         }
         v.ax[i] += ajx[i] - s0; v.ay[i] += ajy[i] - s1; v.az[i] += ajz[i] - s2;
     }
@@ -396,23 +400,76 @@ hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, 
         else hipLaunchKernelGGL(newton_from_compact<false>, g, b, 0, st, v, cx, cy, cz, cgm, cidx, count, nax, nay, naz);
         hipLaunchKernelGGL(scan_block_totals<10>, g, b, 0, st, v, nax, nay, naz, bs);
         hipLaunchKernelGGL((scan_of_totals<10, false>), dim3(1), dim3(1024), 0, st, bs, nb, totals);
-        if (exact) hipLaunchKernelGGL((scan_main<SCAN_GR, true>), g, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status);
-        else hipLaunchKernelGGL((scan_main<SCAN_GR, false>), g, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status);
+        if (exact) hipLaunchKernelGGL((scan_main<SCAN_GR, true>), g, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL);
+        else hipLaunchKernelGGL((scan_main<SCAN_GR, false>), g, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL);
     } else {
         hipLaunchKernelGGL(scan_block_totals<7>, g, b, 0, st, v, nax, nay, naz, bs);
         hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(1024), 0, st, bs, nb, totals);
-        if (kind == SCAN_MOF_JACOBI) hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), g, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status);
-        else hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), g, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status);
+        if (kind == SCAN_MOF_JACOBI) hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), g, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL);
+        else hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), g, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL);
     }
     hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(1), dim3(1024), 0, st, wsum, nb, wtot);
-    if (kind == SCAN_MOF_BARY) hipLaunchKernelGGL(scan_apply<true>, g, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, wsum, wtot);
-    else hipLaunchKernelGGL(scan_apply<false>, g, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, wsum, wtot);
+    if (kind == SCAN_MOF_BARY) hipLaunchKernelGGL(scan_apply<true>, g, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, wsum, wtot, (const double*)nullptr);
+    else hipLaunchKernelGGL(scan_apply<false>, g, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, wsum, wtot, (const double*)nullptr);
     return hipGetLastError();
 }
 
 }  // namespace rebxamd
 
 namespace rebxamd {
+
+// ---- pieces of the Jacobi/barycentric modify_orbits_forces for particle shards.  `v` is the
+// sub-view of one contiguous range (column pointers already offset, n = its length); `ws` is the
+// workspace slice that belongs to the same range (6 columns of v.n doubles, then block sums).
+static inline long long blocks_of(long long n) { return (n + SB - 1) / SB; }
+size_t scan_range_doubles(long long n) { return (size_t)(6 * n + 10 * blocks_of(n) + 16); }
+
+// sums7 <- (m, m x, m y, m z, m vx, m vy, m vz) summed over the range
+hipError_t launch_range_sums(const View& v, double* ws, double* sums7, hipStream_t st) {
+    if (v.n <= 0) return hipMemsetAsync(sums7, 0, 7 * sizeof(double), st);
+    const long long nb = blocks_of(v.n);
+    double* bs = ws + 6 * v.n;
+    hipLaunchKernelGGL(scan_block_totals<7>, dim3((unsigned)nb), dim3(SB), 0, st, v, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, bs);
+    hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(1024), 0, st, bs, nb, sums7);
+    return hipGetLastError();
+}
+
+// own forces and weighted reactions of the range (kept in ws); push3 <- sum of the reactions.
+// before7: Jacobi = sums of every body that precedes the range; barycentric = sums of ALL bodies.
+hipError_t launch_range_mof_forces(const View& v, const DevOp& op, double G, bool barycentric, bool starts_at_origin, const double* before7,
+                                   double* ws, double* push3, hipStream_t st) {
+    if (v.n <= 0) return hipMemsetAsync(push3, 0, 3 * sizeof(double), st);
+    const long long n = v.n, nb = blocks_of(n);
+    double* ajx = ws; double* ajy = ajx + n; double* ajz = ajy + n; double* wx = ajz + n; double* wy = wx + n; double* wz = wy + n;
+    double* bs = wz + n;                    // nb * 7
+    double* wsum = bs + 7 * nb;             // nb * 3
+    double* scratch = wsum + 3 * nb;        // 16
+    const dim3 g((unsigned)nb), b(SB);
+    const double* none = nullptr;
+    hipLaunchKernelGGL(scan_block_totals<7>, g, b, 0, st, v, none, none, none, bs);
+    hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(1024), 0, st, bs, nb, scratch);
+    if (barycentric)
+        hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), g, b, 0, st, v, op, G, none, none, none, (const double*)bs, before7, ajx, ajy, ajz, wx, wy, wz, wsum,
+                           (unsigned*)nullptr, none, 0LL);
+    else
+        hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), g, b, 0, st, v, op, G, none, none, none, (const double*)bs, (const double*)scratch, ajx, ajy, ajz, wx, wy, wz, wsum,
+                           (unsigned*)nullptr, before7, starts_at_origin ? 1LL : 0LL);
+    hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(1), dim3(1024), 0, st, wsum, nb, push3);
+    return hipGetLastError();
+}
+
+// a_i += own_i - (reactions of the bodies from i on).  after3: Jacobi = reactions of every body
+// that follows the range; barycentric = reactions of ALL bodies.
+hipError_t launch_range_mof_apply(const View& v, bool barycentric, const double* after3, double* ws, hipStream_t st) {
+    if (v.n <= 0) return hipSuccess;
+    const long long n = v.n, nb = blocks_of(n);
+    double* ajx = ws; double* ajy = ajx + n; double* ajz = ajy + n; double* wx = ajz + n; double* wy = wx + n; double* wz = wy + n;
+    double* wsum = wz + n + 7 * nb;
+    const dim3 g((unsigned)nb), b(SB);
+    if (barycentric) hipLaunchKernelGGL(scan_apply<true>, g, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, (const double*)wsum, after3, (const double*)nullptr);
+    else hipLaunchKernelGGL(scan_apply<false>, g, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, (const double*)wsum, (const double*)nullptr, after3);
+    return hipGetLastError();
+}
 
 // out (device, 3 doubles): kinetic, Newtonian potential, post-Newtonian potential times c^2
 hipError_t launch_gr_hamiltonian(const View& v, double G, double c, double* ws, double* out, hipStream_t st) {

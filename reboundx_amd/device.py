@@ -123,6 +123,17 @@ class Context:
     def drift(self, view, dt, mode=_lib.MODE_FAST):
         self._check(lib.rebxamd_drift(self._h, ctypes.byref(view), float(dt), mode, self._stream()))
 
+    def shard_sums(self, view, lo, hi, out7):
+        self._check(lib.rebxamd_shard_sums(self._h, ctypes.byref(view), lo, hi, out7.data_ptr(), self._stream()))
+
+    def shard_mof_forces(self, view, coordinates, lo, hi, before7, push3):
+        self._check(lib.rebxamd_shard_mof_forces(self._h, ctypes.byref(view), coordinates, lo, hi,
+                                                 before7.data_ptr() if before7 is not None else None, push3.data_ptr(), self._stream()))
+
+    def shard_mof_apply(self, view, coordinates, lo, hi, after3):
+        self._check(lib.rebxamd_shard_mof_apply(self._h, ctypes.byref(view), coordinates, lo, hi,
+                                                after3.data_ptr() if after3 is not None else None, self._stream()))
+
     def reset_accelerations(self, view):
         self._check(lib.rebxamd_reset_accelerations(self._h, ctypes.byref(view), self._stream()))
 

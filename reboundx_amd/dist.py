@@ -36,6 +36,16 @@ def apply_forces_sharded(ctx, particles, ops, mode=0, group=None):
     the slice locally, and each op's push on its source particle is summed over ranks with one
     small all-reduce (3 doubles per op)."""
     import torch.distributed as dist
+    from ._lib import OP_MOF
+    com = [o for o in ops if o.kind == OP_MOF and o.iarg in (0, 1)]
+    if com:
+        # Jacobi/barycentric modify_orbits_forces are prefix/suffix sums over the global order: they
+        # run as passes of their own (no op reads accelerations, so only the order of additions changes)
+        rest = [o for o in ops if not (o.kind == OP_MOF and o.iarg in (0, 1))]
+        sums = apply_forces_sharded(ctx, particles, rest, mode, group) if rest else None
+        for o in com:
+            mof_com_sharded(ctx, particles, o.iarg, group)
+        return sums
     view = particles.view()
     ctx.apply(particles.head_view(), ops, mode)                   # head on head, with its own back-reactions
     sums = torch.zeros(3 * len(ops), dtype=torch.float64, device=particles.cols["x"].device)
@@ -44,6 +54,48 @@ def apply_forces_sharded(ctx, particles, ops, mode=0, group=None):
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
     ctx.add_pushes(view, ops, sums)
     return sums
+
+
+def mof_com_sharded(ctx, particles, coordinates, group=None, exchange=None):
+    """modify_orbits_forces in Jacobi (0) or barycentric (1) coordinates on [replicated head |
+    this rank's slice] with massive slices: two tiny all-gathers (7 and 3 doubles per rank) carry
+    the prefix sums and the back-reactions across ranks.  `exchange(vec)` -> (world, len) tensor
+    and rank, overriding torch.distributed (used by tests that run the ranks one after the other)."""
+    import torch.distributed as dist
+    view = particles.view()
+    K, n = particles.n_head, particles.n
+    dev = particles.cols["x"].device
+
+    def gather(vec):
+        if exchange is not None:
+            return exchange(vec)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+            out = torch.empty(world * vec.numel(), dtype=vec.dtype, device=vec.device)
+            dist.all_gather_into_tensor(out, vec.contiguous(), group=group)
+            return out.view(world, -1), rank
+        return vec.view(1, -1), 0
+
+    z = lambda k: torch.zeros(k, dtype=torch.float64, device=dev)
+    head_sums, slice_sums = z(7), z(7)
+    ctx.shard_sums(view, 0, K, head_sums)
+    ctx.shard_sums(view, K, n, slice_sums)
+    all_sums, rank = gather(slice_sums)
+    bary = coordinates == 1
+    if bary:
+        before_head = before_slice = head_sums + all_sums.sum(dim=0)
+    else:
+        before_head, before_slice = None, head_sums + all_sums[:rank].sum(dim=0)
+    head_push, slice_push = z(3), z(3)
+    ctx.shard_mof_forces(view, coordinates, 0, K, before_head, head_push)
+    ctx.shard_mof_forces(view, coordinates, K, n, before_slice, slice_push)
+    all_push, rank = gather(slice_push)
+    if bary:
+        after_head = after_slice = head_push + all_push.sum(dim=0)
+    else:
+        after_head, after_slice = all_push.sum(dim=0), all_push[rank + 1:].sum(dim=0)
+    ctx.shard_mof_apply(view, coordinates, 0, K, after_head)
+    ctx.shard_mof_apply(view, coordinates, K, n, after_slice)
 
 
 class HipGrFullEngine:
