@@ -23,6 +23,8 @@ namespace rebxamd {
 
 static constexpr int SB = 256;          // elements per scan workgroup (one per thread)
 static constexpr int SW = SB / 64;
+static constexpr int ST = 8;            // tiles of SB elements per workgroup in the weighted-sum passes: short lists of workgroup totals
+static constexpr int SCHUNK = SB * ST;
 
 enum ScanKind { SCAN_GR = 0, SCAN_MOF_JACOBI = 1, SCAN_MOF_BARY = 2 };
 
@@ -69,6 +71,26 @@ __device__ __forceinline__ void block_scan(double (&v)[C], double (&tot)[C], dou
     }
 }
 
+// Workgroup total of C per-thread values (fixed order: lanes by shuffle tree, then waves in order); valid in thread 0.
+template <int C>
+__device__ __forceinline__ void block_total(double (&v)[C], double (*lds)[C]) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int c = 0; c < C; c++)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[c] += __shfl_down(v[c], off, 64);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < C; c++) lds[wave][c] = v[c];
+    }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int c = 0; c < C; c++) { double t = 0.; for (int w = 0; w < SW; w++) t += lds[w][c]; v[c] = t; }
+    }
+}
+
 // ---- per-element quantities that get scanned
 template <int C>
 __device__ __forceinline__ void weighted_state(const View& v, const double* nax, const double* nay, const double* naz, long long i, double (&q)[C]) {
@@ -79,19 +101,26 @@ __device__ __forceinline__ void weighted_state(const View& v, const double* nax,
     if constexpr (C == 10) { q[7] = m * nax[i]; q[8] = m * nay[i]; q[9] = m * naz[i]; }
 }
 
-// pass 1: workgroup totals of the weighted state
+// pass 1: workgroup totals of the weighted state (a workgroup covers ST tiles of SB bodies)
 template <int C>
 __global__ __launch_bounds__(SB) void scan_block_totals(View v, const double* nax, const double* nay, const double* naz, double* blocksums) {
     __shared__ double lds[SW][C];
-    const long long i = (long long)blockIdx.x * SB + threadIdx.x;
-    double q[C], tot[C];
+    double acc[C];
 #pragma unroll
-    for (int c = 0; c < C; c++) q[c] = 0.;
-    if (i < v.n) weighted_state<C>(v, nax, nay, naz, i, q);
-    block_scan<C, false>(q, tot, lds);
+    for (int c = 0; c < C; c++) acc[c] = 0.;
+    for (int t = 0; t < ST; t++) {
+        const long long i = (long long)blockIdx.x * SCHUNK + t * SB + threadIdx.x;
+        if (i < v.n) {
+            double q[C];
+            weighted_state<C>(v, nax, nay, naz, i, q);
+#pragma unroll
+            for (int c = 0; c < C; c++) acc[c] += q[c];
+        }
+    }
+    block_total<C>(acc, lds);
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int c = 0; c < C; c++) blocksums[(long long)blockIdx.x * C + c] = tot[c];
+        for (int c = 0; c < C; c++) blocksums[(long long)blockIdx.x * C + c] = acc[c];
     }
 }
 
@@ -148,60 +177,68 @@ __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, cons
     constexpr int C = (KIND == SCAN_GR) ? 10 : 7;
     __shared__ double lds[SW][C];
     __shared__ double lds3[SW][3];
-    const long long i = (long long)blockIdx.x * SB + threadIdx.x;
-    const bool live = i < v.n;
-    double q[C], own[C], tot[C];
+    double carry[C];            // sum over the tiles of this workgroup already passed
+    double wacc[3] = {0., 0., 0.};
 #pragma unroll
-    for (int c = 0; c < C; c++) q[c] = 0.;
-    if (live) weighted_state<C>(v, nax, nay, naz, i, q);
+    for (int c = 0; c < C; c++) carry[c] = 0.;
+    for (int t = 0; t < ST; t++) {
+        const long long i = (long long)blockIdx.x * SCHUNK + t * SB + threadIdx.x;
+        const bool live = i < v.n;
+        double q[C], own[C], tot[C];
 #pragma unroll
-    for (int c = 0; c < C; c++) own[c] = q[c];
-    block_scan<C, false>(q, tot, lds);
-    V3 a = {0., 0., 0.};
-    double w[3] = {0., 0., 0.};
-    if (live) {
-        double S[C];        // exclusive prefix (bodies before i), or the grand total for barycentric
+        for (int c = 0; c < C; c++) q[c] = 0.;
+        if (live) weighted_state<C>(v, nax, nay, naz, i, q);
 #pragma unroll
-        for (int c = 0; c < C; c++) {
-            S[c] = (KIND == SCAN_MOF_BARY) ? totals[c] : blocksums[(long long)blockIdx.x * C + c] + (q[c] - own[c]);
-            if (KIND != SCAN_MOF_BARY && pre != nullptr) S[c] += pre[c];      // bodies that precede this view (other shards, the head)
-        }
-        const double eta = S[0], mi = own[0];
-        Part p;
-        p.x = v.x[i]; p.y = v.y[i]; p.z = v.z[i]; p.vx = v.vx[i]; p.vy = v.vy[i]; p.vz = v.vz[i]; p.m = mi;
-        p.beta = p.Rt = p.k1 = __builtin_nan("");
-        p.ta = v.ta ? v.ta[i] : __builtin_nan(""); p.te = v.te ? v.te[i] : __builtin_nan(""); p.ti = v.ti ? v.ti[i] : __builtin_nan("");
-        if constexpr (KIND == SCAN_GR) {
-            if (i >= first_acting) {
-                const double ei = 1. / eta;
-                Jac j;
-                j.x = p.x - S[1] * ei; j.y = p.y - S[2] * ei; j.z = p.z - S[3] * ei;
-                j.vx = p.vx - S[4] * ei; j.vy = p.vy - S[5] * ei; j.vz = p.vz - S[6] * ei;
-                j.ax = nax[i] - S[7] * ei; j.ay = nay[i] - S[8] * ei; j.az = naz[i] - S[9] * ei;
-                const double mu = G * v.m[0];
-                const int it = EXACT ? gr_term_exact(j, mu, op.c, op.iarg, a)
-                                     : gr_term_fast(j, fast_rsqrt(j.x * j.x + j.y * j.y + j.z * j.z), mu, op.d, op.iarg, a);
-                if (it == 10) atomicOr(status, WARN_GR_ITER);
-                const double f = mi / (eta + mi);
-                w[0] = f * a.x; w[1] = f * a.y; w[2] = f * a.z;
+        for (int c = 0; c < C; c++) own[c] = q[c];
+        block_scan<C, false>(q, tot, lds);
+        if (live) {
+            V3 a = {0., 0., 0.};
+            double w[3] = {0., 0., 0.};
+            double S[C];        // exclusive prefix (bodies before i), or the grand total for barycentric
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                S[c] = (KIND == SCAN_MOF_BARY) ? totals[c] : blocksums[(long long)blockIdx.x * C + c] + carry[c] + (q[c] - own[c]);
+                if (KIND != SCAN_MOF_BARY && pre != nullptr) S[c] += pre[c];      // bodies that precede this view (other shards, the head)
             }
-        } else {
-            const bool acts = (KIND == SCAN_MOF_BARY) || i >= first_acting;
-            if (acts) {
-                Src ref;
-                const double inv = eta > 0. ? 1. / eta : 1.;
-                ref.x = S[1] * inv; ref.y = S[2] * inv; ref.z = S[3] * inv; ref.vx = S[4] * inv; ref.vy = S[5] * inv; ref.vz = S[6] * inv; ref.m = eta;
-                mof_exact(p, ref, a);
-                const double f = (KIND == SCAN_MOF_BARY) ? mi / eta : mi / (eta + mi);
-                w[0] = f * a.x; w[1] = f * a.y; w[2] = f * a.z;
+            const double eta = S[0], mi = own[0];
+            Part p;
+            p.x = v.x[i]; p.y = v.y[i]; p.z = v.z[i]; p.vx = v.vx[i]; p.vy = v.vy[i]; p.vz = v.vz[i]; p.m = mi;
+            p.beta = p.Rt = p.k1 = __builtin_nan("");
+            p.ta = v.ta ? v.ta[i] : __builtin_nan(""); p.te = v.te ? v.te[i] : __builtin_nan(""); p.ti = v.ti ? v.ti[i] : __builtin_nan("");
+            if constexpr (KIND == SCAN_GR) {
+                if (i >= first_acting) {
+                    const double ei = 1. / eta;
+                    Jac j;
+                    j.x = p.x - S[1] * ei; j.y = p.y - S[2] * ei; j.z = p.z - S[3] * ei;
+                    j.vx = p.vx - S[4] * ei; j.vy = p.vy - S[5] * ei; j.vz = p.vz - S[6] * ei;
+                    j.ax = nax[i] - S[7] * ei; j.ay = nay[i] - S[8] * ei; j.az = naz[i] - S[9] * ei;
+                    const double mu = G * v.m[0];
+                    const int it = EXACT ? gr_term_exact(j, mu, op.c, op.iarg, a)
+                                         : gr_term_fast(j, fast_rsqrt(j.x * j.x + j.y * j.y + j.z * j.z), mu, op.d, op.iarg, a);
+                    if (it == 10) atomicOr(status, WARN_GR_ITER);
+                    const double f = mi / (eta + mi);
+                    w[0] = f * a.x; w[1] = f * a.y; w[2] = f * a.z;
+                }
+            } else {
+                const bool acts = (KIND == SCAN_MOF_BARY) || i >= first_acting;
+                if (acts) {
+                    Src ref;
+                    const double inv = eta > 0. ? 1. / eta : 1.;
+                    ref.x = S[1] * inv; ref.y = S[2] * inv; ref.z = S[3] * inv; ref.vx = S[4] * inv; ref.vy = S[5] * inv; ref.vz = S[6] * inv; ref.m = eta;
+                    mof_exact(p, ref, a);
+                    const double f = (KIND == SCAN_MOF_BARY) ? mi / eta : mi / (eta + mi);
+                    w[0] = f * a.x; w[1] = f * a.y; w[2] = f * a.z;
+                }
             }
+            ajx[i] = a.x; ajy[i] = a.y; ajz[i] = a.z;
+            wx[i] = w[0]; wy[i] = w[1]; wz[i] = w[2];
+            wacc[0] += w[0]; wacc[1] += w[1]; wacc[2] += w[2];
         }
-        ajx[i] = a.x; ajy[i] = a.y; ajz[i] = a.z;
-        wx[i] = w[0]; wy[i] = w[1]; wz[i] = w[2];
+#pragma unroll
+        for (int c = 0; c < C; c++) carry[c] += tot[c];
     }
-    double wt[3];
-    block_scan<3, true>(w, wt, lds3);
-    if (threadIdx.x == 0) { wsums[(long long)blockIdx.x * 3 + 0] = wt[0]; wsums[(long long)blockIdx.x * 3 + 1] = wt[1]; wsums[(long long)blockIdx.x * 3 + 2] = wt[2]; }
+    block_total<3>(wacc, lds3);
+    if (threadIdx.x == 0) { wsums[(long long)blockIdx.x * 3 + 0] = wacc[0]; wsums[(long long)blockIdx.x * 3 + 1] = wacc[1]; wsums[(long long)blockIdx.x * 3 + 2] = wacc[2]; }
 }
 
 // pass 5: a_i += aJ_i - (sum of w over bodies k >= i)   [barycentric: over all bodies]
@@ -210,21 +247,25 @@ __global__ __launch_bounds__(SB) void scan_apply(View v, const double* ajx, cons
                                                  const double* wx, const double* wy, const double* wz,
                                                  const double* wsums_excl, const double* wtotals, const double* suf) {
     __shared__ double lds3[SW][3];
-    const long long i = (long long)blockIdx.x * SB + threadIdx.x;
-    const bool live = i < v.n;
-    double w[3] = {0., 0., 0.}, wt[3];
-    if (live && !TOTAL) { w[0] = wx[i]; w[1] = wy[i]; w[2] = wz[i]; }
-    if (!TOTAL) block_scan<3, true>(w, wt, lds3);
-    if (live) {
-        double s0, s1, s2;
-        if (TOTAL) { s0 = wtotals[0]; s1 = wtotals[1]; s2 = wtotals[2]; }
-        else {
-            s0 = w[0] + wsums_excl[(long long)blockIdx.x * 3 + 0];
-            s1 = w[1] + wsums_excl[(long long)blockIdx.x * 3 + 1];
-            s2 = w[2] + wsums_excl[(long long)blockIdx.x * 3 + 2];
-            if (suf != nullptr) { s0 += suf[0]; s1 += suf[1]; s2 += suf[2]; }     // bodies that follow this view
+    double carry[3] = {0., 0., 0.};         // reactions of the later tiles of this workgroup
+    for (int t = ST - 1; t >= 0; t--) {
+        const long long i = (long long)blockIdx.x * SCHUNK + t * SB + threadIdx.x;
+        const bool live = i < v.n;
+        double w[3] = {0., 0., 0.}, wt[3] = {0., 0., 0.};
+        if (live && !TOTAL) { w[0] = wx[i]; w[1] = wy[i]; w[2] = wz[i]; }
+        if (!TOTAL) block_scan<3, true>(w, wt, lds3);
+        if (live) {
+            double s0, s1, s2;
+            if (TOTAL) { s0 = wtotals[0]; s1 = wtotals[1]; s2 = wtotals[2]; }
+            else {
+                s0 = w[0] + carry[0] + wsums_excl[(long long)blockIdx.x * 3 + 0];
+                s1 = w[1] + carry[1] + wsums_excl[(long long)blockIdx.x * 3 + 1];
+                s2 = w[2] + carry[2] + wsums_excl[(long long)blockIdx.x * 3 + 2];
+                if (suf != nullptr) { s0 += suf[0]; s1 += suf[1]; s2 += suf[2]; }     // bodies that follow this view
+            }
+            v.ax[i] += ajx[i] - s0; v.ay[i] += ajy[i] - s1; v.az[i] += ajz[i] - s2;
         }
-        v.ax[i] += ajx[i] - s0; v.ay[i] += ajy[i] - s1; v.az[i] += ajz[i] - s2;
+        carry[0] += wt[0]; carry[1] += wt[1]; carry[2] += wt[2];
     }
 }
 
@@ -317,53 +358,58 @@ __global__ __launch_bounds__(SB) void gr_hamiltonian_main(View v, double G, doub
                                                          const double* totals, double* partials) {
     __shared__ double lds[SW][7];
     __shared__ double lds3[SW][3];
-    const long long i = (long long)blockIdx.x * SB + threadIdx.x;
-    const bool live = i < v.n;
-    double q[7], own[7], tot[7];
+    double carry[7] = {0., 0., 0., 0., 0., 0., 0.};
+    double e[3] = {0., 0., 0.};
+    for (int t = 0; t < ST; t++) {
+        const long long i = (long long)blockIdx.x * SCHUNK + t * SB + threadIdx.x;
+        const bool live = i < v.n;
+        double q[7], own[7], tot[7];
 #pragma unroll
-    for (int c = 0; c < 7; c++) q[c] = 0.;
-    if (live) weighted_state<7>(v, nullptr, nullptr, nullptr, i, q);
+        for (int c = 0; c < 7; c++) q[c] = 0.;
+        if (live) weighted_state<7>(v, nullptr, nullptr, nullptr, i, q);
 #pragma unroll
-    for (int c = 0; c < 7; c++) own[c] = q[c];
-    block_scan<7, false>(q, tot, lds);
-    double e[3] = {0., 0., 0.}, et[3];
-    if (live) {
+        for (int c = 0; c < 7; c++) own[c] = q[c];
+        block_scan<7, false>(q, tot, lds);
+        if (live) {
 #pragma clang fp contract(off)
-        const double mi = own[0];
-        e[1] = -0.5 * mi * pot[i];                     // each pair is seen from both ends
-        if (i == 0) {
-            // Jacobi "body" 0 is the centre of mass carrying the total mass (gr.c:219)
-            const double M = totals[0], iM = 1. / M;
-            const double vx = totals[4] * iM, vy = totals[5] * iM, vz = totals[6] * iM;
-            e[0] = 0.5 * M * (vx * vx + vy * vy + vz * vz);
-        } else {
-            double S[7];
+            const double mi = own[0];
+            e[1] += -0.5 * mi * pot[i];                    // each pair is seen from both ends
+            if (i == 0) {
+                // Jacobi "body" 0 is the centre of mass carrying the total mass (gr.c:219)
+                const double M = totals[0], iM = 1. / M;
+                const double vx = totals[4] * iM, vy = totals[5] * iM, vz = totals[6] * iM;
+                e[0] += 0.5 * M * (vx * vx + vy * vy + vz * vz);
+            } else {
+                double S[7];
 #pragma unroll
-            for (int c = 0; c < 7; c++) S[c] = blocksums[(long long)blockIdx.x * 7 + c] + (q[c] - own[c]);
-            const double eta = S[0], ei = 1. / eta;
-            const double mj = mi * eta / (eta + mi);
-            const double x = v.x[i] - S[1] * ei, y = v.y[i] - S[2] * ei, z = v.z[i] - S[3] * ei;
-            const double vx = v.vx[i] - S[4] * ei, vy = v.vy[i] - S[5] * ei, vz = v.vz[i] - S[6] * ei;
-            const double mu = G * v.m[0];
-            const double rdoti2 = vx * vx + vy * vy + vz * vz;
-            double vt2 = rdoti2;
-            const double ri = sqrt(x * x + y * y + z * z);
-            const double vscale2 = mu / ri;
-            for (int it = 0; it < 10; it++) {
-                const double old = vt2;
-                const double A = (0.5 * vt2 + 3. * vscale2) / C2;
-                vt2 = rdoti2 / ((1. - A) * (1. - A));
-                if ((vt2 - old) / vt2 < 2.220446049250313e-16) break;
+                for (int c = 0; c < 7; c++) S[c] = blocksums[(long long)blockIdx.x * 7 + c] + carry[c] + (q[c] - own[c]);
+                const double eta = S[0], ei = 1. / eta;
+                const double mj = mi * eta / (eta + mi);
+                const double x = v.x[i] - S[1] * ei, y = v.y[i] - S[2] * ei, z = v.z[i] - S[3] * ei;
+                const double vx = v.vx[i] - S[4] * ei, vy = v.vy[i] - S[5] * ei, vz = v.vz[i] - S[6] * ei;
+                const double mu = G * v.m[0];
+                const double rdoti2 = vx * vx + vy * vy + vz * vz;
+                double vt2 = rdoti2;
+                const double ri = sqrt(x * x + y * y + z * z);
+                const double vscale2 = mu / ri;
+                for (int it = 0; it < 10; it++) {
+                    const double old = vt2;
+                    const double A = (0.5 * vt2 + 3. * vscale2) / C2;
+                    vt2 = rdoti2 / ((1. - A) * (1. - A));
+                    if ((vt2 - old) / vt2 < 2.220446049250313e-16) break;
+                }
+                e[2] += mj * (0.5 * mu * mu / (ri * ri) - 0.125 * vt2 * vt2 - 1.5 * mu * vt2 / ri);
+                e[0] += 0.5 * mj * vt2;
             }
-            e[2] = mj * (0.5 * mu * mu / (ri * ri) - 0.125 * vt2 * vt2 - 1.5 * mu * vt2 / ri);
-            e[0] = 0.5 * mj * vt2;
         }
+#pragma unroll
+        for (int c = 0; c < 7; c++) carry[c] += tot[c];
     }
-    block_scan<3, false>(e, et, lds3);
+    block_total<3>(e, lds3);
     if (threadIdx.x == 0) {
-        partials[3 * (long long)blockIdx.x + 0] = et[0];
-        partials[3 * (long long)blockIdx.x + 1] = et[1];
-        partials[3 * (long long)blockIdx.x + 2] = et[2];
+        partials[3 * (long long)blockIdx.x + 0] = e[0];
+        partials[3 * (long long)blockIdx.x + 1] = e[1];
+        partials[3 * (long long)blockIdx.x + 2] = e[2];
     }
 }
 
@@ -389,7 +435,8 @@ hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, 
     double* totals = fl + nb;                               // 16
     double* wtot = totals + 16;                             // 3
     double* count = wtot + 3;                               // 1
-    const dim3 g((unsigned)nb), b(SB);
+    const long long nbs = (n + SCHUNK - 1) / SCHUNK;        // workgroups of the weighted-sum passes
+    const dim3 g((unsigned)nb), gs((unsigned)nbs), b(SB);
     int kind = SCAN_GR;
     if (op.kind == REBXAMD_OP_MOF) kind = (op.iarg == REBX_COORDINATES_BARYCENTRIC) ? SCAN_MOF_BARY : SCAN_MOF_JACOBI;
     if (kind == SCAN_GR) {
@@ -398,19 +445,19 @@ hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, 
         hipLaunchKernelGGL(massive_compact, g, b, 0, st, v, fl, cx, cy, cz, cgm, cidx, G);
         if (exact) hipLaunchKernelGGL(newton_from_compact<true>, g, b, 0, st, v, cx, cy, cz, cgm, cidx, count, nax, nay, naz);
         else hipLaunchKernelGGL(newton_from_compact<false>, g, b, 0, st, v, cx, cy, cz, cgm, cidx, count, nax, nay, naz);
-        hipLaunchKernelGGL(scan_block_totals<10>, g, b, 0, st, v, nax, nay, naz, bs);
-        hipLaunchKernelGGL((scan_of_totals<10, false>), dim3(1), dim3(1024), 0, st, bs, nb, totals);
-        if (exact) hipLaunchKernelGGL((scan_main<SCAN_GR, true>), g, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL);
-        else hipLaunchKernelGGL((scan_main<SCAN_GR, false>), g, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL);
+        hipLaunchKernelGGL(scan_block_totals<10>, gs, b, 0, st, v, nax, nay, naz, bs);
+        hipLaunchKernelGGL((scan_of_totals<10, false>), dim3(1), dim3(1024), 0, st, bs, nbs, totals);
+        if (exact) hipLaunchKernelGGL((scan_main<SCAN_GR, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL);
+        else hipLaunchKernelGGL((scan_main<SCAN_GR, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL);
     } else {
-        hipLaunchKernelGGL(scan_block_totals<7>, g, b, 0, st, v, nax, nay, naz, bs);
-        hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(1024), 0, st, bs, nb, totals);
-        if (kind == SCAN_MOF_JACOBI) hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), g, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL);
-        else hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), g, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL);
+        hipLaunchKernelGGL(scan_block_totals<7>, gs, b, 0, st, v, nax, nay, naz, bs);
+        hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(1024), 0, st, bs, nbs, totals);
+        if (kind == SCAN_MOF_JACOBI) hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL);
+        else hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL);
     }
-    hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(1), dim3(1024), 0, st, wsum, nb, wtot);
-    if (kind == SCAN_MOF_BARY) hipLaunchKernelGGL(scan_apply<true>, g, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, wsum, wtot, (const double*)nullptr);
-    else hipLaunchKernelGGL(scan_apply<false>, g, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, wsum, wtot, (const double*)nullptr);
+    hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(1), dim3(1024), 0, st, wsum, nbs, wtot);
+    if (kind == SCAN_MOF_BARY) hipLaunchKernelGGL(scan_apply<true>, gs, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, wsum, wtot, (const double*)nullptr);
+    else hipLaunchKernelGGL(scan_apply<false>, gs, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, wsum, wtot, (const double*)nullptr);
     return hipGetLastError();
 }
 
@@ -421,7 +468,7 @@ namespace rebxamd {
 // ---- pieces of the Jacobi/barycentric modify_orbits_forces for particle shards.  `v` is the
 // sub-view of one contiguous range (column pointers already offset, n = its length); `ws` is the
 // workspace slice that belongs to the same range (6 columns of v.n doubles, then block sums).
-static inline long long blocks_of(long long n) { return (n + SB - 1) / SB; }
+static inline long long blocks_of(long long n) { return (n + SCHUNK - 1) / SCHUNK; }
 size_t scan_range_doubles(long long n) { return (size_t)(6 * n + 10 * blocks_of(n) + 16); }
 
 // sums7 <- (m, m x, m y, m z, m vx, m vy, m vz) summed over the range
@@ -484,15 +531,16 @@ hipError_t launch_gr_hamiltonian(const View& v, double G, double c, double* ws, 
     double* fl = part + 3 * nb;
     double* totals = fl + nb;
     double* count = totals + 16 + 3;
-    const dim3 g((unsigned)nb), b(SB);
+    const long long nbs = (n + SCHUNK - 1) / SCHUNK;
+    const dim3 g((unsigned)nb), gs((unsigned)nbs), b(SB);
     hipLaunchKernelGGL(massive_flag_totals, g, b, 0, st, v, fl);
     hipLaunchKernelGGL((scan_of_totals<1, false>), dim3(1), dim3(1024), 0, st, fl, nb, count);
     hipLaunchKernelGGL(massive_compact, g, b, 0, st, v, fl, cx, cy, cz, cgm, cidx, G);
     hipLaunchKernelGGL(newton_pot_from_compact, g, b, 0, st, v, cx, cy, cz, cgm, cidx, count, pot);
-    hipLaunchKernelGGL(scan_block_totals<7>, g, b, 0, st, v, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, bs);
-    hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(1024), 0, st, bs, nb, totals);
-    hipLaunchKernelGGL(gr_hamiltonian_main, g, b, 0, st, v, G, c * c, pot, bs, totals, part);
-    hipLaunchKernelGGL((scan_of_totals<3, false>), dim3(1), dim3(1024), 0, st, part, nb, out);
+    hipLaunchKernelGGL(scan_block_totals<7>, gs, b, 0, st, v, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, bs);
+    hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(1024), 0, st, bs, nbs, totals);
+    hipLaunchKernelGGL(gr_hamiltonian_main, gs, b, 0, st, v, G, c * c, pot, bs, totals, part);
+    hipLaunchKernelGGL((scan_of_totals<3, false>), dim3(1), dim3(1024), 0, st, part, nbs, out);
     return hipGetLastError();
 }
 

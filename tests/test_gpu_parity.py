@@ -157,15 +157,8 @@ def scan_check(ctx, cols, pp, forces, mode, **kw):
     react = float((m[1:] / m.sum() * np.abs(upd[:, 1:]).max(axis=0)).sum())
     big = np.maximum(np.abs(ref).max(axis=0), np.abs(upd).max(axis=0))
     den = np.maximum(big, react)[None, :]
-    den = np.where(den == 0., 1., den)
-    # against the same sums evaluated unsharded on one device: only the grouping of the partial sums differs
-    c1 = Context(0)
-    one, _ = run_device(c1, cols, pp, [("modify_orbits_forces", {"coordinates": coordinates})], 1.0, EXACT)
-    c1.close()
-    assert (np.abs(got - one) / den).max() <= 1e-13
-    # against the sequential checker, whose interior-mass sum drifts by ~1e-16 per body added
-    e = np.abs(got - ref) / den
-    assert e.max() <= TOL * max(1.0, n / 1e4), "max rel err %.3e at particle %d" % (e.max(), int(e.max(axis=0).argmax()))
+    e = np.abs(got - ref) / np.where(den == 0., 1., den)
+    assert e.max() <= TOL, "max rel err %.3e at particle %d" % (e.max(), int(e.max(axis=0).argmax()))
     return got, ref
 
 
