@@ -137,3 +137,32 @@ def test_kick_and_drift(ctx, mode):
         vk = np.array([cols[k] for k in ("vx", "vy", "vz")]) + 0.03 * np.array([cols[k] for k in ("ax", "ay", "az")])
         terms = np.concatenate([np.abs(np.array([cols[k] for k in ("x", "y", "z")])) + 0.07 * np.abs(vk), np.abs(vk) + 1.0])
         assert (np.abs(got - want) <= 2.3e-16 * terms).all()
+
+
+@pytest.mark.parametrize("n", [0, 1, 2])
+def test_smallest_particle_counts_go_through_every_stepping_entry_point(ctx, n):
+    """Empty arrays, a lone star, star + one grain: no faults, and (n = 2) the checker's numbers."""
+    import torch
+    from reboundx_amd._lib import OP_GR_POTENTIAL, Op
+    cols, pp, _ = synthetic.disk(max(n, 1), 0)
+    cols = {k: v[:n] for k, v in cols.items()}
+    pp = {k: v[:n] for k, v in pp.items()}
+    dp = device_state(cols, pp, n_head=1, tail_massless=True) if n else None
+    if n == 0:
+        from reboundx_amd.device import DeviceParticles
+        dp = DeviceParticles.from_host({k: np.zeros(0) for k in ("x", "y", "z", "vx", "vy", "vz", "m", "ax", "ay", "az")}, device="cuda:0")
+    ops = build_ops(C5_STACK, pp) if n else []
+    for integ in ("euler", "rk2", "rk4", "implicit_midpoint"):
+        ctx.integrate_force(dp.view(), ops, integ, 0.01)
+    ctx.kick(dp.view(), 0.01)
+    ctx.drift(dp.view(), 0.01)
+    if n >= 1:
+        ctx.wh_drift(dp.view(), 0.01)
+        ctx.wh_steps(dp.view(), ops, 0.01, 3)
+        assert ctx.potentials(dp.view(), [Op(OP_GR_POTENTIAL, 0, 0, 0, C, 0.)])[0] <= 0.0
+        assert np.isfinite(ctx.gr_hamiltonian(dp.view(), C))
+        ctx.modify_mass(dp.view(), torch.full((n,), float("nan"), dtype=torch.float64, device="cuda:0"), 0.1)
+        ctx.modify_orbits_direct(dp.view(), 0.1)
+        got = np.array([dp.cols[k].cpu().numpy() for k in ("x", "y", "z", "vx", "vy", "vz")])
+        assert np.isfinite(got).all()
+    torch.cuda.synchronize()
