@@ -74,3 +74,50 @@ def test_replay_with_the_force_evaluated_on_the_device(archives, name, mode):
     scale = max(1.0, np.abs(ref[:, :6]).max())
     assert np.abs(got - ref[:, :6]).max() <= 3e-10 * scale
     sim.free_particle_params()
+
+
+@pytest.mark.parametrize("name", ["modify_mass", "modify_orbits_direct"])
+def test_replay_with_the_operator_run_on_the_device(archives, name):
+    """Same for the two operators: their fixture puts half a step before and half a step after
+    every timestep; REBOUND would call sim->pre/post_timestep_modifications, here the checker's
+    integrator does.  Masses (modify_mass) are part of the compared state."""
+    start, ref = rows(archives["forces"][name][0]), rows(archives["forces"][name][1])
+    dt = float.fromhex(archives["dt"])
+    steps = round(float.fromhex(archives["forces"][name][1]["t"]) / dt)
+    sim = Simulation(integrator="whfast")
+    for p in start:
+        sim.add(m=p[6], x=p[0], y=p[1], z=p[2], vx=p[3], vy=p[4], vz=p[5])
+    sim.dt = dt
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rebx = Extras(sim, os.path.join(GOLDEN, "rebx", name + ".rebx"))
+    rebx.set_mode("exact")
+    ps = sim.particles
+    n = 3
+    fields = ("x", "y", "z", "vx", "vy", "vz", "m")
+
+    def run(hook_fn):
+        def step(ptr, _h, _user):
+            s = ptr.contents
+            cols = [np.ctypeslib.as_array(ctypes.cast(getattr(s, k), ctypes.POINTER(ctypes.c_double)), shape=(n,)) for k in fields]
+            for i in range(n):
+                for k, c in zip(fields, cols):
+                    setattr(ps[i], k, float(c[i]))
+            hook_fn(ctypes.byref(sim))
+            for i in range(n):
+                for k, c in zip(fields, cols):
+                    c[i] = getattr(ps[i], k)
+        return oracle._STEP_FN(step)
+
+    cols = {k: start[:, j].copy() for j, k in enumerate(fields)}
+    for k in ("ax", "ay", "az"):
+        cols[k] = np.zeros(n)
+    state = oracle.Sim(cols)
+    pre, post = run(sim.pre_timestep_modifications), run(sim.post_timestep_modifications)
+    rc = oracle.lib.orc_whfast_steps(ctypes.byref(state.s), dt, steps, oracle._FORCE_FN(0), pre, post, None)
+    assert rc == 0
+    sim.process_messages()
+    got = np.array([state.cols[k] for k in fields]).T
+    assert np.abs(got - ref).max() <= 2e-9
+    assert np.abs(ref[:, :6] - start[:, :6]).max() > 0.1
+    sim.free_particle_params()
