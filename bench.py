@@ -156,7 +156,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n-per-gpu", type=int, default=N_PER_GPU)
     ap.add_argument("--mode", choices=["fast", "exact"], default="fast")
-    ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--cpu-reps", type=int, default=12)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (the GPU box grants 16)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--grfull-n", type=int, default=65536, help="0 disables the gr_full section")

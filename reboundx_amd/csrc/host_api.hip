@@ -19,6 +19,7 @@
 #include <chrono>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -160,6 +161,33 @@ void drop_bridge(const rebx_extras* rebx) {
 
 double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Host threads for the array-of-structs <-> column conversions (REBXAMD_HOST_THREADS, default 8,
+// at most 64).  Below ~100k particles one thread is faster than starting helpers.
+int host_threads(int N) {
+    static const int configured = [] {
+        const char* e = getenv("REBXAMD_HOST_THREADS");
+        int t = e ? atoi(e) : 8;
+        const int hw = (int)std::thread::hardware_concurrency();
+        if (hw > 0 && t > hw) t = hw;
+        return t < 1 ? 1 : (t > 64 ? 64 : t);
+    }();
+    return N < 100000 ? 1 : configured;
+}
+
+// fn(lo, hi, k) on nt contiguous chunks of [0, N); chunk k runs on its own thread
+template <class Fn> void parallel_chunks(int N, int nt, Fn fn) {
+    if (nt <= 1) { fn(0, N, 0); return; }
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)nt - 1);
+    const long long per = ((long long)N + nt - 1) / nt;
+    for (int k = 1; k < nt; k++) {
+        const int lo = (int)std::min<long long>(N, k * per), hi = (int)std::min<long long>(N, (k + 1) * per);
+        pool.emplace_back([=] { fn(lo, hi, k); });
+    }
+    fn(0, (int)std::min<long long>(N, per), 0);
+    for (std::thread& t : pool) t.join();
 }
 
 }  // namespace
@@ -610,39 +638,60 @@ bool ensure_capacity(struct rebx_extras* rebx, Bridge* b, size_t n) {
 // lists of source-type parameters.  One walk per list, no matter how many forces are stacked.
 void flatten_params(struct rebx_extras* rebx, Bridge* b, const struct reb_particle* ps, int N) {
     const double nan = std::nan("");
-    for (int k = 0; k < P_NPAR; k++) {
-        b->par_used[k] = false;
-        for (int i = 0; i < N; i++) b->h_par[k][i] = nan;
-    }
+    struct Local {
+        bool used[P_NPAR] = {};
+        std::vector<int> radiation_sources, tides_primaries;
+        std::vector<SourceJ> j2, j4;
+        std::vector<SourceC> central;
+        int first_primary = -1;
+    };
+    const int nt = host_threads(N);
+    std::vector<Local> local((size_t)nt);
+    // each thread walks the lists of its own particles; the short source lists are merged in index order afterwards
+    parallel_chunks(N, nt, [&](int lo, int hi, int t) {
+        Local& L = local[(size_t)t];
+        for (int k = 0; k < P_NPAR; k++)
+            for (int i = lo; i < hi; i++) b->h_par[k][i] = nan;
+        for (int i = lo; i < hi; i++) {
+            const double *J2 = nullptr, *J4 = nullptr, *Req = nullptr, *A = nullptr, *gam = nullptr;
+            for (const struct rebx_node* node = (const struct rebx_node*)ps[i].ap; node; node = node->next) {
+                const struct rebx_param* p = (const struct rebx_param*)node->object;
+                const char* name = p->name;
+                bool dense = false;
+                for (int k = 0; k < P_NPAR; k++) {
+                    if (strcmp(name, kParamName[k]) == 0) {
+                        // the first match in list order wins, as a linear search would find it
+                        if (p->value && std::isnan(b->h_par[k][i])) { b->h_par[k][i] = *(const double*)p->value; L.used[k] = true; }
+                        dense = true;
+                        break;
+                    }
+                }
+                if (dense) continue;
+                if (!strcmp(name, "J2")) { if (!J2) J2 = (const double*)p->value; }
+                else if (!strcmp(name, "J4")) { if (!J4) J4 = (const double*)p->value; }
+                else if (!strcmp(name, "R_eq")) { if (!Req) Req = (const double*)p->value; }
+                else if (!strcmp(name, "Acentral")) { if (!A) A = (const double*)p->value; }
+                else if (!strcmp(name, "gammacentral")) { if (!gam) gam = (const double*)p->value; }
+                else if (!strcmp(name, "radiation_source")) { if (p->value && (L.radiation_sources.empty() || L.radiation_sources.back() != i)) L.radiation_sources.push_back(i); }
+                else if (!strcmp(name, "tides_primary")) { if (p->value && (L.tides_primaries.empty() || L.tides_primaries.back() != i)) L.tides_primaries.push_back(i); }
+                else if (!strcmp(name, "primary")) { if (p->value && L.first_primary < 0) L.first_primary = i; }
+            }
+            if (J2 && Req) L.j2.push_back({i, *J2, *Req});
+            if (J4 && Req) L.j4.push_back({i, *J4, *Req});
+            if (A && gam) L.central.push_back({i, *A, *gam});
+        }
+    });
+    for (int k = 0; k < P_NPAR; k++) b->par_used[k] = false;
     b->radiation_sources.clear(); b->tides_primaries.clear(); b->j2.clear(); b->j4.clear(); b->central.clear();
     b->first_primary = -1;
-    for (int i = 0; i < N; i++) {
-        const double *J2 = nullptr, *J4 = nullptr, *Req = nullptr, *A = nullptr, *gam = nullptr;
-        for (const struct rebx_node* node = (const struct rebx_node*)ps[i].ap; node; node = node->next) {
-            const struct rebx_param* p = (const struct rebx_param*)node->object;
-            const char* name = p->name;
-            bool dense = false;
-            for (int k = 0; k < P_NPAR; k++) {
-                if (strcmp(name, kParamName[k]) == 0) {
-                    // the first match in list order wins, as a linear search would find it
-                    if (p->value && std::isnan(b->h_par[k][i])) { b->h_par[k][i] = *(const double*)p->value; b->par_used[k] = true; }
-                    dense = true;
-                    break;
-                }
-            }
-            if (dense) continue;
-            if (!strcmp(name, "J2")) { if (!J2) J2 = (const double*)p->value; }
-            else if (!strcmp(name, "J4")) { if (!J4) J4 = (const double*)p->value; }
-            else if (!strcmp(name, "R_eq")) { if (!Req) Req = (const double*)p->value; }
-            else if (!strcmp(name, "Acentral")) { if (!A) A = (const double*)p->value; }
-            else if (!strcmp(name, "gammacentral")) { if (!gam) gam = (const double*)p->value; }
-            else if (!strcmp(name, "radiation_source")) { if (p->value && (b->radiation_sources.empty() || b->radiation_sources.back() != i)) b->radiation_sources.push_back(i); }
-            else if (!strcmp(name, "tides_primary")) { if (p->value && (b->tides_primaries.empty() || b->tides_primaries.back() != i)) b->tides_primaries.push_back(i); }
-            else if (!strcmp(name, "primary")) { if (p->value && b->first_primary < 0) b->first_primary = i; }
-        }
-        if (J2 && Req) b->j2.push_back({i, *J2, *Req});
-        if (J4 && Req) b->j4.push_back({i, *J4, *Req});
-        if (A && gam) b->central.push_back({i, *A, *gam});
+    for (const Local& L : local) {
+        for (int k = 0; k < P_NPAR; k++) b->par_used[k] = b->par_used[k] || L.used[k];
+        b->radiation_sources.insert(b->radiation_sources.end(), L.radiation_sources.begin(), L.radiation_sources.end());
+        b->tides_primaries.insert(b->tides_primaries.end(), L.tides_primaries.begin(), L.tides_primaries.end());
+        b->j2.insert(b->j2.end(), L.j2.begin(), L.j2.end());
+        b->j4.insert(b->j4.end(), L.j4.begin(), L.j4.end());
+        b->central.insert(b->central.end(), L.central.begin(), L.central.end());
+        if (b->first_primary < 0) b->first_primary = L.first_primary;
     }
 }
 
@@ -705,17 +754,30 @@ bool stage_in(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* b, c
               rebxamd_view& v, double t[3]) {
     if (!ensure_capacity(rebx, b, (size_t)N)) return false;
     t[0] = now_ms();
-    unsigned long long sum = 1469598103934665603ull;
-    long long last_massive = -1;
     double* const* h = b->h_dyn;
-    for (int i = 0; i < N; i++) {
-        const struct reb_particle& p = particles[i];
-        h[H_X][i] = p.x; h[H_Y][i] = p.y; h[H_Z][i] = p.z;
-        h[H_VX][i] = p.vx; h[H_VY][i] = p.vy; h[H_VZ][i] = p.vz;
-        h[H_M][i] = p.m;
-        h[H_AX][i] = p.ax; h[H_AY][i] = p.ay; h[H_AZ][i] = p.az;
-        if (p.m != 0.) last_massive = i;
-        sum = (sum ^ (unsigned long long)(uintptr_t)p.ap) * 1099511628211ull;
+    const int nt = host_threads(N);
+    unsigned long long chunk_sum[64];
+    long long chunk_last[64];
+    parallel_chunks(N, nt, [&](int lo, int hi, int k) {
+        unsigned long long cs = 1469598103934665603ull;
+        long long lm = -1;
+        for (int i = lo; i < hi; i++) {
+            const struct reb_particle& p = particles[i];
+            h[H_X][i] = p.x; h[H_Y][i] = p.y; h[H_Z][i] = p.z;
+            h[H_VX][i] = p.vx; h[H_VY][i] = p.vy; h[H_VZ][i] = p.vz;
+            h[H_M][i] = p.m;
+            h[H_AX][i] = p.ax; h[H_AY][i] = p.ay; h[H_AZ][i] = p.az;
+            if (p.m != 0.) lm = i;
+            cs = (cs ^ (unsigned long long)(uintptr_t)p.ap) * 1099511628211ull;
+        }
+        chunk_sum[k] = cs; chunk_last[k] = lm;
+    });
+    // fold of the per-chunk folds, in chunk order: changes whenever any list head changes
+    unsigned long long sum = 1469598103934665603ull ^ (unsigned long long)nt;
+    long long last_massive = -1;
+    for (int k = 0; k < nt; k++) {
+        sum = (sum ^ chunk_sum[k]) * 1099511628211ull;
+        if (chunk_last[k] > last_massive) last_massive = chunk_last[k];
     }
     const bool rebuild = b->built_generation != b->generation || b->built_n != N || b->built_checksum != sum;
     if (rebuild) flatten_params(rebx, b, particles, N);
@@ -794,9 +856,9 @@ void run_builtin(struct reb_simulation* sim, struct rebx_extras* rebx, const std
     uint32_t bits = 0;
     ok = ok && rebxamd_fetch_warnings(b->ctx, &bits, st) == REBXAMD_OK;     // synchronises the stream
     if (!ok) { rebx_error(rebx, "REBOUNDx (MI355X) Error: device to host copy failed.\n"); return; }
-    for (int i = 0; i < N; i++) {
-        particles[i].ax = h[H_AX][i]; particles[i].ay = h[H_AY][i]; particles[i].az = h[H_AZ][i];
-    }
+    parallel_chunks(N, host_threads(N), [&](int lo, int hi, int) {
+        for (int i = lo; i < hi; i++) { particles[i].ax = h[H_AX][i]; particles[i].ay = h[H_AY][i]; particles[i].az = h[H_AZ][i]; }
+    });
     const double t4 = now_ms();
     report_warnings(sim, bits);
     b->timings[0] = t[1] - t[0]; b->timings[1] = t[2] - t[1]; b->timings[2] = t3 - t[2]; b->timings[3] = t4 - t3;
@@ -1230,11 +1292,13 @@ bool state_back(struct rebx_extras* rebx, Bridge* b, struct reb_particle* ps, in
     ok = ok && hipStreamSynchronize(st) == hipSuccess;
     if (!ok) { rebx_error(rebx, "REBOUNDx (MI355X) Error: device to host copy failed.\n"); return false; }
     double* const* h = b->h_dyn;
-    for (int i = 0; i < N; i++) {
-        ps[i].x = h[H_X][i]; ps[i].y = h[H_Y][i]; ps[i].z = h[H_Z][i];
-        ps[i].vx = h[H_VX][i]; ps[i].vy = h[H_VY][i]; ps[i].vz = h[H_VZ][i];
-        if (with_mass) ps[i].m = h[H_M][i];
-    }
+    parallel_chunks(N, host_threads(N), [&](int lo, int hi, int) {
+        for (int i = lo; i < hi; i++) {
+            ps[i].x = h[H_X][i]; ps[i].y = h[H_Y][i]; ps[i].z = h[H_Z][i];
+            ps[i].vx = h[H_VX][i]; ps[i].vy = h[H_VY][i]; ps[i].vz = h[H_VZ][i];
+            if (with_mass) ps[i].m = h[H_M][i];
+        }
+    });
     return true;
 }
 // a parameter column nobody set was not uploaded: operators that take it unconditionally get the NaN column

@@ -1,0 +1,43 @@
+"""Times the drop-in path (host array-of-structs in and out through sim->additional_forces):
+pack, host-to-device, kernels, device-to-host + unpack, as reported by rebxamd_last_timings.
+usage: python scripts/bench_dropin.py [n]"""
+import ctypes
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from reboundx_amd import synthetic  # noqa: E402
+from reboundx_amd.extras import Extras, Particle, Simulation  # noqa: E402
+
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000
+C = synthetic.C_DEFAULT
+cols, pp, _ = synthetic.disk(n, 0)
+sim = Simulation()
+arr = (Particle * n)()
+view = np.frombuffer(arr, dtype=np.float64).reshape(n, 16)
+for j, k in enumerate(("x", "y", "z", "vx", "vy", "vz", "ax", "ay", "az", "m")):
+    view[:, j] = cols[k]
+sim._store = arr
+sim._particles = ctypes.cast(arr, ctypes.POINTER(Particle))
+sim.N = n
+arr[0]._sim = ctypes.pointer(sim)
+rebx = Extras(sim)
+for name in ("gr", "gravitational_harmonics"):          # executed: harmonics, then gr (no per-particle lists needed beyond the star's)
+    f = rebx.load_force(name)
+    if name == "gr":
+        f.params["c"] = C
+    rebx.add_force(f)
+arr[0].params["J2"] = 1e-3
+arr[0].params["J4"] = 1e-3
+arr[0].params["R_eq"] = 1e-3
+for k in range(4):
+    t0 = time.perf_counter()
+    sim.call_additional_forces()
+    wall = time.perf_counter() - t0
+    t = rebx.last_timings()
+    print("call %d  n=%d  wall %8.2f ms | pack %7.2f  h2d %7.2f  kernels %6.3f  d2h+unpack %7.2f ms | %.3e evals/s end to end, %.2f GB/s over PCIe (80 B in, 24 B out per particle)" % (
+        k, n, wall * 1e3, t["pack_ms"], t["h2d_ms"], t["kernel_ms"], t["d2h_unpack_ms"], n / wall, 104 * n / ((t["h2d_ms"] + t["d2h_unpack_ms"]) * 1e-3) / 1e9), flush=True)
