@@ -462,6 +462,13 @@ int rebxamd_fetch_warnings(rebxamd_ctx* ctx, uint32_t* bits, void* stream);
  * rebxamd_timing_read waits for the recorded events, returns the summed kernel time and the
  * number of launches since the last read, and starts over. */
 int rebxamd_timing_enable(rebxamd_ctx* ctx, int on);
+/* Kernel selection (no counterpart in the reference).  The streaming passes have instances built
+ * for the common force stacks (radiation + harmonics + gr; radiation + harmonics + gr_potential +
+ * tides + modify_orbits_forces; tides + modify_orbits_forces + gr_potential; the single forces)
+ * that run the stack as straight-line code; every other stack walks its op list at run time.
+ * Both compute the same expressions.  on = 0 makes this context always walk the list
+ * (default: 1). */
+int rebxamd_fixed_stacks(rebxamd_ctx* ctx, int on);
 int rebxamd_timing_read(rebxamd_ctx* ctx, double* total_ms, int* launches);
 
 /* gr_full on one device (gr_full.c:61-231).  The three phases are also exposed on row

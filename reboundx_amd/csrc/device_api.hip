@@ -31,6 +31,7 @@ struct rebxamd_ctx {
     size_t scan_cap = 0;
     // optional timing of the dominant kernels with HIP events on the launch stream
     bool timing = false;
+    bool fixed_stacks = true;   // stacks with a kernel instance of their own use it
     std::vector<hipEvent_t> ev;         // pairs: start, stop
     size_t ev_used = 0;
 };
@@ -115,6 +116,12 @@ extern "C" int rebxamd_timing_enable(rebxamd_ctx* ctx, int on) {
     if (!ctx) return REBXAMD_ERR_ARG;
     ctx->timing = on != 0;
     ctx->ev_used = 0;
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_fixed_stacks(rebxamd_ctx* ctx, int on) {
+    if (!ctx) return REBXAMD_ERR_ARG;
+    ctx->fixed_stacks = on != 0;
     return REBXAMD_OK;
 }
 
@@ -283,7 +290,7 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
         HIP_TRY(launch_head(v, prog, ctx->hc, ctx->status, exact, st));
         if (v.n > K) {
             TimedLaunch tl(ctx, st);
-            HIP_TRY(launch_stream(v, prog, K, ctx->hc, nullptr, nullptr, false, exact, vec2, ctx->status, st));
+            HIP_TRY(launch_stream(v, prog, K, ctx->hc, nullptr, nullptr, false, exact, vec2, ctx->fixed_stacks, ctx->status, st));
         }
         return REBXAMD_OK;
     }
@@ -334,7 +341,7 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
     HIP_TRY(launch_stage(v, prog, ctx->hc, st));
     {
         TimedLaunch tl(ctx, st);
-        HIP_TRY(launch_stream(v, prog, first, ctx->hc, ctx->partials, &nblocks, nslots > 0, exact, vec2, ctx->status, st));
+        HIP_TRY(launch_stream(v, prog, first, ctx->hc, ctx->partials, &nblocks, nslots > 0, exact, vec2, ctx->fixed_stacks, ctx->status, st));
     }
     if (nslots > 0 || sums_out) HIP_TRY(launch_finalize(v, prog, ctx->partials, nblocks, ctx->chunk_sums, sums_out, st));
     return REBXAMD_OK;

@@ -65,7 +65,7 @@ enum { WARN_GR_ITER = 1u, WARN_GRFULL_SWEEPS = 2u, WARN_IM_ITER = 4u };
 // launchers implemented in stream_kernels.hip
 hipError_t launch_head(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, bool exact, hipStream_t st);
 hipError_t launch_stream(const View& v, const Program& prog, long long lo, const HeadConsts* hc, double* partials,
-                         int* nblocks_out, bool backreact, bool exact, bool vec2, unsigned* status, hipStream_t st);
+                         int* nblocks_out, bool backreact, bool exact, bool vec2, bool fixed, unsigned* status, hipStream_t st);
 hipError_t launch_stage(const View& v, const Program& prog, HeadConsts* hc, hipStream_t st);
 // chunk_sums: scratch of REBXAMD_MAX_OPS * 64 * 3 doubles
 // sums_out: nullptr = add the totals to the source particles; else store 3 doubles per op there

@@ -55,13 +55,13 @@ __device__ __forceinline__ double wave_sum(double v) {
 // update, `br` the push on the source (already signed).  Fast mode reuses the separation
 // from the source (`g`) when the previous force on this particle had the same source.
 template <bool EXACT>
-__device__ __forceinline__ bool sourced_effect(const DevOp& op, const Part& p, const Src& S, double G, Geo& g, V3& d, V3& br) {
+__device__ __forceinline__ bool sourced_effect(const int kind, const DevOp& op, const Part& p, const Src& S, double G, Geo& g, V3& d, V3& br) {
     br.x = br.y = br.z = 0.;
     if (!EXACT) {
-        if (op.kind == REBXAMD_OP_RADIATION && !is_set(p.beta)) return false;
+        if (kind == REBXAMD_OP_RADIATION && !is_set(p.beta)) return false;
         if (g.src != op.src) geo_compute(p, S, op.src, g);
     }
-    switch (op.kind) {
+    switch (kind) {
     case REBXAMD_OP_RADIATION:
         if (EXACT) { if (!is_set(p.beta)) return false; rad_exact(p, S, G, op.a, d); }
         else rad_fast(p, S, g, G, op.c, d);
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(64) void head_kernel(View v, Program prog, HeadCons
                     mof_particle<EXACT>(p, S, acc, br);
                     acted = true;
                 } else {
-                    acted = sourced_effect<EXACT>(op, p, S, G, geo, d, br);
+                    acted = sourced_effect<EXACT>(op.kind, op, p, S, G, geo, d, br);
                     if (acted) {
 #pragma clang fp contract(off)
                         acc.x += d.x; acc.y += d.y; acc.z += d.z;
@@ -369,84 +369,128 @@ __device__ __forceinline__ void part_defaults(Part& p) {
     p.beta = p.Rt = p.k1 = p.ta = p.te = p.ti = nan;
 }
 
-// All forces of the program on one particle behind the head (massless by the caller's
+// One force of the program on one particle behind the head (massless by the caller's
 // assertion: it pushes on nothing and feels no tides).  `t` points at the device tables; every
-// lane reads the same entries, so these become scalar loads.
+// lane reads the same entries, so these become scalar loads.  `kind` is op.kind, passed
+// separately so that instances built for a fixed stack see it as a constant.
 template <bool EXACT>
-__device__ __forceinline__ void tail_particle(const Program& prog, const HeadConsts* __restrict__ t, const Part& p, V3& acc, unsigned* status) {
-    const double G = prog.G;
-    Geo g; g.src = -1; g.dx = g.dy = g.dz = g.ri = 0.;
-    for (int o = 0; o < prog.nops; o++) {
-        const DevOp op = prog.ops[o];
-        if (op.kind == REBXAMD_OP_GR) {
-            double nx = 0., ny = 0., nz = 0.;
-            Jac j;
-            V3 corr;
-            int q;
-            const int nheadm = t->nheadm;
-            if (!EXACT && nheadm == 1) {
-                // one massive body: its separation serves the Newtonian pull and (to an ulp of the
-                // body's own coordinates) the Jacobi position
-                const int h0 = t->head0;
-                if (g.src != h0) geo_compute(p, t->src[o], h0, g);
-                const double w = -(G * t->head[0][3]) * (g.ri * g.ri * g.ri);
-                j.x = g.dx; j.y = g.dy; j.z = g.dz;
+__device__ __forceinline__ void tail_op(const int kind, const int o, const DevOp& op, const double G, const HeadConsts* __restrict__ t,
+                                        const Part& p, V3& acc, Geo& g, unsigned* status) {
+    if (kind == REBXAMD_OP_GR) {
+        double nx = 0., ny = 0., nz = 0.;
+        Jac j;
+        V3 corr;
+        int q;
+        const int nheadm = t->nheadm;
+        if (!EXACT && nheadm == 1) {
+            // one massive body: its separation serves the Newtonian pull and (to an ulp of the
+            // body's own coordinates) the Jacobi position
+            const int h0 = t->head0;
+            if (g.src != h0) geo_compute(p, t->src[o], h0, g);
+            const double w = -(G * t->head[0][3]) * (g.ri * g.ri * g.ri);
+            j.x = g.dx; j.y = g.dy; j.z = g.dz;
+            j.vx = p.vx - t->gr_c[3]; j.vy = p.vy - t->gr_c[4]; j.vz = p.vz - t->gr_c[5];
+            j.ax = w * g.dx - t->gr_c[6]; j.ay = w * g.dy - t->gr_c[7]; j.az = w * g.dz - t->gr_c[8];
+            q = gr_term_fast(j, g.ri, t->gr_mu, op.d, op.iarg, corr);
+        } else {
+            // Newtonian pull of the massive head bodies (all of them precede this body)
+            for (int u = 0; u < nheadm; u++) {
+                if (EXACT) newton_pair_exact(p.x, p.y, p.z, t->head[u][0], t->head[u][1], t->head[u][2], t->head[u][3], true, G, nx, ny, nz);
+                else newton_pair_fast(p.x, p.y, p.z, t->head[u][0], t->head[u][1], t->head[u][2], t->head[u][3], G, nx, ny, nz);
+            }
+            {
+#pragma clang fp contract(off)
+                j.x = p.x - t->gr_c[0]; j.y = p.y - t->gr_c[1]; j.z = p.z - t->gr_c[2];
                 j.vx = p.vx - t->gr_c[3]; j.vy = p.vy - t->gr_c[4]; j.vz = p.vz - t->gr_c[5];
-                j.ax = w * g.dx - t->gr_c[6]; j.ay = w * g.dy - t->gr_c[7]; j.az = w * g.dz - t->gr_c[8];
-                q = gr_term_fast(j, g.ri, t->gr_mu, op.d, op.iarg, corr);
-            } else {
-                // Newtonian pull of the massive head bodies (all of them precede this body)
-                for (int u = 0; u < nheadm; u++) {
-                    if (EXACT) newton_pair_exact(p.x, p.y, p.z, t->head[u][0], t->head[u][1], t->head[u][2], t->head[u][3], true, G, nx, ny, nz);
-                    else newton_pair_fast(p.x, p.y, p.z, t->head[u][0], t->head[u][1], t->head[u][2], t->head[u][3], G, nx, ny, nz);
-                }
-                {
+                j.ax = nx - t->gr_c[6]; j.ay = ny - t->gr_c[7]; j.az = nz - t->gr_c[8];
+            }
+            q = EXACT ? gr_term_exact(j, t->gr_mu, op.c, op.iarg, corr)
+                      : gr_term_fast(j, fast_rsqrt(j.x * j.x + j.y * j.y + j.z * j.z), t->gr_mu, op.d, op.iarg, corr);
+        }
+        if (q == 10) atomicOr(status, WARN_GR_ITER);
+        // a massless body's inertial correction equals its Jacobi correction
+        acc.x += corr.x; acc.y += corr.y; acc.z += corr.z;
+    } else if (kind == REBXAMD_OP_MOF) {
+        Src ref;
+        if (op.iarg == REBX_COORDINATES_PARTICLE) {
+            ref = t->src[o];
+        } else {
+            ref.x = t->com[0]; ref.y = t->com[1]; ref.z = t->com[2];
+            ref.vx = t->com[3]; ref.vy = t->com[4]; ref.vz = t->com[5]; ref.m = t->com[6];
+        }
+        V3 a;
+        if (EXACT) mof_exact(p, ref, a); else mof_fast(p, ref, a);
+        acc.x += a.x; acc.y += a.y; acc.z += a.z;
+        if (op.iarg == REBX_COORDINATES_BARYCENTRIC) {
+            const int nb = t->nbary;
+            for (int i = 0; i < nb; i++) {
+                acc.x -= t->bary[i][0]; acc.y -= t->bary[i][1]; acc.z -= t->bary[i][2];
+            }
+        }
+    } else if (kind != REBXAMD_OP_TIDES) {
+        V3 d, br;
+        if (sourced_effect<EXACT>(kind, op, p, t->src[o], G, g, d, br)) {
 #pragma clang fp contract(off)
-                    j.x = p.x - t->gr_c[0]; j.y = p.y - t->gr_c[1]; j.z = p.z - t->gr_c[2];
-                    j.vx = p.vx - t->gr_c[3]; j.vy = p.vy - t->gr_c[4]; j.vz = p.vz - t->gr_c[5];
-                    j.ax = nx - t->gr_c[6]; j.ay = ny - t->gr_c[7]; j.az = nz - t->gr_c[8];
-                }
-                q = EXACT ? gr_term_exact(j, t->gr_mu, op.c, op.iarg, corr)
-                          : gr_term_fast(j, fast_rsqrt(j.x * j.x + j.y * j.y + j.z * j.z), t->gr_mu, op.d, op.iarg, corr);
-            }
-            if (q == 10) atomicOr(status, WARN_GR_ITER);
-            // a massless body's inertial correction equals its Jacobi correction
-            acc.x += corr.x; acc.y += corr.y; acc.z += corr.z;
-        } else if (op.kind == REBXAMD_OP_MOF) {
-            Src ref;
-            if (op.iarg == REBX_COORDINATES_PARTICLE) {
-                ref = t->src[o];
-            } else {
-                ref.x = t->com[0]; ref.y = t->com[1]; ref.z = t->com[2];
-                ref.vx = t->com[3]; ref.vy = t->com[4]; ref.vz = t->com[5]; ref.m = t->com[6];
-            }
-            V3 a;
-            if (EXACT) mof_exact(p, ref, a); else mof_fast(p, ref, a);
-            acc.x += a.x; acc.y += a.y; acc.z += a.z;
-            if (op.iarg == REBX_COORDINATES_BARYCENTRIC) {
-                const int nb = t->nbary;
-                for (int i = 0; i < nb; i++) {
-                    acc.x -= t->bary[i][0]; acc.y -= t->bary[i][1]; acc.z -= t->bary[i][2];
-                }
-            }
-        } else if (op.kind != REBXAMD_OP_TIDES) {
-            V3 d, br;
-            if (sourced_effect<EXACT>(op, p, t->src[o], G, g, d, br)) {
-#pragma clang fp contract(off)
-                acc.x += d.x; acc.y += d.y; acc.z += d.z;
-            }
+            acc.x += d.x; acc.y += d.y; acc.z += d.z;
+        }
+    }
+}
+
+// A fixed stack of forces as a compile-time signature: the op kinds in execution order, four
+// bits each, first op in the lowest bits (kinds are 1..15; 0 ends the list).  Kernel instances
+// built for a signature run the ops as straight-line code; signature 0 walks the op list at run time.
+typedef unsigned long long Sig;
+constexpr Sig sig_of(int k0, int k1 = 0, int k2 = 0, int k3 = 0, int k4 = 0, int k5 = 0, int k6 = 0, int k7 = 0) {
+    return (Sig)k0 | (Sig)k1 << 4 | (Sig)k2 << 8 | (Sig)k3 << 12 | (Sig)k4 << 16 | (Sig)k5 << 20 | (Sig)k6 << 24 | (Sig)k7 << 28;
+}
+constexpr int sig_len(Sig s) { int n = 0; for (; s; s >>= 4) n++; return n; }
+
+// Optional columns a fixed stack reads.  Behind the head every body is massless, and massless
+// bodies neither raise nor feel tides (reference src/tides_precession.c:84-87): the tail pass of
+// a stack with tides_precession leaves R_tides and k1 unread.
+constexpr int sig_cols(Sig s, bool tail) {
+    int c = 0;
+    for (; s; s >>= 4) {
+        const int k = (int)(s & 15ull);
+        if (k == REBXAMD_OP_RADIATION) c |= COL_VEL | COL_BETA;
+        else if (k == REBXAMD_OP_GR) c |= COL_VEL;
+        else if (k == REBXAMD_OP_TIDES) c |= tail ? 0 : COL_TIDES;
+        else if (k == REBXAMD_OP_MOF) c |= COL_VEL | COL_TAU;
+    }
+    return c;
+}
+
+template <bool EXACT, Sig SIG, int O>
+__device__ __forceinline__ void tail_fixed(const Program& prog, const HeadConsts* __restrict__ t, const Part& p, V3& acc, Geo& g, unsigned* status) {
+    constexpr int kind = (int)((SIG >> (4 * O)) & 15ull);
+    if constexpr (kind != 0) {
+        tail_op<EXACT>(kind, O, prog.ops[O], prog.G, t, p, acc, g, status);
+        tail_fixed<EXACT, SIG, O + 1>(prog, t, p, acc, g, status);
+    }
+}
+
+// All forces of the program on one particle behind the head.
+template <bool EXACT, Sig SIG>
+__device__ __forceinline__ void tail_particle(const Program& prog, const HeadConsts* __restrict__ t, const Part& p, V3& acc, unsigned* status) {
+    Geo g; g.src = -1; g.dx = g.dy = g.dz = g.ri = 0.;
+    if constexpr (SIG != 0ull) {
+        tail_fixed<EXACT, SIG, 0>(prog, t, p, acc, g, status);
+    } else {
+        for (int o = 0; o < prog.nops; o++) {
+            const DevOp op = prog.ops[o];
+            tail_op<EXACT>(op.kind, o, op, prog.G, t, p, acc, g, status);
         }
     }
 }
 
 // One op on one particle where every body may be massive: the push on the source is returned.
 template <bool EXACT>
-__device__ __forceinline__ void general_op(const DevOp& op, const Src& S, double G, const Part& p, Geo& g, V3& acc, double& bx, double& by, double& bz) {
+__device__ __forceinline__ void general_op(const int kind, const DevOp& op, const Src& S, double G, const Part& p, Geo& g, V3& acc, double& bx, double& by, double& bz) {
     V3 d, br;
-    if (op.kind == REBXAMD_OP_MOF) {
+    if (kind == REBXAMD_OP_MOF) {
         mof_particle<EXACT>(p, S, acc, br);
         bx += br.x; by += br.y; bz += br.z;
-    } else if (sourced_effect<EXACT>(op, p, S, G, g, d, br)) {
+    } else if (sourced_effect<EXACT>(kind, op, p, S, G, g, d, br)) {
 #pragma clang fp contract(off)
         acc.x += d.x; acc.y += d.y; acc.z += d.z;
         bx += br.x; by += br.y; bz += br.z;
@@ -454,12 +498,38 @@ __device__ __forceinline__ void general_op(const DevOp& op, const Src& S, double
 }
 
 struct StreamShared { double part[WAVES][REBXAMD_MAX_OPS][3]; };
+struct GeneralLane { long long i0; bool act0, act1, any_mass; int wave, lane; };
 
-template <bool EXACT, bool BACKREACT, bool VEC2, int COLS>
+// One op on this thread's two particles in the any-mass-layout pass; the wavefront's summed push on
+// the op's source goes to LDS.
+template <bool EXACT>
+__device__ __forceinline__ void general_step(const int kind, const int o, const DevOp& op, const double G, const HeadConsts* __restrict__ tab,
+                                             const Part (&p)[2], V3 (&acc)[2], Geo (&g)[2], const GeneralLane& L, StreamShared& sh) {
+    const Src S = tab->src[o];
+    double bx = 0., by = 0., bz = 0.;
+    if (L.act0 && L.i0 != op.src) general_op<EXACT>(kind, op, S, G, p[0], g[0], acc[0], bx, by, bz);
+    if (L.act1 && L.i0 + 1 != op.src) general_op<EXACT>(kind, op, S, G, p[1], g[1], acc[1], bx, by, bz);
+    if (op.slot >= 0) {
+        // a wavefront whose bodies are all massless pushes on nothing
+        if (L.any_mass) { bx = wave_sum(bx); by = wave_sum(by); bz = wave_sum(bz); }
+        else { bx = by = bz = 0.; }
+        if (L.lane == 0) { sh.part[L.wave][op.slot][0] = bx; sh.part[L.wave][op.slot][1] = by; sh.part[L.wave][op.slot][2] = bz; }
+    }
+}
+template <bool EXACT, Sig SIG, int O>
+__device__ __forceinline__ void general_fixed(const Program& prog, const HeadConsts* __restrict__ tab, const Part (&p)[2], V3 (&acc)[2], Geo (&g)[2],
+                                              const GeneralLane& L, StreamShared& sh) {
+    constexpr int kind = (int)((SIG >> (4 * O)) & 15ull);
+    if constexpr (kind != 0) {
+        general_step<EXACT>(kind, O, prog.ops[O], prog.G, tab, p, acc, g, L, sh);
+        general_fixed<EXACT, SIG, O + 1>(prog, tab, p, acc, g, L, sh);
+    }
+}
+
+template <bool EXACT, bool BACKREACT, bool VEC2, int COLS, Sig SIG = 0ull>
 __global__ __launch_bounds__(BLOCK, (!EXACT && !BACKREACT && COLS != COL_ALL) ? 4 : 3) void stream_kernel(View v, Program prog, long long lo, long long base,
                                                        const HeadConsts* __restrict__ tab, double* partials, unsigned* status) {
     const int tid = threadIdx.x;
-    const double G = prog.G;
     const long long i0 = base + 2 * ((long long)blockIdx.x * BLOCK + tid);
     const bool in0 = i0 < v.n, in1 = i0 + 1 < v.n;
     const bool act0 = in0 && i0 >= lo, act1 = in1 && i0 + 1 >= lo;
@@ -502,26 +572,19 @@ __global__ __launch_bounds__(BLOCK, (!EXACT && !BACKREACT && COLS != COL_ALL) ? 
 
     if (!BACKREACT) {
         // one particle after the other keeps the live register set small
-        if (act0) tail_particle<EXACT>(prog, tab, p[0], acc[0], status);
-        if (act1) tail_particle<EXACT>(prog, tab, p[1], acc[1], status);
+        if (act0) tail_particle<EXACT, SIG>(prog, tab, p[0], acc[0], status);
+        if (act1) tail_particle<EXACT, SIG>(prog, tab, p[1], acc[1], status);
     } else {
         __shared__ StreamShared sh;
         const int wave = tid >> 6, lane = tid & 63;
         Geo g[2];
         g[0].src = -1; g[0].dx = g[0].dy = g[0].dz = g[0].ri = 0.; g[1] = g[0];
         const bool any_mass = __ballot((act0 && p[0].m != 0.) || (act1 && p[1].m != 0.)) != 0ull;
-        for (int o = 0; o < prog.nops; o++) {
-            const DevOp op = prog.ops[o];
-            const Src S = tab->src[o];
-            double bx = 0., by = 0., bz = 0.;
-            if (act0 && i0 != op.src) general_op<EXACT>(op, S, G, p[0], g[0], acc[0], bx, by, bz);
-            if (act1 && i0 + 1 != op.src) general_op<EXACT>(op, S, G, p[1], g[1], acc[1], bx, by, bz);
-            if (op.slot >= 0) {
-                // a wavefront whose bodies are all massless pushes on nothing
-                if (any_mass) { bx = wave_sum(bx); by = wave_sum(by); bz = wave_sum(bz); }
-                else { bx = by = bz = 0.; }
-                if (lane == 0) { sh.part[wave][op.slot][0] = bx; sh.part[wave][op.slot][1] = by; sh.part[wave][op.slot][2] = bz; }
-            }
+        GeneralLane L = {i0, act0, act1, any_mass, wave, lane};
+        if constexpr (SIG != 0ull) {
+            general_fixed<EXACT, SIG, 0>(prog, tab, p, acc, g, L, sh);
+        } else {
+            for (int o = 0; o < prog.nops; o++) general_step<EXACT>(prog.ops[o].kind, o, prog.ops[o], prog.G, tab, p, acc, g, L, sh);
         }
         __syncthreads();
         if (tid < prog.nslots * 3) {
@@ -653,10 +716,32 @@ hipError_t launch_head(const View& v, const Program& prog, HeadConsts* hc, unsig
 }
 
 template <bool EXACT, bool BACKREACT>
-static void launch_stream_cols(dim3 g, dim3 b, hipStream_t st, bool vec2, int cols, const View& v, const Program& prog, long long lo,
+static void launch_stream_cols(dim3 g, dim3 b, hipStream_t st, bool vec2, bool fixed, int cols, const View& v, const Program& prog, long long lo,
                                long long base, const HeadConsts* hc, double* partials, unsigned* status) {
 #define LAUNCH(V, C) hipLaunchKernelGGL((stream_kernel<EXACT, BACKREACT, V, C>), g, b, 0, st, v, prog, lo, base, hc, partials, status)
     if (!vec2) { LAUNCH(false, COL_ALL); return; }
+    // stacks with an instance of their own
+    Sig sig = 0ull;
+    if (fixed && prog.nops <= 8) for (int o = 0; o < prog.nops; o++) sig |= (Sig)(prog.ops[o].kind & 15) << (4 * o);
+#define FIXED(...) \
+    { constexpr Sig S_ = sig_of(__VA_ARGS__); \
+      if (sig == S_) { hipLaunchKernelGGL((stream_kernel<EXACT, BACKREACT, true, sig_cols(S_, !BACKREACT), S_>), g, b, 0, st, v, prog, lo, base, hc, partials, status); return; } }
+    if constexpr (!BACKREACT) {
+        FIXED(REBXAMD_OP_RADIATION, REBXAMD_OP_J2, REBXAMD_OP_J4, REBXAMD_OP_GR)
+        FIXED(REBXAMD_OP_RADIATION, REBXAMD_OP_J2, REBXAMD_OP_J4, REBXAMD_OP_GR_POTENTIAL, REBXAMD_OP_TIDES, REBXAMD_OP_MOF)
+        FIXED(REBXAMD_OP_RADIATION)
+        FIXED(REBXAMD_OP_J2, REBXAMD_OP_J4)
+        FIXED(REBXAMD_OP_GR)
+        FIXED(REBXAMD_OP_GR_POTENTIAL)
+        FIXED(REBXAMD_OP_MOF)
+    } else {
+        FIXED(REBXAMD_OP_TIDES, REBXAMD_OP_MOF, REBXAMD_OP_GR_POTENTIAL)
+        FIXED(REBXAMD_OP_J2, REBXAMD_OP_J4)
+        FIXED(REBXAMD_OP_GR_POTENTIAL)
+        FIXED(REBXAMD_OP_TIDES)
+        FIXED(REBXAMD_OP_MOF)
+    }
+#undef FIXED
     if (cols == 0) LAUNCH(true, 0);
     else if ((cols & ~(COL_VEL | COL_BETA)) == 0) LAUNCH(true, COL_VEL | COL_BETA);
     else if ((cols & ~(COL_VEL | COL_TIDES | COL_TAU)) == 0) LAUNCH(true, COL_VEL | COL_TIDES | COL_TAU);
@@ -665,7 +750,7 @@ static void launch_stream_cols(dim3 g, dim3 b, hipStream_t st, bool vec2, int co
 }
 
 hipError_t launch_stream(const View& v, const Program& prog, long long lo, const HeadConsts* hc, double* partials,
-                         int* nblocks_out, bool backreact, bool exact, bool vec2, unsigned* status, hipStream_t st) {
+                         int* nblocks_out, bool backreact, bool exact, bool vec2, bool fixed, unsigned* status, hipStream_t st) {
     const long long base = lo & ~1ll;
     const int nb = stream_block_count(lo, v.n, vec2);
     if (nblocks_out) *nblocks_out = nb;
@@ -673,11 +758,11 @@ hipError_t launch_stream(const View& v, const Program& prog, long long lo, const
     const dim3 g(nb), b(BLOCK);
     const int cols = (prog.need_vel ? COL_VEL : 0) | (prog.need_beta ? COL_BETA : 0) | (prog.need_tides ? COL_TIDES : 0) | (prog.need_tau ? COL_TAU : 0);
     if (exact) {
-        if (backreact) launch_stream_cols<true, true>(g, b, st, vec2, cols, v, prog, lo, base, hc, partials, status);
-        else launch_stream_cols<true, false>(g, b, st, vec2, cols, v, prog, lo, base, hc, partials, status);
+        if (backreact) launch_stream_cols<true, true>(g, b, st, vec2, fixed, cols, v, prog, lo, base, hc, partials, status);
+        else launch_stream_cols<true, false>(g, b, st, vec2, fixed, cols, v, prog, lo, base, hc, partials, status);
     } else {
-        if (backreact) launch_stream_cols<false, true>(g, b, st, vec2, cols, v, prog, lo, base, hc, partials, status);
-        else launch_stream_cols<false, false>(g, b, st, vec2, cols, v, prog, lo, base, hc, partials, status);
+        if (backreact) launch_stream_cols<false, true>(g, b, st, vec2, fixed, cols, v, prog, lo, base, hc, partials, status);
+        else launch_stream_cols<false, false>(g, b, st, vec2, fixed, cols, v, prog, lo, base, hc, partials, status);
     }
     return hipGetLastError();
 }

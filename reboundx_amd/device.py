@@ -145,6 +145,10 @@ class Context:
     def timing_enable(self, on=True):
         self._check(lib.rebxamd_timing_enable(self._h, 1 if on else 0))
 
+    def fixed_stacks(self, on=True):
+        """Whether stacks with a kernel instance of their own use it (default) or walk the op list."""
+        self._check(lib.rebxamd_fixed_stacks(self._h, 1 if on else 0))
+
     def timing_read(self):
         ms, cnt = ctypes.c_double(0), ctypes.c_int(0)
         self._check(lib.rebxamd_timing_read(self._h, ctypes.byref(ms), ctypes.byref(cnt)))

@@ -17,6 +17,8 @@ n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 C = synthetic.C_DEFAULT
 ctx = Context(0)
+if os.environ.get("FIXED") == "0":          # walk the op list even for stacks with an instance of their own
+    ctx.fixed_stacks(False)
 
 CONFIGS = {
     "C2 rad+J2J4+gr (112 B)": (0.0, 112, [("radiation_forces", {"c": C}), ("gravitational_harmonics", {}), ("gr", {"c": C})]),

@@ -94,6 +94,47 @@ def test_central_force(ctx, gamma, mode):
     check(ctx, zero_acc(cols), pp, [("central_force", {})], mode, pow_ulps=16)
 
 
+C5_STACK = [("radiation_forces", {"c": C}), ("gravitational_harmonics", {}), ("gr_potential", {"c": C}),
+            ("tides_precession", {}), ("modify_orbits_forces", {"coordinates": 2})]
+FIXED_STACKS = [C2_STACK, C5_STACK, [("radiation_forces", {"c": C})], [("gravitational_harmonics", {})], [("gr", {"c": C})],
+                [("gr_potential", {"c": C})], [("tides_precession", {})], [("modify_orbits_forces", {"coordinates": 2})],
+                [("tides_precession", {}), ("modify_orbits_forces", {"coordinates": 2}), ("gr_potential", {"c": C})]]
+
+
+@pytest.mark.parametrize("mode", [EXACT, FAST])
+@pytest.mark.parametrize("dust_mass", [0.0, 1e-13])
+@pytest.mark.parametrize("stack", FIXED_STACKS, ids=lambda s: "+".join(f[0] for f in s))
+def test_kernel_instances_built_for_a_stack_agree_with_the_op_list_walk(ctx, stack, dust_mass, mode):
+    """Stacks with a kernel instance of their own (massless tail and all-massive layouts) against
+    the same stack run by walking the op list, and both against the checker."""
+    n = 40003
+    cols, pp, _ = synthetic.disk(n, 2 if dust_mass == 0.0 else 0, dust_mass=dust_mass)
+    pp["primary"] = np.zeros(n, dtype=np.uint8)
+    pp["primary"][0] = 1
+    synthetic.add_newtonian(cols, n_head=3 if dust_mass == 0.0 else 1)
+    if dust_mass != 0.0 and any(f[0] == "gr" for f in stack):
+        pytest.skip("gr with every particle massive runs on the prefix-sum passes")
+    ref = run_oracle(cols, pp, stack)
+    try:
+        ctx.fixed_stacks(False)
+        walked, _ = run_device(ctx, cols, pp, stack, 1.0, mode)
+    finally:
+        ctx.fixed_stacks(True)
+    fixed, _ = run_device(ctx, cols, pp, stack, 1.0, mode)
+    nhead = 3 if dust_mass == 0.0 else 1
+    if mode == EXACT:
+        assert ulp_diff(fixed[:, nhead:], walked[:, nhead:]).max() == 0
+    for got in (walked, fixed):
+        assert rel_err(got[:, nhead:], ref[:, nhead:]).max() <= TOL
+        # rows of bodies that collect pushes from the others: bar relative to the summed terms
+        scale = np.maximum(np.abs(ref[:, :nhead]).max(), np.abs(ref[:, nhead:] - cols_acc(cols)[:, nhead:]).max() * max(dust_mass, 1e-300) * n)
+        assert np.abs(got[:, :nhead] - ref[:, :nhead]).max() <= 1e-12 * scale
+
+
+def cols_acc(cols):
+    return np.stack([cols["ax"], cols["ay"], cols["az"]])
+
+
 C3_STACK = [("tides_precession", {}), ("modify_orbits_forces", {"coordinates": 2}), ("gr_potential", {"c": C})]
 
 
