@@ -252,10 +252,16 @@ def main():
                                              "one thread alone: %.3g evals/s" % (args.cpu_reps, n_local, threads, secs, single)}
     gr = None
     if args.grfull_n > 0:
-        gr = grfull_section(ctx, args.grfull_n, mode, dist, "cuda:%d" % local_rank)     # collective: every rank takes part
+        try:
+            gr = grfull_section(ctx, args.grfull_n, mode, dist, "cuda:%d" % local_rank)     # collective: every rank takes part
+        except Exception as e:  # noqa: BLE001 -- a failure of this secondary section must not lose the headline line
+            gr = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         if args.c5_n > 0:
-            out["resident_run"] = c5_section(ctx, args.c5_n, args.c5_steps, mode, "cuda:%d" % local_rank)
+            try:
+                out["resident_run"] = c5_section(ctx, args.c5_n, args.c5_steps, mode, "cuda:%d" % local_rank)
+            except Exception as e:  # noqa: BLE001
+                out["resident_run"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if gr is not None:
             out["gr_full"] = gr
         print(json.dumps(out), flush=True)

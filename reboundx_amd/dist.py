@@ -132,7 +132,8 @@ class HipGrFullEngine:
 def grfull_sharded(engine, c, gravity_ignore_10=0, group=None):
     """One gr_full evaluation (reference src/gr_full.c:61-231) with rows sharded over the
     ranks of `group`.  Adds the result to the engine's particle accelerations on every rank
-    and returns the number of sweeps run.  With no process group it runs all rows locally.
+    and returns the number of sweeps run.  With no process group it runs all rows locally; with
+    one, the collectives run whatever its size (a one-rank group exercises the same calls).
 
     Communication per evaluation: one all-gather of the potential sums (8 B per body) and ONE
     all-gather per sweep that carries the rank's rows of the three new acceleration columns and
@@ -151,13 +152,13 @@ def grfull_sharded(engine, c, gravity_ignore_10=0, group=None):
     ao3, out3 = engine.zeros(3, npad), engine.zeros(3, npad)       # rows of one tensor, so that one copy packs them
     pot = engine.zeros(npad)
     flag = engine.flag()
-    if world > 1:
+    if use_dist:
         send = engine.zeros(3 * per + 1)
         recv_flat = engine.zeros(world * (3 * per + 1))
         recv = recv_flat.view(world, 3 * per + 1)
     engine.newton(gravity_ignore_10, an, [ao3[0], ao3[1], ao3[2]])   # replicated: every rank holds the full incoming field
     engine.pot(c, r0, r1, pot)
-    if world > 1:
+    if use_dist:
         dist.all_gather_into_tensor(pot, pot[rank * per:(rank + 1) * per].clone(), group=group)
     engine.const(c, r0, r1, pot, ac)
     sweeps = 0
@@ -165,7 +166,7 @@ def grfull_sharded(engine, c, gravity_ignore_10=0, group=None):
         sweeps = k + 1
         flag.zero_()
         engine.sweep(c, r0, r1, an, [ao3[0], ao3[1], ao3[2]], ac, [out3[0], out3[1], out3[2]], flag)
-        if world > 1:
+        if use_dist:
             send[:3 * per].view(3, per).copy_(out3.view(3, world, per)[:, rank, :])
             send[3 * per:].copy_(flag)
             dist.all_gather_into_tensor(recv_flat, send, group=group)

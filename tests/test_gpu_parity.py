@@ -492,6 +492,19 @@ def test_gr_full_sharded_driver_on_the_hip_engine(ctx):
     assert ulp_diff(np.array(dp.acc_host()), np.array(ref.acc)).max() == 0
 
 
+def test_multi_gpu_drivers_over_a_one_rank_rccl_group():
+    """torch.distributed backend "nccl" (RCCL) on this GPU: the sharded gr_full driver and the
+    sharded per-particle driver make the same collective calls as on several GPUs and must
+    reproduce the runs made without a process group (child process: tests/rccl_one_rank.py)."""
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_one_rank.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-u", script], capture_output=True, text=True, timeout=110, env=env)
+    assert r.returncode == 0 and "rccl one-rank ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 @pytest.mark.parametrize("mode", [EXACT, FAST])
 def test_particle_sharded_run_with_massive_slices_matches_unsharded_checker(ctx, mode):
     """Config C3 on several devices: every grain has mass, so each shard's pushes on the star
