@@ -140,9 +140,10 @@ def c5_section(ctx, n, steps, mode, device):
     queued = (time.perf_counter() - t0) / steps
     x = dp.cols["x"]
     finite = bool(torch.isfinite(x).all().item())
-    # per queued step: the fused force pass (152 B) and one kick+drift pass (neighbouring half
-    # drifts merge; pos, vel, acc read, pos, vel written, acc cleared: 144 B)
-    bytes_per_step = (152 + 144) * n
+    # per queued step one pass over the grains carries forces, kick and drift: positions, velocities,
+    # mass and the six parameters read (104 B), positions and velocities written (48 B); the
+    # accelerations stay in registers
+    bytes_per_step = 152 * n
     return {"n": n, "steps": steps, "effects": 5, "us_per_step_host_synced": synced * 1e6, "us_per_step_queued": queued * 1e6,
             "particle_steps_per_s": n / queued, "state_finite": finite,
             "roofline": {"bound": "hbm", "achieved": bytes_per_step / queued / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -469,6 +469,12 @@ int rebxamd_timing_enable(rebxamd_ctx* ctx, int on);
  * Both compute the same expressions.  on = 0 makes this context always walk the list
  * (default: 1). */
 int rebxamd_fixed_stacks(rebxamd_ctx* ctx, int on);
+/* Kernel selection for rebxamd_wh_steps (no counterpart in the reference).  When the force stack
+ * is one streaming run, the pass over the massless bodies also kicks and drifts them, so that
+ * their accelerations never go through memory (the acceleration columns stay zero).  on = 0 makes
+ * this context run force pass and kick+drift pass separately (default: 1).  Both compute the
+ * same expressions. */
+int rebxamd_carried_steps(rebxamd_ctx* ctx, int on);
 int rebxamd_timing_read(rebxamd_ctx* ctx, double* total_ms, int* launches);
 
 /* gr_full on one device (gr_full.c:61-231).  The three phases are also exposed on row

@@ -66,6 +66,7 @@ _sig = {
     "rebxamd_fetch_warnings": (c_int, [c_void_p, POINTER(c_uint32), c_void_p]),
     "rebxamd_timing_enable": (c_int, [c_void_p, c_int]),
     "rebxamd_fixed_stacks": (c_int, [c_void_p, c_int]),
+    "rebxamd_carried_steps": (c_int, [c_void_p, c_int]),
     "rebxamd_timing_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int)]),
     "rebxamd_grfull_newton": (c_int, [c_void_p, POINTER(View), c_int] + [c_void_p] * 6 + [c_void_p]),
     "rebxamd_grfull_finish": (c_int, [c_void_p, POINTER(View), c_void_p, c_void_p, c_void_p, c_void_p]),

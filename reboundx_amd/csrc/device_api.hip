@@ -31,6 +31,7 @@ struct rebxamd_ctx {
     size_t scan_cap = 0;
     // optional timing of the dominant kernels with HIP events on the launch stream
     bool timing = false;
+    bool carried_steps = true;  // Wisdom-Holman runs: kick and drift ride in the force pass when the layout allows
     bool fixed_stacks = true;   // stacks with a kernel instance of their own use it
     std::vector<hipEvent_t> ev;         // pairs: start, stop
     size_t ev_used = 0;
@@ -122,6 +123,12 @@ extern "C" int rebxamd_timing_enable(rebxamd_ctx* ctx, int on) {
 extern "C" int rebxamd_fixed_stacks(rebxamd_ctx* ctx, int on) {
     if (!ctx) return REBXAMD_ERR_ARG;
     ctx->fixed_stacks = on != 0;
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_carried_steps(rebxamd_ctx* ctx, int on) {
+    if (!ctx) return REBXAMD_ERR_ARG;
+    ctx->carried_steps = on != 0;
     return REBXAMD_OK;
 }
 
@@ -223,8 +230,12 @@ static bool has_backreaction(const rebxamd_op& o) {
 // target_lo < 0: the normal path.  target_lo >= 0 (sharded runs): forces act on particles
 // [target_lo, n) only, every layout goes through the reduction path, and the per-op pushes on
 // the sources are stored in sums_out (device, 3 doubles per op of the run) instead of applied.
+// step != nullptr (Wisdom-Holman runs): when the layout takes the head + massless-tail path, body
+// 0 is recorded and drifted after the head pass and the tail pass carries the kick and the drift
+// of every other body (no acceleration traffic); any other layout returns STEP_NOT_CARRIED untouched.
+static constexpr int STEP_NOT_CARRIED = -1000;
 static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_op* ops, int lo, int hi, int mode, hipStream_t st,
-                         long long target_lo = -1, double* sums_out = nullptr, bool pushes_only = false) {
+                         long long target_lo = -1, double* sums_out = nullptr, bool pushes_only = false, const StepArgs* step = nullptr) {
     const View v = make_view(u);
     Program prog;
     memset(&prog, 0, sizeof(prog));
@@ -286,11 +297,18 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
     const long long K = v.n_head < v.n ? v.n_head : v.n;
     const bool sparse = target_lo < 0 && (u->tail_massless != 0 || K == v.n) && K >= 1 && K <= REBXAMD_MAX_HEAD && max_src < K;
 
+    if (step && !(sparse && K == 1)) return STEP_NOT_CARRIED;
     if (sparse) {
         HIP_TRY(launch_head(v, prog, ctx->hc, ctx->status, exact, st));
+        if (step) {
+            double* const x[3] = {const_cast<double*>(u->x), const_cast<double*>(u->y), const_cast<double*>(u->z)};
+            double* const vel[3] = {const_cast<double*>(u->vx), const_cast<double*>(u->vy), const_cast<double*>(u->vz)};
+            double* const a[3] = {u->ax, u->ay, u->az};
+            HIP_TRY(launch_wh_star(x, vel, a, step->h, ctx->star, st));
+        }
         if (v.n > K) {
             TimedLaunch tl(ctx, st);
-            HIP_TRY(launch_stream(v, prog, K, ctx->hc, nullptr, nullptr, false, exact, vec2, ctx->fixed_stacks, ctx->status, st));
+            HIP_TRY(launch_stream(v, prog, K, ctx->hc, nullptr, nullptr, false, exact, vec2, ctx->fixed_stacks, ctx->status, st, step));
         }
         return REBXAMD_OK;
     }
@@ -571,12 +589,29 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
     HIP_TRY(launch_wh_drift(x, v, nullptr, mu, 0.5 * dt, 0., view->n, ctx->star, exact, st));
     rc = rebxamd_reset_accelerations(ctx, view, stream);
     if (rc != REBXAMD_OK) return rc;
+    // When the whole stack is one streaming run, the pass over the massless bodies carries the
+    // kick and the drift as well: their accelerations never leave registers.
+    bool carried = ctx->carried_steps && nops > 0 && nops <= REBXAMD_MAX_OPS;
+    int ngr = 0, ncom = 0;
+    for (int k = 0; k < nops && carried; k++) {
+        if (ops[k].kind == REBXAMD_OP_GR_FULL) carried = false;
+        if (ops[k].kind == REBXAMD_OP_GR && ++ngr > 1) carried = false;
+        if (ops[k].kind == REBXAMD_OP_MOF && ops[k].iarg != REBX_COORDINATES_PARTICLE && ++ncom > 1) carried = false;
+    }
     for (int64_t k = 0; k < nsteps; k++) {
+        const double h = k + 1 < nsteps ? dt : 0.5 * dt;
+        if (carried) {
+            const StepArgs sa = {mu, h, dt, ctx->star};
+            rc = run_streaming(ctx, view, ops, 0, nops, mode, st, -1, nullptr, false, &sa);
+            if (rc == REBXAMD_OK) continue;
+            if (rc != STEP_NOT_CARRIED) return rc;
+            carried = false;
+        }
         if (nops > 0) {
             rc = rebxamd_apply(ctx, view, ops, nops, mode, stream);
             if (rc != REBXAMD_OK) return rc;
         }
-        HIP_TRY(launch_wh_drift(x, v, a, mu, k + 1 < nsteps ? dt : 0.5 * dt, dt, view->n, ctx->star, exact, st));
+        HIP_TRY(launch_wh_drift(x, v, a, mu, h, dt, view->n, ctx->star, exact, st));
     }
     return REBXAMD_OK;
 }

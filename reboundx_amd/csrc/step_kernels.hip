@@ -5,6 +5,7 @@
 // expression order without FMA contraction (bitwise equal to a non-FMA CPU build).
 #include "internal.h"
 #include "effects.h"
+#include "kepler.h"
 
 namespace rebxamd {
 
@@ -132,138 +133,7 @@ __global__ __launch_bounds__(1024) void im_sum_kernel(const double* partials, lo
 
 // ---------------------------------------------------------------- Wisdom-Holman drift and kick
 // for one dominant mass at index 0 and massless bodies behind it (the layout of a debris-disk
-// run).  REBOUND owns this step in a host run; on the device it is what keeps a multi-step run
-// resident.  In Jacobi coordinates massless bodies do not move the interior centre of mass, so
-// body i >= 1 is propagated on a Kepler orbit about body 0 with mass parameter G*m0 (universal
-// variables, Stumpff series), and body 0 drifts linearly.
-
-// c_n(z) = sum_k (-z)^k / (2k+n)!  for n = 0..3: series after quartering the argument until
-// |z| <= 0.1 (nine terms leave < 1e-23), then the duplication formulas.
-#define REBXAMD_STUMPFF_BODY                                                                         \
-    c3 = 1. / 121645100408832000.; c2 = 1. / 6402373705728000.;                                      \
-    c3 = 1. / 355687428096000. - z * c3; c2 = 1. / 20922789888000. - z * c2;                         \
-    c3 = 1. / 1307674368000. - z * c3;   c2 = 1. / 87178291200. - z * c2;                            \
-    c3 = 1. / 6227020800. - z * c3;      c2 = 1. / 479001600. - z * c2;                              \
-    c3 = 1. / 39916800. - z * c3;        c2 = 1. / 3628800. - z * c2;                                \
-    c3 = 1. / 362880. - z * c3;          c2 = 1. / 40320. - z * c2;                                  \
-    c3 = 1. / 5040. - z * c3;            c2 = 1. / 720. - z * c2;                                    \
-    c3 = 1. / 120. - z * c3;             c2 = 1. / 24. - z * c2;                                     \
-    c3 = 1. / 6. - z * c3;               c2 = 1. / 2. - z * c2;                                      \
-    c1 = 1. - z * c3; c0 = 1. - z * c2;                                                              \
-    for (; n > 0; n--) {                                                                             \
-        z *= 4.;                                                                                     \
-        c3 = 0.25 * (c2 + c0 * c3);                                                                  \
-        c2 = 0.5 * c1 * c1;                                                                          \
-        c1 = c0 * c1;                                                                                \
-        c0 = 2. * c0 * c0 - 1.;                                                                      \
-    }
-
-template <bool EXACT>
-__device__ __forceinline__ void stumpff_dev(double z, double (&c)[4]) {
-    int n = 0;
-    while (fabs(z) > 0.1) { z *= 0.25; n++; }
-    double c3, c2, c1, c0;
-    if (EXACT) {
-#pragma clang fp contract(off)
-        REBXAMD_STUMPFF_BODY
-    } else {
-        REBXAMD_STUMPFF_BODY
-    }
-    c[0] = c0; c[1] = c1; c[2] = c2; c[3] = c3;
-}
-
-template <bool EXACT>
-__device__ __forceinline__ void gfuncs_dev(double beta, double X, double (&G)[4]) {
-    double c[4];
-    const double X2 = X * X;
-    stumpff_dev<EXACT>(beta * X2, c);
-    if (EXACT) {
-#pragma clang fp contract(off)
-        G[0] = c[0]; G[1] = X * c[1]; G[2] = X2 * c[2]; G[3] = X2 * X * c[3];
-    } else {
-        G[0] = c[0]; G[1] = X * c[1]; G[2] = X2 * c[2]; G[3] = X2 * X * c[3];
-    }
-}
-
-// two-body propagation of the relative state (x, v) about mass parameter M over dt.
-// Reference-order arithmetic: Newton on the universal Kepler equation from the second-order
-// guess, IEEE division and square root, iterated to a fixed point (the checker's algorithm).
-__device__ __forceinline__ void kepler_exact(double (&q)[6], double M, double dt) {
-#pragma clang fp contract(off)
-    const double x0 = q[0], y0 = q[1], z0 = q[2], vx0 = q[3], vy0 = q[4], vz0 = q[5];
-    const double r0 = sqrt(x0 * x0 + y0 * y0 + z0 * z0);
-    const double r0i = 1. / r0;
-    const double v2 = vx0 * vx0 + vy0 * vy0 + vz0 * vz0;
-    const double beta = 2. * M * r0i - v2;
-    const double eta0 = x0 * vx0 + y0 * vy0 + z0 * vz0;
-    const double zeta0 = M - beta * r0;
-    double X = dt * r0i * (1. - 0.5 * dt * eta0 * r0i * r0i);
-    double G[4];
-    double lo = -HUGE_VAL, hi = HUGE_VAL, prev1 = __builtin_nan(""), prev2 = __builtin_nan("");
-    for (int it = 0; it < 60; it++) {
-        gfuncs_dev<true>(beta, X, G);
-        const double s = r0 * X + eta0 * G[2] + zeta0 * G[3] - dt;
-        const double sp = r0 + eta0 * G[1] + zeta0 * G[2];
-        double Xn = X - s / sp;
-        if (s > 0.) hi = X; else lo = X;
-        if (!(Xn > lo && Xn < hi)) Xn = (isfinite(lo) && isfinite(hi)) ? 0.5 * (lo + hi) : Xn;
-        if (Xn == X || Xn == prev1 || Xn == prev2) { X = Xn; break; }
-        prev2 = prev1; prev1 = X; X = Xn;
-    }
-    gfuncs_dev<true>(beta, X, G);
-    const double r = r0 + eta0 * G[1] + zeta0 * G[2];
-    const double ri = 1. / r;
-    const double fm1 = -M * G[2] * r0i, g = dt - M * G[3], fd = -M * G[1] * r0i * ri, gdm1 = -M * G[2] * ri;
-    q[0] += fm1 * x0 + g * vx0; q[1] += fm1 * y0 + g * vy0; q[2] += fm1 * z0 + g * vz0;
-    q[3] += fd * x0 + gdm1 * vx0; q[4] += fd * y0 + gdm1 * vy0; q[5] += fd * z0 + gdm1 * vz0;
-}
-
-// Default arithmetic: refined hardware reciprocals, third-order starting guess and Halley's
-// method (cubic convergence): a step shorter than 1e-6 of X leaves an error below rounding, so
-// the usual cost is two evaluations of the G functions plus the final one.  The bracket of the
-// root (the residual is monotonic in X: its derivative is r > 0) guards every step.
-__device__ __forceinline__ void kepler_fast(double (&q)[6], double M, double dt) {
-    const double x0 = q[0], y0 = q[1], z0 = q[2], vx0 = q[3], vy0 = q[4], vz0 = q[5];
-    const double r2 = x0 * x0 + y0 * y0 + z0 * z0;
-    const double r0i = fast_rsqrt(r2);
-    const double r0 = r2 * r0i;
-    const double v2 = vx0 * vx0 + vy0 * vy0 + vz0 * vz0;
-    const double beta = 2. * M * r0i - v2;
-    const double eta0 = x0 * vx0 + y0 * vy0 + z0 * vz0;
-    const double zeta0 = M - beta * r0;
-    // series inversion of r0 X + eta0 X^2/2 + zeta0 X^3/6 = dt
-    const double u = dt * r0i, a = 0.5 * eta0 * r0i, b = zeta0 * r0i * (1. / 6.);
-    double X = u * (1. - u * (a - u * (2. * a * a - b)));
-    double G[4];
-    double lo = -HUGE_VAL, hi = HUGE_VAL, prev = __builtin_nan("");
-    for (int it = 0; it < 60; it++) {
-        gfuncs_dev<false>(beta, X, G);
-        const double s = r0 * X + eta0 * G[2] + zeta0 * G[3] - dt;
-        const double sp = r0 + eta0 * G[1] + zeta0 * G[2];
-        const double spp = eta0 * G[0] + zeta0 * G[1];
-        if (s > 0.) hi = X; else lo = X;
-        // Halley: dX = -s / (s' - s s'' / (2 s'))
-        const double spi = fast_rcp(sp);
-        const double dX = -s * fast_rcp(sp - 0.5 * s * spp * spi);
-        double Xn = X + dX;
-        const bool inside = Xn > lo && Xn < hi;
-        if (!inside) Xn = (isfinite(lo) && isfinite(hi)) ? 0.5 * (lo + hi) : X - s * spi;
-        const bool done = (inside && fabs(dX) <= 1e-6 * fabs(Xn)) || Xn == X || Xn == prev;
-        prev = X; X = Xn;
-        if (done) break;
-    }
-    gfuncs_dev<false>(beta, X, G);
-    const double r = r0 + eta0 * G[1] + zeta0 * G[2];
-    const double ri = fast_rcp(r);
-    const double fm1 = -M * G[2] * r0i, g = dt - M * G[3], fd = -M * G[1] * r0i * ri, gdm1 = -M * G[2] * ri;
-    q[0] += fm1 * x0 + g * vx0; q[1] += fm1 * y0 + g * vy0; q[2] += fm1 * z0 + g * vz0;
-    q[3] += fd * x0 + gdm1 * vx0; q[4] += fd * y0 + gdm1 * vy0; q[5] += fd * z0 + gdm1 * vz0;
-}
-
-template <bool EXACT>
-__device__ __forceinline__ void kepler_dev(double (&q)[6], double M, double dt) {
-    if (EXACT) kepler_exact(q, M, dt); else kepler_fast(q, M, dt);
-}
+// run); the propagation itself is in kepler.h.
 
 // star[0..5] <- state of body 0 before the drift; body 0 drifts linearly; star[6..8] <- its new
 // position.  With accelerations given: star[9..11] <- a_0, and a_0 is cleared for the next force pass.
@@ -287,28 +157,15 @@ template <bool EXACT, bool KICK>
 __global__ __launch_bounds__(TB) void wh_drift_kernel(Cols3 x, Cols3 v, Cols3 a, double mu, double h, double dtk, long long n, const double* __restrict__ star) {
     const long long i = (long long)blockIdx.x * TB + threadIdx.x + 1;
     if (i >= n) return;
-    double q[6];
-    {
-#pragma clang fp contract(off)
-        double vx = v.x[i], vy = v.y[i], vz = v.z[i];
-        if (KICK) {
-            const double ax = a.x[i], ay = a.y[i], az = a.z[i];
-            a.x[i] = 0.; a.y[i] = 0.; a.z[i] = 0.;
-            if (EXACT) {
-                vx += dtk * (ax - star[9]); vy += dtk * (ay - star[10]); vz += dtk * (az - star[11]);
-            } else {
-                vx = fma(dtk, ax - star[9], vx); vy = fma(dtk, ay - star[10], vy); vz = fma(dtk, az - star[11], vz);
-            }
-        }
-        q[0] = x.x[i] - star[0]; q[1] = x.y[i] - star[1]; q[2] = x.z[i] - star[2];
-        q[3] = vx - star[3]; q[4] = vy - star[4]; q[5] = vz - star[5];
+    double s[6] = {x.x[i], x.y[i], x.z[i], v.x[i], v.y[i], v.z[i]};
+    double ax = 0., ay = 0., az = 0.;
+    if (KICK) {
+        ax = a.x[i]; ay = a.y[i]; az = a.z[i];
+        a.x[i] = 0.; a.y[i] = 0.; a.z[i] = 0.;
     }
-    kepler_dev<EXACT>(q, mu, h);
-    {
-#pragma clang fp contract(off)
-        x.x[i] = q[0] + star[6]; x.y[i] = q[1] + star[7]; x.z[i] = q[2] + star[8];
-        v.x[i] = q[3] + star[3]; v.y[i] = q[4] + star[4]; v.z[i] = q[5] + star[5];
-    }
+    wh_kick_drift<EXACT, KICK>(s, ax, ay, az, mu, h, dtk, star);
+    x.x[i] = s[0]; x.y[i] = s[1]; x.z[i] = s[2];
+    v.x[i] = s[3]; v.y[i] = s[4]; v.z[i] = s[5];
 }
 
 static inline dim3 grid_for(long long n) { return dim3((unsigned)((n + TB - 1) / TB)); }
@@ -359,6 +216,15 @@ hipError_t launch_im_update(double* const fin[3], const double* const orig[3], d
     if (exact) hipLaunchKernelGGL(im_update_kernel<true>, grid_for(n), dim3(TB), 0, st, f, o, av, aa, dt, n, partials);
     else hipLaunchKernelGGL(im_update_kernel<false>, grid_for(n), dim3(TB), 0, st, f, o, av, aa, dt, n, partials);
     hipLaunchKernelGGL(im_sum_kernel, dim3(1), dim3(1024), 0, st, partials, im_partial_count(n), sums);
+    return hipGetLastError();
+}
+
+// Body 0 alone: records its state (and acceleration, which is cleared) in `star` and drifts it.
+hipError_t launch_wh_star(double* const x[3], double* const v[3], double* const a[3], double h, double* star, hipStream_t st) {
+    const Cols3 cx = {x[0], x[1], x[2]};
+    const Cols3 ca = a ? Cols3{a[0], a[1], a[2]} : Cols3{nullptr, nullptr, nullptr};
+    const CCols3 ccv = {v[0], v[1], v[2]};
+    hipLaunchKernelGGL(wh_star_drift_kernel, dim3(1), dim3(64), 0, st, cx, ccv, ca, h, star);
     return hipGetLastError();
 }
 

@@ -20,6 +20,7 @@
 //       source particles in a fixed order (deterministic, no atomics).
 #include "internal.h"
 #include "effects.h"
+#include "kepler.h"
 
 namespace rebxamd {
 
@@ -526,9 +527,14 @@ __device__ __forceinline__ void general_fixed(const Program& prog, const HeadCon
     }
 }
 
-template <bool EXACT, bool BACKREACT, bool VEC2, int COLS, Sig SIG = 0ull>
+// STEP (tail pass only): the pass carries a whole Wisdom-Holman step of the massless bodies.  The
+// forces start from zero instead of the acceleration columns, the body is kicked with them and
+// drifted on its Kepler orbit about body 0, and positions and velocities are written back; the
+// acceleration columns are neither read nor written.
+template <bool EXACT, bool BACKREACT, bool VEC2, int COLS, Sig SIG = 0ull, bool STEP = false>
 __global__ __launch_bounds__(BLOCK, (!EXACT && !BACKREACT && COLS != COL_ALL) ? 4 : 3) void stream_kernel(View v, Program prog, long long lo, long long base,
-                                                       const HeadConsts* __restrict__ tab, double* partials, unsigned* status) {
+                                                       const HeadConsts* __restrict__ tab, double* partials, unsigned* status, StepArgs step) {
+    static_assert(!STEP || (!BACKREACT && (COLS & COL_VEL)), "a stepping pass streams massless bodies and needs their velocities");
     const int tid = threadIdx.x;
     const long long i0 = base + 2 * ((long long)blockIdx.x * BLOCK + tid);
     const bool in0 = i0 < v.n, in1 = i0 + 1 < v.n;
@@ -550,8 +556,10 @@ __global__ __launch_bounds__(BLOCK, (!EXACT && !BACKREACT && COLS != COL_ALL) ? 
         if ((COLS & COL_TAU) && v.ta) ldpair(v.ta, i0, p[0].ta, p[1].ta);
         if ((COLS & COL_TAU) && v.te) ldpair(v.te, i0, p[0].te, p[1].te);
         if ((COLS & COL_TAU) && v.ti) ldpair(v.ti, i0, p[0].ti, p[1].ti);
-        const d2v ax = *reinterpret_cast<const d2v*>(v.ax + i0), ay = *reinterpret_cast<const d2v*>(v.ay + i0), az = *reinterpret_cast<const d2v*>(v.az + i0);
-        acc[0].x = ax.x; acc[1].x = ax.y; acc[0].y = ay.x; acc[1].y = ay.y; acc[0].z = az.x; acc[1].z = az.y;
+        if (!STEP) {
+            const d2v ax = *reinterpret_cast<const d2v*>(v.ax + i0), ay = *reinterpret_cast<const d2v*>(v.ay + i0), az = *reinterpret_cast<const d2v*>(v.az + i0);
+            acc[0].x = ax.x; acc[1].x = ax.y; acc[0].y = ay.x; acc[1].y = ay.y; acc[0].z = az.x; acc[1].z = az.y;
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < 2; k++) {
@@ -566,7 +574,7 @@ __global__ __launch_bounds__(BLOCK, (!EXACT && !BACKREACT && COLS != COL_ALL) ? 
             if ((COLS & COL_TAU) && v.ta) p[k].ta = ldone(v.ta, i);
             if ((COLS & COL_TAU) && v.te) p[k].te = ldone(v.te, i);
             if ((COLS & COL_TAU) && v.ti) p[k].ti = ldone(v.ti, i);
-            acc[k].x = v.ax[i]; acc[k].y = v.ay[i]; acc[k].z = v.az[i];
+            if (!STEP) { acc[k].x = v.ax[i]; acc[k].y = v.ay[i]; acc[k].z = v.az[i]; }
         }
     }
 
@@ -596,6 +604,34 @@ __global__ __launch_bounds__(BLOCK, (!EXACT && !BACKREACT && COLS != COL_ALL) ? 
         }
     }
 
+    if (STEP) {
+        double* const px = const_cast<double*>(v.x); double* const py = const_cast<double*>(v.y); double* const pz = const_cast<double*>(v.z);
+        double* const pvx = const_cast<double*>(v.vx); double* const pvy = const_cast<double*>(v.vy); double* const pvz = const_cast<double*>(v.vz);
+        double s[2][6];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (!(k ? act1 : act0)) continue;
+            s[k][0] = p[k].x; s[k][1] = p[k].y; s[k][2] = p[k].z; s[k][3] = p[k].vx; s[k][4] = p[k].vy; s[k][5] = p[k].vz;
+            wh_kick_drift<EXACT, true>(s[k], acc[k].x, acc[k].y, acc[k].z, step.mu, step.h, step.dtk, step.star);
+        }
+        if (full) {
+            d2v t;
+            t.x = s[0][0]; t.y = s[1][0]; *reinterpret_cast<d2v*>(px + i0) = t;
+            t.x = s[0][1]; t.y = s[1][1]; *reinterpret_cast<d2v*>(py + i0) = t;
+            t.x = s[0][2]; t.y = s[1][2]; *reinterpret_cast<d2v*>(pz + i0) = t;
+            t.x = s[0][3]; t.y = s[1][3]; *reinterpret_cast<d2v*>(pvx + i0) = t;
+            t.x = s[0][4]; t.y = s[1][4]; *reinterpret_cast<d2v*>(pvy + i0) = t;
+            t.x = s[0][5]; t.y = s[1][5]; *reinterpret_cast<d2v*>(pvz + i0) = t;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                if (!(k ? act1 : act0)) continue;
+                const long long i = i0 + k;
+                px[i] = s[k][0]; py[i] = s[k][1]; pz[i] = s[k][2]; pvx[i] = s[k][3]; pvy[i] = s[k][4]; pvz[i] = s[k][5];
+            }
+        }
+        return;
+    }
     if (full) {
         d2v ax, ay, az;
         ax.x = acc[0].x; ax.y = acc[1].x; ay.x = acc[0].y; ay.y = acc[1].y; az.x = acc[0].z; az.y = acc[1].z;
@@ -717,15 +753,30 @@ hipError_t launch_head(const View& v, const Program& prog, HeadConsts* hc, unsig
 
 template <bool EXACT, bool BACKREACT>
 static void launch_stream_cols(dim3 g, dim3 b, hipStream_t st, bool vec2, bool fixed, int cols, const View& v, const Program& prog, long long lo,
-                               long long base, const HeadConsts* hc, double* partials, unsigned* status) {
-#define LAUNCH(V, C) hipLaunchKernelGGL((stream_kernel<EXACT, BACKREACT, V, C>), g, b, 0, st, v, prog, lo, base, hc, partials, status)
+                               long long base, const HeadConsts* hc, double* partials, unsigned* status, const StepArgs* step) {
+    const StepArgs sa = step ? *step : StepArgs{0., 0., 0., nullptr};
+    Sig sig = 0ull;
+    if (fixed && vec2 && prog.nops <= 8) for (int o = 0; o < prog.nops; o++) sig |= (Sig)(prog.ops[o].kind & 15) << (4 * o);
+    if (step) {
+        // a whole Wisdom-Holman step in the pass (massless tail only)
+        if constexpr (!BACKREACT) {
+#define FIXED_STEP(...) \
+    { constexpr Sig S_ = sig_of(__VA_ARGS__); \
+      if (sig == S_) { hipLaunchKernelGGL((stream_kernel<EXACT, false, true, sig_cols(S_, true) | COL_VEL, S_, true>), g, b, 0, st, v, prog, lo, base, hc, partials, status, sa); return; } }
+            FIXED_STEP(REBXAMD_OP_RADIATION, REBXAMD_OP_J2, REBXAMD_OP_J4, REBXAMD_OP_GR)
+            FIXED_STEP(REBXAMD_OP_RADIATION, REBXAMD_OP_J2, REBXAMD_OP_J4, REBXAMD_OP_GR_POTENTIAL, REBXAMD_OP_TIDES, REBXAMD_OP_MOF)
+#undef FIXED_STEP
+            if (vec2) hipLaunchKernelGGL((stream_kernel<EXACT, false, true, COL_ALL, 0ull, true>), g, b, 0, st, v, prog, lo, base, hc, partials, status, sa);
+            else hipLaunchKernelGGL((stream_kernel<EXACT, false, false, COL_ALL, 0ull, true>), g, b, 0, st, v, prog, lo, base, hc, partials, status, sa);
+        }
+        return;
+    }
+#define LAUNCH(V, C) hipLaunchKernelGGL((stream_kernel<EXACT, BACKREACT, V, C>), g, b, 0, st, v, prog, lo, base, hc, partials, status, sa)
     if (!vec2) { LAUNCH(false, COL_ALL); return; }
     // stacks with an instance of their own
-    Sig sig = 0ull;
-    if (fixed && prog.nops <= 8) for (int o = 0; o < prog.nops; o++) sig |= (Sig)(prog.ops[o].kind & 15) << (4 * o);
 #define FIXED(...) \
     { constexpr Sig S_ = sig_of(__VA_ARGS__); \
-      if (sig == S_) { hipLaunchKernelGGL((stream_kernel<EXACT, BACKREACT, true, sig_cols(S_, !BACKREACT), S_>), g, b, 0, st, v, prog, lo, base, hc, partials, status); return; } }
+      if (sig == S_) { hipLaunchKernelGGL((stream_kernel<EXACT, BACKREACT, true, sig_cols(S_, !BACKREACT), S_>), g, b, 0, st, v, prog, lo, base, hc, partials, status, sa); return; } }
     if constexpr (!BACKREACT) {
         FIXED(REBXAMD_OP_RADIATION, REBXAMD_OP_J2, REBXAMD_OP_J4, REBXAMD_OP_GR)
         FIXED(REBXAMD_OP_RADIATION, REBXAMD_OP_J2, REBXAMD_OP_J4, REBXAMD_OP_GR_POTENTIAL, REBXAMD_OP_TIDES, REBXAMD_OP_MOF)
@@ -750,7 +801,8 @@ static void launch_stream_cols(dim3 g, dim3 b, hipStream_t st, bool vec2, bool f
 }
 
 hipError_t launch_stream(const View& v, const Program& prog, long long lo, const HeadConsts* hc, double* partials,
-                         int* nblocks_out, bool backreact, bool exact, bool vec2, bool fixed, unsigned* status, hipStream_t st) {
+                         int* nblocks_out, bool backreact, bool exact, bool vec2, bool fixed, unsigned* status, hipStream_t st, const StepArgs* step) {
+    if (step && backreact) return hipErrorInvalidValue;
     const long long base = lo & ~1ll;
     const int nb = stream_block_count(lo, v.n, vec2);
     if (nblocks_out) *nblocks_out = nb;
@@ -758,11 +810,11 @@ hipError_t launch_stream(const View& v, const Program& prog, long long lo, const
     const dim3 g(nb), b(BLOCK);
     const int cols = (prog.need_vel ? COL_VEL : 0) | (prog.need_beta ? COL_BETA : 0) | (prog.need_tides ? COL_TIDES : 0) | (prog.need_tau ? COL_TAU : 0);
     if (exact) {
-        if (backreact) launch_stream_cols<true, true>(g, b, st, vec2, fixed, cols, v, prog, lo, base, hc, partials, status);
-        else launch_stream_cols<true, false>(g, b, st, vec2, fixed, cols, v, prog, lo, base, hc, partials, status);
+        if (backreact) launch_stream_cols<true, true>(g, b, st, vec2, fixed, cols, v, prog, lo, base, hc, partials, status, step);
+        else launch_stream_cols<true, false>(g, b, st, vec2, fixed, cols, v, prog, lo, base, hc, partials, status, step);
     } else {
-        if (backreact) launch_stream_cols<false, true>(g, b, st, vec2, fixed, cols, v, prog, lo, base, hc, partials, status);
-        else launch_stream_cols<false, false>(g, b, st, vec2, fixed, cols, v, prog, lo, base, hc, partials, status);
+        if (backreact) launch_stream_cols<false, true>(g, b, st, vec2, fixed, cols, v, prog, lo, base, hc, partials, status, step);
+        else launch_stream_cols<false, false>(g, b, st, vec2, fixed, cols, v, prog, lo, base, hc, partials, status, step);
     }
     return hipGetLastError();
 }

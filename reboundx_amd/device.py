@@ -149,6 +149,10 @@ class Context:
         """Whether stacks with a kernel instance of their own use it (default) or walk the op list."""
         self._check(lib.rebxamd_fixed_stacks(self._h, 1 if on else 0))
 
+    def carried_steps(self, on=True):
+        """Whether wh_steps lets the force pass carry kick and drift (default) or runs them as a pass of their own."""
+        self._check(lib.rebxamd_carried_steps(self._h, 1 if on else 0))
+
     def timing_read(self):
         ms, cnt = ctypes.c_double(0), ctypes.c_int(0)
         self._check(lib.rebxamd_timing_read(self._h, ctypes.byref(ms), ctypes.byref(cnt)))

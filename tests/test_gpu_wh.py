@@ -56,6 +56,39 @@ def test_steps_match_the_checker(ctx, forces, mode):
     assert np.abs(got - want).max() <= 1e-12 * scale
 
 
+C2_STACK = [("radiation_forces", {"c": C}), ("gravitational_harmonics", {}), ("gr", {"c": C})]
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("forces", [C5_STACK, C2_STACK, [("gr", {"c": C})], [("modify_orbits_forces", {"coordinates": 1}), ("gr_potential", {"c": C})]],
+                         ids=["five-effects", "rad+harmonics+gr", "gr", "barycentric-drag+gr_potential"])
+@pytest.mark.parametrize("n", [2, 3, 1500, 4099])
+def test_steps_carried_by_the_force_pass_equal_separate_passes(ctx, n, forces, mode):
+    """rebxamd_wh_steps lets the pass over the massless bodies carry kick and drift; run with that
+    switched off, force pass and kick+drift pass are separate kernels.  Same expressions: in
+    reference-order arithmetic the states must agree bit for bit, and the acceleration columns
+    are zero afterwards either way."""
+    dt, steps = 0.05, 7
+    cols, pp, _ = synthetic.disk(n, 0)
+    cols["vx"][0], cols["vy"][0] = 1e-3, -2e-3
+    ops = build_ops(forces, pp)
+    out = []
+    for carried in (True, False):
+        dp = device_particles(cols, pp)
+        try:
+            ctx.carried_steps(carried)
+            ctx.wh_steps(dp.view(), ops, dt, steps, mode)
+        finally:
+            ctx.carried_steps(True)
+        out.append(state_of(dp))
+        assert float(np.abs(np.array(dp.acc_host())).max()) == 0.0
+    assert np.isfinite(out[0]).all()
+    if mode == 1:
+        assert np.array_equal(out[0], out[1])
+    else:
+        assert np.abs(out[0] - out[1]).max() <= 1e-13 * np.abs(out[1]).max()
+
+
 def eccentric_swarm(n, seed=11):
     """Star + massless bodies with e up to 0.95, all inclinations, a in [0.5, 3]."""
     rng = np.random.default_rng(seed)
