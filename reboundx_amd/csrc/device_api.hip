@@ -299,13 +299,8 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
 
     if (step && !(sparse && K == 1)) return STEP_NOT_CARRIED;
     if (sparse) {
-        HIP_TRY(launch_head(v, prog, ctx->hc, ctx->status, exact, st));
-        if (step) {
-            double* const x[3] = {const_cast<double*>(u->x), const_cast<double*>(u->y), const_cast<double*>(u->z)};
-            double* const vel[3] = {const_cast<double*>(u->vx), const_cast<double*>(u->vy), const_cast<double*>(u->vz)};
-            double* const a[3] = {u->ax, u->ay, u->az};
-            HIP_TRY(launch_wh_star(x, vel, a, step->h, ctx->star, st));
-        }
+        // in a stepping run the head pass (one body) also records and drifts that body
+        HIP_TRY(launch_head(v, prog, ctx->hc, ctx->status, exact, st, step ? ctx->star : nullptr, step ? step->h : 0.));
         if (v.n > K) {
             TimedLaunch tl(ctx, st);
             HIP_TRY(launch_stream(v, prog, K, ctx->hc, nullptr, nullptr, false, exact, vec2, ctx->fixed_stacks, ctx->status, st, step));
@@ -555,12 +550,9 @@ extern "C" int rebxamd_wh_drift(rebxamd_ctx* ctx, const rebxamd_view* view, doub
     if (!(view->n_head <= 1 && view->tail_massless)) return fail(ctx, REBXAMD_ERR_UNSUPPORTED, "rebxamd_wh_drift handles one massive body at index 0 followed by massless ones (n_head = 1, tail_massless = 1)");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
-    double m0 = 0.;
-    HIP_TRY(hipMemcpyAsync(&m0, view->m, sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
     double* const x[3] = {const_cast<double*>(view->x), const_cast<double*>(view->y), const_cast<double*>(view->z)};
     double* const v[3] = {const_cast<double*>(view->vx), const_cast<double*>(view->vy), const_cast<double*>(view->vz)};
-    HIP_TRY(launch_wh_drift(x, v, nullptr, view->G * m0, dt, 0., view->n, ctx->star, mode == REBXAMD_MODE_EXACT, st));
+    HIP_TRY(launch_wh_drift(x, v, nullptr, view->m, view->G, dt, 0., view->n, ctx->star, mode == REBXAMD_MODE_EXACT, st));
     return REBXAMD_OK;
 }
 
@@ -575,10 +567,6 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     const bool exact = mode == REBXAMD_MODE_EXACT;
-    double m0 = 0.;
-    HIP_TRY(hipMemcpyAsync(&m0, view->m, sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    const double mu = view->G * m0;
     double* const x[3] = {const_cast<double*>(view->x), const_cast<double*>(view->y), const_cast<double*>(view->z)};
     double* const v[3] = {const_cast<double*>(view->vx), const_cast<double*>(view->vy), const_cast<double*>(view->vz)};
     double* const a[3] = {view->ax, view->ay, view->az};
@@ -586,7 +574,7 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
     // flow of the two-body problem composes exactly); only the ends of the run are half steps.
     // The kick rides in the drift kernel that follows it, which also clears the accelerations
     // for the next force pass.
-    HIP_TRY(launch_wh_drift(x, v, nullptr, mu, 0.5 * dt, 0., view->n, ctx->star, exact, st));
+    HIP_TRY(launch_wh_drift(x, v, nullptr, view->m, view->G, 0.5 * dt, 0., view->n, ctx->star, exact, st));
     rc = rebxamd_reset_accelerations(ctx, view, stream);
     if (rc != REBXAMD_OK) return rc;
     // When the whole stack is one streaming run, the pass over the massless bodies carries the
@@ -601,7 +589,7 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
     for (int64_t k = 0; k < nsteps; k++) {
         const double h = k + 1 < nsteps ? dt : 0.5 * dt;
         if (carried) {
-            const StepArgs sa = {mu, h, dt, ctx->star};
+            const StepArgs sa = {h, dt, ctx->star};
             rc = run_streaming(ctx, view, ops, 0, nops, mode, st, -1, nullptr, false, &sa);
             if (rc == REBXAMD_OK) continue;
             if (rc != STEP_NOT_CARRIED) return rc;
@@ -611,7 +599,7 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
             rc = rebxamd_apply(ctx, view, ops, nops, mode, stream);
             if (rc != REBXAMD_OK) return rc;
         }
-        HIP_TRY(launch_wh_drift(x, v, a, mu, h, dt, view->n, ctx->star, exact, st));
+        HIP_TRY(launch_wh_drift(x, v, a, view->m, view->G, h, dt, view->n, ctx->star, exact, st));
     }
     return REBXAMD_OK;
 }

@@ -61,14 +61,16 @@ struct HeadConsts {
 };
 
 // Wisdom-Holman kick and drift carried by the streaming pass behind the head (tail bodies
-// massless): mass parameter of body 0, drift length, kick length, and the record of body 0
-// (its state before the drift, its position after it, its acceleration).
-struct StepArgs { double mu, h, dtk; const double* star; };
+// massless): drift length, kick length, and the record of body 0 (its state before the drift, its
+// position after it, its acceleration, its mass parameter G*m_0).
+struct StepArgs { double h, dtk; const double* star; };
 
 enum { WARN_GR_ITER = 1u, WARN_GRFULL_SWEEPS = 2u, WARN_IM_ITER = 4u };
 
 // launchers implemented in stream_kernels.hip
-hipError_t launch_head(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, bool exact, hipStream_t st);
+// star != nullptr: a one-body head is recorded in `star`, its acceleration cleared, and drifted over h (Wisdom-Holman runs)
+hipError_t launch_head(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, bool exact, hipStream_t st,
+                       double* star = nullptr, double h = 0.);
 hipError_t launch_stream(const View& v, const Program& prog, long long lo, const HeadConsts* hc, double* partials,
                          int* nblocks_out, bool backreact, bool exact, bool vec2, bool fixed, unsigned* status, hipStream_t st,
                          const StepArgs* step = nullptr);
@@ -96,8 +98,7 @@ hipError_t launch_lincomb(double* const out[3], const double* const v[3], const 
 hipError_t launch_rk2_final(double* const v[3], const double* const a1[3], const double* const a2[3], double b1, double b2, long long n, bool exact, hipStream_t st);
 hipError_t launch_rk4_mid(double* const sv[3], const double* const v[3], double* const k2a[3], double* const k3a[3], double dt, long long n, bool exact, hipStream_t st);
 hipError_t launch_rk4_final(double* const v[3], const double* const a1[3], const double* const a4[3], const double* const k23[3], double dt6, long long n, bool exact, hipStream_t st);
-hipError_t launch_wh_star(double* const x[3], double* const v[3], double* const a[3], double h, double* star, hipStream_t st);
-hipError_t launch_wh_drift(double* const x[3], double* const v[3], double* const a[3], double mu, double h, double dtk, long long n,
+hipError_t launch_wh_drift(double* const x[3], double* const v[3], double* const a[3], const double* m, double G, double h, double dtk, long long n,
                            double* star, bool exact, hipStream_t st);
 long long im_partial_count(long long n);
 hipError_t launch_im_update(double* const fin[3], const double* const orig[3], double* const avgv[3], double* const avga[3], double dt,

@@ -141,11 +141,12 @@ __device__ __forceinline__ void kepler_dev(double (&q)[6], double M, double dt) 
 }
 
 // Kick and drift of one massless body of a Wisdom-Holman step about body 0.  `star` holds body
-// 0's state before its drift [0..5], its position after it [6..8] and its acceleration [9..11].
+// 0's state before its drift [0..5], its position after it [6..8], its acceleration [9..11] and
+// its mass parameter G*m_0 [12].
 // KICK: v += dtk*(a - a_0) first (Jacobi kick of a massless body), then the Kepler drift over h
 // relative to body 0.
 template <bool EXACT, bool KICK>
-__device__ __forceinline__ void wh_kick_drift(double (&s)[6], double ax, double ay, double az, double mu, double h, double dtk,
+__device__ __forceinline__ void wh_kick_drift(double (&s)[6], double ax, double ay, double az, double h, double dtk,
                                               const double* __restrict__ star) {
     double q[6];
     {
@@ -161,7 +162,7 @@ __device__ __forceinline__ void wh_kick_drift(double (&s)[6], double ax, double 
         q[0] = s[0] - star[0]; q[1] = s[1] - star[1]; q[2] = s[2] - star[2];
         q[3] = vx - star[3]; q[4] = vy - star[4]; q[5] = vz - star[5];
     }
-    kepler_dev<EXACT>(q, mu, h);
+    kepler_dev<EXACT>(q, star[12], h);
     {
 #pragma clang fp contract(off)
         s[0] = q[0] + star[6]; s[1] = q[1] + star[7]; s[2] = q[2] + star[8];

@@ -136,10 +136,12 @@ __global__ __launch_bounds__(1024) void im_sum_kernel(const double* partials, lo
 // run); the propagation itself is in kepler.h.
 
 // star[0..5] <- state of body 0 before the drift; body 0 drifts linearly; star[6..8] <- its new
-// position.  With accelerations given: star[9..11] <- a_0, and a_0 is cleared for the next force pass.
-__global__ void wh_star_drift_kernel(Cols3 x, CCols3 v, Cols3 a, double h, double* star) {
+// position; star[12] <- G*m_0.  With accelerations given: star[9..11] <- a_0, and a_0 is cleared
+// for the next force pass.
+__global__ void wh_star_drift_kernel(Cols3 x, CCols3 v, Cols3 a, const double* m, double G, double h, double* star) {
 #pragma clang fp contract(off)
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    star[12] = G * m[0];
     const double x0 = x.x[0], y0 = x.y[0], z0 = x.z[0], vx = v.x[0], vy = v.y[0], vz = v.z[0];
     star[0] = x0; star[1] = y0; star[2] = z0; star[3] = vx; star[4] = vy; star[5] = vz;
     const double nx = x0 + h * vx, ny = y0 + h * vy, nz = z0 + h * vz;
@@ -154,7 +156,7 @@ __global__ void wh_star_drift_kernel(Cols3 x, CCols3 v, Cols3 a, double h, doubl
 // KICK: v_i += dtk*(a_i - a_0) first (Jacobi kick with massless bodies; a_i is cleared afterwards so
 // that the next force pass accumulates onto zero), then the Kepler drift over h.
 template <bool EXACT, bool KICK>
-__global__ __launch_bounds__(TB) void wh_drift_kernel(Cols3 x, Cols3 v, Cols3 a, double mu, double h, double dtk, long long n, const double* __restrict__ star) {
+__global__ __launch_bounds__(TB) void wh_drift_kernel(Cols3 x, Cols3 v, Cols3 a, double h, double dtk, long long n, const double* __restrict__ star) {
     const long long i = (long long)blockIdx.x * TB + threadIdx.x + 1;
     if (i >= n) return;
     double s[6] = {x.x[i], x.y[i], x.z[i], v.x[i], v.y[i], v.z[i]};
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(TB) void wh_drift_kernel(Cols3 x, Cols3 v, Cols3 a,
         ax = a.x[i]; ay = a.y[i]; az = a.z[i];
         a.x[i] = 0.; a.y[i] = 0.; a.z[i] = 0.;
     }
-    wh_kick_drift<EXACT, KICK>(s, ax, ay, az, mu, h, dtk, star);
+    wh_kick_drift<EXACT, KICK>(s, ax, ay, az, h, dtk, star);
     x.x[i] = s[0]; x.y[i] = s[1]; x.z[i] = s[2];
     v.x[i] = s[3]; v.y[i] = s[4]; v.z[i] = s[5];
 }
@@ -219,30 +221,21 @@ hipError_t launch_im_update(double* const fin[3], const double* const orig[3], d
     return hipGetLastError();
 }
 
-// Body 0 alone: records its state (and acceleration, which is cleared) in `star` and drifts it.
-hipError_t launch_wh_star(double* const x[3], double* const v[3], double* const a[3], double h, double* star, hipStream_t st) {
-    const Cols3 cx = {x[0], x[1], x[2]};
-    const Cols3 ca = a ? Cols3{a[0], a[1], a[2]} : Cols3{nullptr, nullptr, nullptr};
-    const CCols3 ccv = {v[0], v[1], v[2]};
-    hipLaunchKernelGGL(wh_star_drift_kernel, dim3(1), dim3(64), 0, st, cx, ccv, ca, h, star);
-    return hipGetLastError();
-}
-
 // a == nullptr: drift only.  Otherwise kick by dtk with the accelerations in `a` (which are cleared), then drift.
-hipError_t launch_wh_drift(double* const x[3], double* const v[3], double* const a[3], double mu, double h, double dtk, long long n,
+hipError_t launch_wh_drift(double* const x[3], double* const v[3], double* const a[3], const double* m, double G, double h, double dtk, long long n,
                            double* star, bool exact, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     const Cols3 cx = {x[0], x[1], x[2]}, cv = {v[0], v[1], v[2]};
     const Cols3 ca = a ? Cols3{a[0], a[1], a[2]} : Cols3{nullptr, nullptr, nullptr};
     const CCols3 ccv = {v[0], v[1], v[2]};
-    hipLaunchKernelGGL(wh_star_drift_kernel, dim3(1), dim3(64), 0, st, cx, ccv, ca, h, star);
+    hipLaunchKernelGGL(wh_star_drift_kernel, dim3(1), dim3(64), 0, st, cx, ccv, ca, m, G, h, star);
     if (n > 1) {
         if (a) {
-            if (exact) hipLaunchKernelGGL((wh_drift_kernel<true, true>), grid_for(n - 1), dim3(TB), 0, st, cx, cv, ca, mu, h, dtk, n, star);
-            else hipLaunchKernelGGL((wh_drift_kernel<false, true>), grid_for(n - 1), dim3(TB), 0, st, cx, cv, ca, mu, h, dtk, n, star);
+            if (exact) hipLaunchKernelGGL((wh_drift_kernel<true, true>), grid_for(n - 1), dim3(TB), 0, st, cx, cv, ca, h, dtk, n, star);
+            else hipLaunchKernelGGL((wh_drift_kernel<false, true>), grid_for(n - 1), dim3(TB), 0, st, cx, cv, ca, h, dtk, n, star);
         } else {
-            if (exact) hipLaunchKernelGGL((wh_drift_kernel<true, false>), grid_for(n - 1), dim3(TB), 0, st, cx, cv, ca, mu, h, dtk, n, star);
-            else hipLaunchKernelGGL((wh_drift_kernel<false, false>), grid_for(n - 1), dim3(TB), 0, st, cx, cv, ca, mu, h, dtk, n, star);
+            if (exact) hipLaunchKernelGGL((wh_drift_kernel<true, false>), grid_for(n - 1), dim3(TB), 0, st, cx, cv, ca, h, dtk, n, star);
+            else hipLaunchKernelGGL((wh_drift_kernel<false, false>), grid_for(n - 1), dim3(TB), 0, st, cx, cv, ca, h, dtk, n, star);
         }
     }
     return hipGetLastError();

@@ -148,8 +148,12 @@ struct HeadShared {
     Com com[REBXAMD_MAX_HEAD + 1];
 };
 
+// star != nullptr (Wisdom-Holman runs, one head body): instead of storing body 0's acceleration the
+// pass records body 0 for the stepping pass that follows -- star[0..5] its state, star[9..11] its
+// acceleration (the column is cleared), star[12] its mass parameter G*m_0 -- drifts it linearly
+// over h and records the new position in star[6..8].
 template <bool EXACT>
-__global__ __launch_bounds__(64) void head_kernel(View v, Program prog, HeadConsts* hc, unsigned* status) {
+__global__ __launch_bounds__(64) void head_kernel(View v, Program prog, HeadConsts* hc, unsigned* status, double* star, double h) {
     __shared__ HeadShared sh;
     const int t = threadIdx.x;
     const int K = (int)(v.n_head < v.n ? v.n_head : v.n);
@@ -343,6 +347,18 @@ __global__ __launch_bounds__(64) void head_kernel(View v, Program prog, HeadCons
             }
             __syncthreads();
         }
+    }
+    if (star != nullptr) {
+        if (t == 0 && valid) {
+#pragma clang fp contract(off)
+            star[0] = p.x; star[1] = p.y; star[2] = p.z; star[3] = p.vx; star[4] = p.vy; star[5] = p.vz;
+            star[9] = acc.x; star[10] = acc.y; star[11] = acc.z; star[12] = G * p.m;
+            v.ax[0] = 0.; v.ay[0] = 0.; v.az[0] = 0.;
+            const double nx = p.x + h * p.vx, ny = p.y + h * p.vy, nz = p.z + h * p.vz;
+            const_cast<double*>(v.x)[0] = nx; const_cast<double*>(v.y)[0] = ny; const_cast<double*>(v.z)[0] = nz;
+            star[6] = nx; star[7] = ny; star[8] = nz;
+        }
+        return;
     }
     if (valid) { v.ax[t] = acc.x; v.ay[t] = acc.y; v.az[t] = acc.z; }
 }
@@ -612,7 +628,7 @@ __global__ __launch_bounds__(BLOCK, (!EXACT && !BACKREACT && COLS != COL_ALL) ? 
         for (int k = 0; k < 2; k++) {
             if (!(k ? act1 : act0)) continue;
             s[k][0] = p[k].x; s[k][1] = p[k].y; s[k][2] = p[k].z; s[k][3] = p[k].vx; s[k][4] = p[k].vy; s[k][5] = p[k].vz;
-            wh_kick_drift<EXACT, true>(s[k], acc[k].x, acc[k].y, acc[k].z, step.mu, step.h, step.dtk, step.star);
+            wh_kick_drift<EXACT, true>(s[k], acc[k].x, acc[k].y, acc[k].z, step.h, step.dtk, step.star);
         }
         if (full) {
             d2v t;
@@ -745,16 +761,16 @@ int stream_block_count(long long lo, long long n, bool) {
     return (int)((pairs + BLOCK - 1) / BLOCK);
 }
 
-hipError_t launch_head(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, bool exact, hipStream_t st) {
-    if (exact) hipLaunchKernelGGL(head_kernel<true>, dim3(1), dim3(64), 0, st, v, prog, hc, status);
-    else hipLaunchKernelGGL(head_kernel<false>, dim3(1), dim3(64), 0, st, v, prog, hc, status);
+hipError_t launch_head(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, bool exact, hipStream_t st, double* star, double h) {
+    if (exact) hipLaunchKernelGGL(head_kernel<true>, dim3(1), dim3(64), 0, st, v, prog, hc, status, star, h);
+    else hipLaunchKernelGGL(head_kernel<false>, dim3(1), dim3(64), 0, st, v, prog, hc, status, star, h);
     return hipGetLastError();
 }
 
 template <bool EXACT, bool BACKREACT>
 static void launch_stream_cols(dim3 g, dim3 b, hipStream_t st, bool vec2, bool fixed, int cols, const View& v, const Program& prog, long long lo,
                                long long base, const HeadConsts* hc, double* partials, unsigned* status, const StepArgs* step) {
-    const StepArgs sa = step ? *step : StepArgs{0., 0., 0., nullptr};
+    const StepArgs sa = step ? *step : StepArgs{0., 0., nullptr};
     Sig sig = 0ull;
     if (fixed && vec2 && prog.nops <= 8) for (int o = 0; o < prog.nops; o++) sig |= (Sig)(prog.ops[o].kind & 15) << (4 * o);
     if (step) {
