@@ -373,6 +373,30 @@ int rebxamd_shard_mof_forces(rebxamd_ctx* ctx, const rebxamd_view* view, int coo
 int rebxamd_shard_mof_apply(rebxamd_ctx* ctx, const rebxamd_view* view, int coordinates, int64_t lo, int64_t hi, const double* after3,
                             void* stream);
 
+/* gr (src/gr.c:73-171) when the particles are sharded over devices and the slices hold massive
+ * bodies (no counterpart in the reference, which is one sequential loop).  Same global order
+ * and ranges as above; body ids are positions in the global order.  Per range:
+ *   1. rebxamd_shard_massive     records <- {x, y, z, G m, id0 + (i - lo)} of the massive bodies of
+ *      the range in index order (5 doubles each; capacity 5*(hi-lo)), count <- their number (one
+ *      double) -> all-gather counts and records; concatenate head, slice of rank 0, slice of rank 1, ...;
+ *   2. rebxamd_shard_gr_newton   Newtonian pull of the gathered records on the bodies of the range
+ *      (a record whose id equals the body's own id is skipped; kept inside the context);
+ *      sums10 <- (m, m x, m v, m a_newton) over the range -> all-gather the slice sums;
+ *   3. rebxamd_shard_gr_forces   before10 = sums of every body that precedes the range (NULL for the
+ *      range that starts at body 0); push3 <- summed back-reaction of the range -> all-gather;
+ *   4. rebxamd_shard_gr_apply    after3 = pushes of every body that follows the range (NULL = none);
+ *      adds to ax/ay/az of the range.
+ * Steps 2-4 of one range must not be separated by other calls on the same context that use the
+ * same range start.  The cost of step 2 is (bodies of the range) x (massive bodies of the system).
+ * reboundx_amd/dist.py (gr_sharded) is the driver. */
+int rebxamd_shard_massive(rebxamd_ctx* ctx, const rebxamd_view* view, int64_t lo, int64_t hi, int64_t id0, double* records, double* count,
+                          void* stream);
+int rebxamd_shard_gr_newton(rebxamd_ctx* ctx, const rebxamd_view* view, int64_t lo, int64_t hi, int64_t id0, const double* records,
+                            int64_t nrecords, double* sums10, int mode, void* stream);
+int rebxamd_shard_gr_forces(rebxamd_ctx* ctx, const rebxamd_view* view, double c, int max_iterations, int64_t lo, int64_t hi,
+                            const double* before10, double* push3, int mode, void* stream);
+int rebxamd_shard_gr_apply(rebxamd_ctx* ctx, const rebxamd_view* view, int64_t lo, int64_t hi, const double* after3, void* stream);
+
 /* src/core.c:860-866 on device columns. */
 int rebxamd_reset_accelerations(rebxamd_ctx* ctx, const rebxamd_view* view, void* stream);
 

@@ -52,6 +52,10 @@ _sig = {
     "rebxamd_shard_sums": (c_int, [c_void_p, POINTER(View), c_int64, c_int64, c_void_p, c_void_p]),
     "rebxamd_shard_mof_forces": (c_int, [c_void_p, POINTER(View), c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "rebxamd_shard_mof_apply": (c_int, [c_void_p, POINTER(View), c_int, c_int64, c_int64, c_void_p, c_void_p]),
+    "rebxamd_shard_massive": (c_int, [c_void_p, POINTER(View), c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "rebxamd_shard_gr_newton": (c_int, [c_void_p, POINTER(View), c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p]),
+    "rebxamd_shard_gr_forces": (c_int, [c_void_p, POINTER(View), c_double, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p]),
+    "rebxamd_shard_gr_apply": (c_int, [c_void_p, POINTER(View), c_int64, c_int64, c_void_p, c_void_p]),
     "rebxamd_reset_accelerations": (c_int, [c_void_p, POINTER(View), c_void_p]),
     "rebxamd_wh_drift": (c_int, [c_void_p, POINTER(View), c_double, c_int, c_void_p]),
     "rebxamd_wh_steps": (c_int, [c_void_p, POINTER(View), POINTER(Op), c_int, c_double, c_int64, c_int, c_void_p]),

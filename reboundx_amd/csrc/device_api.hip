@@ -313,7 +313,7 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
         // their own; the ops around them keep streaming (no op reads accelerations, so only the
         // order of additions into a_i is affected, and it is kept)
         if (target_lo >= 0)
-            return fail(ctx, REBXAMD_ERR_UNSUPPORTED, "gr and Jacobi/barycentric modify_orbits_forces are not available on particle shards that hold massive bodies outside the replicated head");
+            return fail(ctx, REBXAMD_ERR_UNSUPPORTED, "gr and Jacobi/barycentric modify_orbits_forces on particle shards that hold massive bodies run through the rebxamd_shard_* entry points");
         const int rcw = ensure(ctx, &ctx->scan, &ctx->scan_cap, scan_workspace_doubles(v.n) * sizeof(double), st);
         if (rcw != REBXAMD_OK) return rcw;
         int a = lo;
@@ -677,6 +677,65 @@ extern "C" int rebxamd_shard_mof_apply(rebxamd_ctx* ctx, const rebxamd_view* vie
     rc = shard_workspace(ctx, view, lo, (hipStream_t)stream, &ws);
     if (rc != REBXAMD_OK) return rc;
     HIP_TRY(launch_range_mof_apply(sub_view(view, lo, hi), coordinates == REBX_COORDINATES_BARYCENTRIC, after3, ws, (hipStream_t)stream));
+    return REBXAMD_OK;
+}
+
+// ------------------------------------------------------------------ gr on particle shards that hold massive bodies
+
+extern "C" int rebxamd_shard_massive(rebxamd_ctx* ctx, const rebxamd_view* view, int64_t lo, int64_t hi, int64_t id0, double* records, double* count,
+                                     void* stream) {
+    int rc = shard_check(ctx, view, lo, hi, "rebxamd_shard_massive: bad argument");
+    if (rc != REBXAMD_OK) return rc;
+    if (!count || (hi > lo && !records) || id0 < 0) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_shard_massive: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    double* ws = nullptr;
+    rc = shard_workspace(ctx, view, lo, (hipStream_t)stream, &ws);
+    if (rc != REBXAMD_OK) return rc;
+    HIP_TRY(launch_range_massive(sub_view(view, lo, hi), view->G, (double)id0, ws, records, count, (hipStream_t)stream));
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_shard_gr_newton(rebxamd_ctx* ctx, const rebxamd_view* view, int64_t lo, int64_t hi, int64_t id0, const double* records,
+                                       int64_t nrecords, double* sums10, int mode, void* stream) {
+    int rc = shard_check(ctx, view, lo, hi, "rebxamd_shard_gr_newton: bad argument");
+    if (rc != REBXAMD_OK) return rc;
+    if (!sums10 || nrecords < 0 || (nrecords > 0 && !records) || id0 < 0 || (mode != REBXAMD_MODE_FAST && mode != REBXAMD_MODE_EXACT))
+        return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_shard_gr_newton: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    double* ws = nullptr;
+    rc = shard_workspace(ctx, view, lo, (hipStream_t)stream, &ws);
+    if (rc != REBXAMD_OK) return rc;
+    HIP_TRY(launch_range_gr_newton(sub_view(view, lo, hi), records, nrecords, (double)id0, mode == REBXAMD_MODE_EXACT, ws, sums10, (hipStream_t)stream));
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_shard_gr_forces(rebxamd_ctx* ctx, const rebxamd_view* view, double c, int max_iterations, int64_t lo, int64_t hi,
+                                       const double* before10, double* push3, int mode, void* stream) {
+    int rc = shard_check(ctx, view, lo, hi, "rebxamd_shard_gr_forces: bad argument");
+    if (rc != REBXAMD_OK) return rc;
+    if (!push3 || (lo > 0 && !before10) || (mode != REBXAMD_MODE_FAST && mode != REBXAMD_MODE_EXACT))
+        return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_shard_gr_forces: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    double* ws = nullptr;
+    rc = shard_workspace(ctx, view, lo, (hipStream_t)stream, &ws);
+    if (rc != REBXAMD_OK) return rc;
+    DevOp op;
+    memset(&op, 0, sizeof(op));
+    op.kind = REBXAMD_OP_GR; op.src = 0; op.iarg = max_iterations; op.slot = -1; op.a = c; op.c = c * c; op.d = 1. / (c * c);
+    HIP_TRY(launch_range_gr_forces(sub_view(view, lo, hi), op, view->G, lo == 0, before10, view->m, mode == REBXAMD_MODE_EXACT, ws, push3, ctx->status,
+                                   (hipStream_t)stream));
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_shard_gr_apply(rebxamd_ctx* ctx, const rebxamd_view* view, int64_t lo, int64_t hi, const double* after3, void* stream) {
+    int rc = shard_check(ctx, view, lo, hi, "rebxamd_shard_gr_apply: bad argument");
+    if (rc != REBXAMD_OK) return rc;
+    if (view->n > 0 && (!view->ax || !view->ay || !view->az)) return fail(ctx, REBXAMD_ERR_ARG, "acceleration columns missing");
+    HIP_TRY(hipSetDevice(ctx->device));
+    double* ws = nullptr;
+    rc = shard_workspace(ctx, view, lo, (hipStream_t)stream, &ws);
+    if (rc != REBXAMD_OK) return rc;
+    HIP_TRY(launch_range_gr_apply(sub_view(view, lo, hi), after3, ws, (hipStream_t)stream));
     return REBXAMD_OK;
 }
 

@@ -86,6 +86,11 @@ int stream_block_count(long long lo, long long n, bool vec2);
 // gr and Jacobi/barycentric modify_orbits_forces for arbitrary mass layouts (scan_kernels.hip)
 size_t scan_workspace_doubles(long long n);
 size_t scan_range_doubles(long long n);
+hipError_t launch_range_massive(const View& v, double G, double id0, double* ws, double* rec, double* count, hipStream_t st);
+hipError_t launch_range_gr_newton(const View& v, const double* rec, long long M, double id0, bool exact, double* ws, double* sums10, hipStream_t st);
+hipError_t launch_range_gr_forces(const View& v, const DevOp& op, double G, bool starts_at_origin, const double* before10, const double* m0,
+                                  bool exact, double* ws, double* push3, unsigned* status, hipStream_t st);
+hipError_t launch_range_gr_apply(const View& v, const double* after3, double* ws, hipStream_t st);
 hipError_t launch_range_sums(const View& v, double* ws, double* sums7, hipStream_t st);
 hipError_t launch_range_mof_forces(const View& v, const DevOp& op, double G, bool barycentric, bool starts_at_origin, const double* before7,
                                    double* ws, double* push3, hipStream_t st);

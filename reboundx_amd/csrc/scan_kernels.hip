@@ -173,7 +173,7 @@ template <int KIND, bool EXACT>
 __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, const double* nax, const double* nay, const double* naz,
                                                 const double* blocksums, const double* totals,
                                                 double* ajx, double* ajy, double* ajz, double* wx, double* wy, double* wz,
-                                                double* wsums, unsigned* status, const double* pre, long long first_acting) {
+                                                double* wsums, unsigned* status, const double* pre, long long first_acting, const double* m0) {
     constexpr int C = (KIND == SCAN_GR) ? 10 : 7;
     __shared__ double lds[SW][C];
     __shared__ double lds3[SW][3];
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, cons
                     j.x = p.x - S[1] * ei; j.y = p.y - S[2] * ei; j.z = p.z - S[3] * ei;
                     j.vx = p.vx - S[4] * ei; j.vy = p.vy - S[5] * ei; j.vz = p.vz - S[6] * ei;
                     j.ax = nax[i] - S[7] * ei; j.ay = nay[i] - S[8] * ei; j.az = naz[i] - S[9] * ei;
-                    const double mu = G * v.m[0];
+                    const double mu = G * m0[0];       // body 0 of the whole system (the view may be a range behind it)
                     const int it = EXACT ? gr_term_exact(j, mu, op.c, op.iarg, a)
                                          : gr_term_fast(j, fast_rsqrt(j.x * j.x + j.y * j.y + j.z * j.z), mu, op.d, op.iarg, a);
                     if (it == 10) atomicOr(status, WARN_GR_ITER);
@@ -307,6 +307,53 @@ __global__ __launch_bounds__(SB) void newton_from_compact(View v, const double* 
         const int cnt = (int)((M - j0) < SB ? (M - j0) : SB);
         for (int k = 0; k < cnt; k++) {
             if (ti[k] == i) continue;
+            const double dx = tx[k] - xi, dy = ty[k] - yi, dz = tz[k] - zi;
+            const double r2 = dx * dx + dy * dy + dz * dz;
+            if (EXACT) {
+#pragma clang fp contract(off)
+                const double w = tg[k] / (r2 * sqrt(r2));
+                ax += w * dx; ay += w * dy; az += w * dz;
+            } else {
+                const double ri = fast_rsqrt(r2);
+                const double w = tg[k] * (ri * ri * ri);
+                ax = fma(w, dx, ax); ay = fma(w, dy, ay); az = fma(w, dz, az);
+            }
+        }
+    }
+    if (live) { nax[i] = ax; nay[i] = ay; naz[i] = az; }
+}
+
+// The same for particle shards: the massive bodies of a range as records {x, y, z, G m, id} (ids are
+// global body numbers, exact in fp64), and the pull of a list of such records (gathered from every
+// shard, in ascending id order) on the bodies of a range.
+__global__ __launch_bounds__(SB) void massive_records(View v, const double* blocksums, double* rec, double G, double id0) {
+    __shared__ double lds[SW][1];
+    const long long i = (long long)blockIdx.x * SB + threadIdx.x;
+    const bool massive = i < v.n && v.m[i] != 0.;
+    double q[1] = {massive ? 1. : 0.}, tot[1];
+    block_scan<1, false>(q, tot, lds);
+    if (massive) {
+        double* r = rec + 5 * (long long)(blocksums[blockIdx.x] + q[0] - 1.);
+        r[0] = v.x[i]; r[1] = v.y[i]; r[2] = v.z[i]; r[3] = G * v.m[i]; r[4] = id0 + (double)i;
+    }
+}
+template <bool EXACT>
+__global__ __launch_bounds__(SB) void newton_from_records(View v, const double* rec, long long M, double id0, double* nax, double* nay, double* naz) {
+    __shared__ double tx[SB], ty[SB], tz[SB], tg[SB], ti[SB];
+    const long long i = (long long)blockIdx.x * SB + threadIdx.x;
+    const bool live = i < v.n;
+    const double own = id0 + (double)i;
+    double xi = 0., yi = 0., zi = 0.;
+    if (live) { xi = v.x[i]; yi = v.y[i]; zi = v.z[i]; }
+    double ax = 0., ay = 0., az = 0.;
+    for (long long j0 = 0; j0 < M; j0 += SB) {
+        const long long j = j0 + threadIdx.x;
+        __syncthreads();
+        if (j < M) { const double* r = rec + 5 * j; tx[threadIdx.x] = r[0]; ty[threadIdx.x] = r[1]; tz[threadIdx.x] = r[2]; tg[threadIdx.x] = r[3]; ti[threadIdx.x] = r[4]; }
+        __syncthreads();
+        const int cnt = (int)((M - j0) < SB ? (M - j0) : SB);
+        for (int k = 0; k < cnt; k++) {
+            if (ti[k] == own) continue;
             const double dx = tx[k] - xi, dy = ty[k] - yi, dz = tz[k] - zi;
             const double r2 = dx * dx + dy * dy + dz * dz;
             if (EXACT) {
@@ -447,13 +494,13 @@ hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, 
         else hipLaunchKernelGGL(newton_from_compact<false>, g, b, 0, st, v, cx, cy, cz, cgm, cidx, count, nax, nay, naz);
         hipLaunchKernelGGL(scan_block_totals<10>, gs, b, 0, st, v, nax, nay, naz, bs);
         hipLaunchKernelGGL((scan_of_totals<10, false>), dim3(1), dim3(1024), 0, st, bs, nbs, totals);
-        if (exact) hipLaunchKernelGGL((scan_main<SCAN_GR, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL);
-        else hipLaunchKernelGGL((scan_main<SCAN_GR, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL);
+        if (exact) hipLaunchKernelGGL((scan_main<SCAN_GR, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL, v.m);
+        else hipLaunchKernelGGL((scan_main<SCAN_GR, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL, v.m);
     } else {
         hipLaunchKernelGGL(scan_block_totals<7>, gs, b, 0, st, v, nax, nay, naz, bs);
         hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(1024), 0, st, bs, nbs, totals);
-        if (kind == SCAN_MOF_JACOBI) hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL);
-        else hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL);
+        if (kind == SCAN_MOF_JACOBI) hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL, v.m);
+        else hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL, v.m);
     }
     hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(1), dim3(1024), 0, st, wsum, nbs, wtot);
     if (kind == SCAN_MOF_BARY) hipLaunchKernelGGL(scan_apply<true>, gs, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, wsum, wtot, (const double*)nullptr);
@@ -469,7 +516,8 @@ namespace rebxamd {
 // sub-view of one contiguous range (column pointers already offset, n = its length); `ws` is the
 // workspace slice that belongs to the same range (6 columns of v.n doubles, then block sums).
 static inline long long blocks_of(long long n) { return (n + SCHUNK - 1) / SCHUNK; }
-size_t scan_range_doubles(long long n) { return (size_t)(6 * n + 10 * blocks_of(n) + 16); }
+// (gr: 9 columns, 13 workgroup sums per weighted-sum workgroup, one flag total per compaction workgroup)
+size_t scan_range_doubles(long long n) { return (size_t)(9 * n + 13 * blocks_of(n) + (n + SB - 1) / SB + 32); }
 
 // sums7 <- (m, m x, m y, m z, m vx, m vy, m vz) summed over the range
 hipError_t launch_range_sums(const View& v, double* ws, double* sums7, hipStream_t st) {
@@ -497,10 +545,10 @@ hipError_t launch_range_mof_forces(const View& v, const DevOp& op, double G, boo
     hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(1024), 0, st, bs, nb, scratch);
     if (barycentric)
         hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), g, b, 0, st, v, op, G, none, none, none, (const double*)bs, before7, ajx, ajy, ajz, wx, wy, wz, wsum,
-                           (unsigned*)nullptr, none, 0LL);
+                           (unsigned*)nullptr, none, 0LL, v.m);
     else
         hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), g, b, 0, st, v, op, G, none, none, none, (const double*)bs, (const double*)scratch, ajx, ajy, ajz, wx, wy, wz, wsum,
-                           (unsigned*)nullptr, before7, starts_at_origin ? 1LL : 0LL);
+                           (unsigned*)nullptr, before7, starts_at_origin ? 1LL : 0LL, v.m);
     hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(1), dim3(1024), 0, st, wsum, nb, push3);
     return hipGetLastError();
 }
@@ -515,6 +563,71 @@ hipError_t launch_range_mof_apply(const View& v, bool barycentric, const double*
     const dim3 g((unsigned)nb), b(SB);
     if (barycentric) hipLaunchKernelGGL(scan_apply<true>, g, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, (const double*)wsum, after3, (const double*)nullptr);
     else hipLaunchKernelGGL(scan_apply<false>, g, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, (const double*)wsum, (const double*)nullptr, after3);
+    return hipGetLastError();
+}
+
+// ---- pieces of gr for particle shards.  Range workspace: Newtonian acc (3 columns), own
+// post-Newtonian acc (3), weighted reactions (3), workgroup sums (10 + 3 per workgroup), flag totals.
+struct GrRange { double *nax, *nay, *naz, *ajx, *ajy, *ajz, *wx, *wy, *wz, *bs, *wsum, *fl, *scratch; };
+static GrRange gr_range(double* ws, long long n) {
+    GrRange r;
+    const long long nb = blocks_of(n);
+    r.nax = ws; r.nay = r.nax + n; r.naz = r.nay + n; r.ajx = r.naz + n; r.ajy = r.ajx + n; r.ajz = r.ajy + n;
+    r.wx = r.ajz + n; r.wy = r.wx + n; r.wz = r.wy + n;
+    r.bs = r.wz + n; r.wsum = r.bs + 10 * nb; r.fl = r.wsum + 3 * nb; r.scratch = r.fl + (n + SB - 1) / SB;
+    return r;
+}
+
+// rec <- records {x, y, z, G m, id0 + index} of the massive bodies of the range, in index order; count <- how many
+hipError_t launch_range_massive(const View& v, double G, double id0, double* ws, double* rec, double* count, hipStream_t st) {
+    if (v.n <= 0) return hipMemsetAsync(count, 0, sizeof(double), st);
+    const GrRange r = gr_range(ws, v.n);
+    const long long nb = (v.n + SB - 1) / SB;
+    hipLaunchKernelGGL(massive_flag_totals, dim3((unsigned)nb), dim3(SB), 0, st, v, r.fl);
+    hipLaunchKernelGGL((scan_of_totals<1, false>), dim3(1), dim3(1024), 0, st, r.fl, nb, count);
+    hipLaunchKernelGGL(massive_records, dim3((unsigned)nb), dim3(SB), 0, st, v, (const double*)r.fl, rec, G, id0);
+    return hipGetLastError();
+}
+
+// Newtonian pull of the M gathered records on the bodies of the range (kept in ws), then
+// sums10 <- (m, m x, m v, m a_newton) summed over the range
+hipError_t launch_range_gr_newton(const View& v, const double* rec, long long M, double id0, bool exact, double* ws, double* sums10, hipStream_t st) {
+    if (v.n <= 0) return hipMemsetAsync(sums10, 0, 10 * sizeof(double), st);
+    const GrRange r = gr_range(ws, v.n);
+    const dim3 g((unsigned)((v.n + SB - 1) / SB)), b(SB);
+    if (exact) hipLaunchKernelGGL(newton_from_records<true>, g, b, 0, st, v, rec, M, id0, r.nax, r.nay, r.naz);
+    else hipLaunchKernelGGL(newton_from_records<false>, g, b, 0, st, v, rec, M, id0, r.nax, r.nay, r.naz);
+    const long long nb = blocks_of(v.n);
+    hipLaunchKernelGGL(scan_block_totals<10>, dim3((unsigned)nb), b, 0, st, v, (const double*)r.nax, (const double*)r.nay, (const double*)r.naz, r.bs);
+    hipLaunchKernelGGL((scan_of_totals<10, false>), dim3(1), dim3(1024), 0, st, r.bs, nb, sums10);
+    return hipGetLastError();
+}
+
+// post-Newtonian term of every body of the range in its Jacobi frame and its weighted reaction (kept
+// in ws); push3 <- sum of the reactions.  before10: sums of every body that precedes the range
+// (nullptr for the range that starts at body 0); m0: mass of body 0 of the whole system.
+// Runs after launch_range_gr_newton, which leaves the exclusive workgroup sums in ws.
+hipError_t launch_range_gr_forces(const View& v, const DevOp& op, double G, bool starts_at_origin, const double* before10, const double* m0,
+                                  bool exact, double* ws, double* push3, unsigned* status, hipStream_t st) {
+    if (v.n <= 0) return hipMemsetAsync(push3, 0, 3 * sizeof(double), st);
+    const GrRange r = gr_range(ws, v.n);
+    const long long nb = blocks_of(v.n);
+    const dim3 g((unsigned)nb), b(SB);
+    const long long first = starts_at_origin ? 1LL : 0LL;
+    if (exact) hipLaunchKernelGGL((scan_main<SCAN_GR, true>), g, b, 0, st, v, op, G, (const double*)r.nax, (const double*)r.nay, (const double*)r.naz, (const double*)r.bs,
+                                  (const double*)r.scratch, r.ajx, r.ajy, r.ajz, r.wx, r.wy, r.wz, r.wsum, status, before10, first, m0);
+    else hipLaunchKernelGGL((scan_main<SCAN_GR, false>), g, b, 0, st, v, op, G, (const double*)r.nax, (const double*)r.nay, (const double*)r.naz, (const double*)r.bs,
+                            (const double*)r.scratch, r.ajx, r.ajy, r.ajz, r.wx, r.wy, r.wz, r.wsum, status, before10, first, m0);
+    hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(1), dim3(1024), 0, st, r.wsum, nb, push3);
+    return hipGetLastError();
+}
+
+// a_i += own_i - (reactions of the bodies from i on); after3 = reactions of every body that follows the range
+hipError_t launch_range_gr_apply(const View& v, const double* after3, double* ws, hipStream_t st) {
+    if (v.n <= 0) return hipSuccess;
+    const GrRange r = gr_range(ws, v.n);
+    hipLaunchKernelGGL(scan_apply<false>, dim3((unsigned)blocks_of(v.n)), dim3(SB), 0, st, v, (const double*)r.ajx, (const double*)r.ajy, (const double*)r.ajz,
+                       (const double*)r.wx, (const double*)r.wy, (const double*)r.wz, (const double*)r.wsum, (const double*)nullptr, after3);
     return hipGetLastError();
 }
 

@@ -134,6 +134,20 @@ class Context:
         self._check(lib.rebxamd_shard_mof_apply(self._h, ctypes.byref(view), coordinates, lo, hi,
                                                 after3.data_ptr() if after3 is not None else None, self._stream()))
 
+    def shard_massive(self, view, lo, hi, id0, records, count):
+        self._check(lib.rebxamd_shard_massive(self._h, ctypes.byref(view), lo, hi, id0, records.data_ptr(), count.data_ptr(), self._stream()))
+
+    def shard_gr_newton(self, view, lo, hi, id0, records, nrecords, sums10, mode=0):
+        self._check(lib.rebxamd_shard_gr_newton(self._h, ctypes.byref(view), lo, hi, id0, records.data_ptr() if nrecords else None, nrecords,
+                                                sums10.data_ptr(), mode, self._stream()))
+
+    def shard_gr_forces(self, view, c, max_iterations, lo, hi, before10, push3, mode=0):
+        self._check(lib.rebxamd_shard_gr_forces(self._h, ctypes.byref(view), c, max_iterations, lo, hi,
+                                                before10.data_ptr() if before10 is not None else None, push3.data_ptr(), mode, self._stream()))
+
+    def shard_gr_apply(self, view, lo, hi, after3):
+        self._check(lib.rebxamd_shard_gr_apply(self._h, ctypes.byref(view), lo, hi, after3.data_ptr() if after3 is not None else None, self._stream()))
+
     def reset_accelerations(self, view):
         self._check(lib.rebxamd_reset_accelerations(self._h, ctypes.byref(view), self._stream()))
 

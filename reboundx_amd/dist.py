@@ -36,15 +36,18 @@ def apply_forces_sharded(ctx, particles, ops, mode=0, group=None):
     the slice locally, and each op's push on its source particle is summed over ranks with one
     small all-reduce (3 doubles per op)."""
     import torch.distributed as dist
-    from ._lib import OP_MOF
-    com = [o for o in ops if o.kind == OP_MOF and o.iarg in (0, 1)]
-    if com:
-        # Jacobi/barycentric modify_orbits_forces are prefix/suffix sums over the global order: they
+    from ._lib import OP_GR, OP_MOF
+    scans = [o for o in ops if (o.kind == OP_MOF and o.iarg in (0, 1)) or o.kind == OP_GR]
+    if scans:
+        # gr and Jacobi/barycentric modify_orbits_forces are prefix/suffix sums over the global order: they
         # run as passes of their own (no op reads accelerations, so only the order of additions changes)
-        rest = [o for o in ops if not (o.kind == OP_MOF and o.iarg in (0, 1))]
+        rest = [o for o in ops if o not in scans]
         sums = apply_forces_sharded(ctx, particles, rest, mode, group) if rest else None
-        for o in com:
-            mof_com_sharded(ctx, particles, o.iarg, group)
+        for o in scans:
+            if o.kind == OP_GR:
+                gr_sharded(ctx, particles, o.a, o.iarg, mode, group)
+            else:
+                mof_com_sharded(ctx, particles, o.iarg, group)
         return sums
     view = particles.view()
     ctx.apply(particles.head_view(), ops, mode)                   # head on head, with its own back-reactions
@@ -96,6 +99,73 @@ def mof_com_sharded(ctx, particles, coordinates, group=None, exchange=None):
         after_head, after_slice = all_push.sum(dim=0), all_push[rank + 1:].sum(dim=0)
     ctx.shard_mof_apply(view, coordinates, 0, K, after_head)
     ctx.shard_mof_apply(view, coordinates, K, n, after_slice)
+
+
+def _gatherer(group, exchange):
+    """all-gather of equal-length device vectors -> ((world, len) tensor, rank).  `exchange`
+    overrides torch.distributed (tests that run the ranks one after the other)."""
+    import torch.distributed as dist
+
+    def gather(vec):
+        if exchange is not None:
+            return exchange(vec)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+            out = torch.empty(world * vec.numel(), dtype=vec.dtype, device=vec.device)
+            dist.all_gather_into_tensor(out, vec.contiguous(), group=group)
+            return out.view(world, -1), rank
+        return vec.reshape(1, -1), 0
+    return gather
+
+
+def gr_sharded(ctx, particles, c, max_iterations=10, mode=0, group=None, exchange=None, slice_offsets=None):
+    """gr (reference src/gr.c:73-171) on [replicated head | this rank's slice] with massive bodies in
+    the slices.  Four small all-gathers: the number of massive bodies per slice, their records
+    (padded to the largest count), the 10 prefix sums and the 3 back-reaction sums per slice.
+    `slice_offsets[r]`: number of slice bodies on the ranks before r (default: from the gathered
+    slice lengths)."""
+    view = particles.view()
+    K, n = particles.n_head, particles.n
+    dev = particles.cols["x"].device
+    gather = _gatherer(group, exchange)
+    z = lambda k: torch.zeros(k, dtype=torch.float64, device=dev)
+
+    # 1. massive bodies: head (replicated, same on every rank) and slices
+    lens, rank = gather(torch.tensor([float(n - K)], dtype=torch.float64, device=dev))
+    lens = [int(v) for v in lens[:, 0].tolist()]
+    if slice_offsets is None:
+        slice_offsets = [sum(lens[:r]) for r in range(len(lens))]
+    id_head, id_slice = 0, K + slice_offsets[rank]
+    head_rec, head_cnt = z(5 * max(K, 1)), z(1)
+    ctx.shard_massive(view, 0, K, id_head, head_rec, head_cnt)
+    slice_rec, slice_cnt = z(5 * max(n - K, 1)), z(1)
+    ctx.shard_massive(view, K, n, id_slice, slice_rec, slice_cnt)
+    counts, _ = gather(slice_cnt)
+    counts = [int(v) for v in counts[:, 0].tolist()]
+    cap = max(max(counts), 1)
+    padded = z(5 * cap)
+    padded[:5 * counts[rank]].copy_(slice_rec[:5 * counts[rank]])
+    all_rec, _ = gather(padded)
+    nh = int(head_cnt.item())
+    records = torch.cat([head_rec[:5 * nh]] + [all_rec[r, :5 * counts[r]] for r in range(len(counts))]).contiguous()
+    nrec = records.numel() // 5
+
+    # 2. Newtonian pull of every massive body, and the prefix sums
+    head_sums, slice_sums = z(10), z(10)
+    ctx.shard_gr_newton(view, 0, K, id_head, records, nrec, head_sums, mode)
+    ctx.shard_gr_newton(view, K, n, id_slice, records, nrec, slice_sums, mode)
+    all_sums, _ = gather(slice_sums)
+    before_slice = head_sums + all_sums[:rank].sum(dim=0)
+
+    # 3. post-Newtonian terms in the Jacobi frames, back-reactions
+    head_push, slice_push = z(3), z(3)
+    ctx.shard_gr_forces(view, c, max_iterations, 0, K, None, head_push, mode)
+    ctx.shard_gr_forces(view, c, max_iterations, K, n, before_slice, slice_push, mode)
+    all_push, _ = gather(slice_push)
+
+    # 4. back to inertial accelerations
+    ctx.shard_gr_apply(view, 0, K, all_push.sum(dim=0))
+    ctx.shard_gr_apply(view, K, n, all_push[rank + 1:].sum(dim=0))
 
 
 class HipGrFullEngine:
