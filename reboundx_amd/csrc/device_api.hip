@@ -13,7 +13,8 @@ using namespace rebxamd;
 struct rebxamd_ctx {
     int device = 0;
     std::string err;
-    HeadConsts* hc = nullptr;
+    HeadConsts* hc = nullptr;           // four tables: one per stage of a Runge-Kutta update
+    int hc_stage = 0;                   // which of them the next head / staging pass fills
     unsigned* status = nullptr;         // warning bits raised by kernels
     long long* ll = nullptr;            // 1 x int64 result slot
     double* partials = nullptr;         // back-reaction partial sums
@@ -79,13 +80,13 @@ extern "C" int rebxamd_create(int device, rebxamd_ctx** out) {
     rebxamd_ctx* ctx = new rebxamd_ctx();
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess ||
-        hipMalloc((void**)&ctx->hc, sizeof(HeadConsts)) != hipSuccess ||
+        hipMalloc((void**)&ctx->hc, 4 * sizeof(HeadConsts)) != hipSuccess ||
         hipMalloc((void**)&ctx->status, sizeof(unsigned)) != hipSuccess ||
         hipMalloc((void**)&ctx->ll, sizeof(long long)) != hipSuccess ||
         hipMalloc((void**)&ctx->gf_flag, sizeof(unsigned)) != hipSuccess ||
         hipMalloc((void**)&ctx->star, 16 * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&ctx->chunk_sums, sizeof(double) * REBXAMD_MAX_OPS * 64 * 3) != hipSuccess ||
-        hipMemset(ctx->hc, 0, sizeof(HeadConsts)) != hipSuccess ||
+        hipMemset(ctx->hc, 0, 4 * sizeof(HeadConsts)) != hipSuccess ||
         hipMemset(ctx->status, 0, sizeof(unsigned)) != hipSuccess) {
         rebxamd_destroy(ctx);
         return REBXAMD_ERR_HIP;
@@ -297,13 +298,22 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
     const long long K = v.n_head < v.n ? v.n_head : v.n;
     const bool sparse = target_lo < 0 && (u->tail_massless != 0 || K == v.n) && K >= 1 && K <= REBXAMD_MAX_HEAD && max_src < K;
 
-    if (step && !(sparse && K == 1)) return STEP_NOT_CARRIED;
+    const bool wh = step && step->epi == EPI_WH;
+    if (step && !(sparse && (wh ? K == 1 : v.n > K))) return STEP_NOT_CARRIED;
+    HeadConsts* const hc = ctx->hc + ctx->hc_stage;
     if (sparse) {
-        // in a stepping run the head pass (one body) also records and drifts that body
-        HIP_TRY(launch_head(v, prog, ctx->hc, ctx->status, exact, st, step ? ctx->star : nullptr, step ? step->h : 0.));
-        if (v.n > K) {
+        if (step && !wh) {
+            // force-integrator update of the bodies behind the head: the head passes of every stage have
+            // run (tables ctx->hc[0..]); this pass evaluates all stages per body
             TimedLaunch tl(ctx, st);
             HIP_TRY(launch_stream(v, prog, K, ctx->hc, nullptr, nullptr, false, exact, vec2, ctx->fixed_stacks, ctx->status, st, step));
+            return REBXAMD_OK;
+        }
+        // in a Wisdom-Holman run the head pass (one body) also records and drifts that body
+        HIP_TRY(launch_head(v, prog, hc, ctx->status, exact, st, wh ? ctx->star : nullptr, wh ? step->h : 0.));
+        if (v.n > K) {
+            TimedLaunch tl(ctx, st);
+            HIP_TRY(launch_stream(v, prog, K, hc, nullptr, nullptr, false, exact, vec2, ctx->fixed_stacks, ctx->status, st, step));
         }
         return REBXAMD_OK;
     }
@@ -351,10 +361,10 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
         if (rc != REBXAMD_OK) return rc;
     }
     int nblocks = 0;
-    HIP_TRY(launch_stage(v, prog, ctx->hc, st));
+    HIP_TRY(launch_stage(v, prog, hc, st));
     {
         TimedLaunch tl(ctx, st);
-        HIP_TRY(launch_stream(v, prog, first, ctx->hc, ctx->partials, &nblocks, nslots > 0, exact, vec2, ctx->fixed_stacks, ctx->status, st));
+        HIP_TRY(launch_stream(v, prog, first, hc, ctx->partials, &nblocks, nslots > 0, exact, vec2, ctx->fixed_stacks, ctx->status, st));
     }
     if (nslots > 0 || sums_out) HIP_TRY(launch_finalize(v, prog, ctx->partials, nblocks, ctx->chunk_sums, sums_out, st));
     return REBXAMD_OK;
@@ -408,6 +418,18 @@ extern "C" int rebxamd_add_pushes(rebxamd_ctx* ctx, const rebxamd_view* view, co
 
 // ------------------------------------------------------------------ force integrators, kick, drift
 
+// whether rebxamd_apply would run the whole op list as a single streaming run
+static bool one_streaming_run(const rebxamd_op* ops, int nops) {
+    if (nops <= 0 || nops > REBXAMD_MAX_OPS) return false;
+    int ngr = 0, ncom = 0;
+    for (int k = 0; k < nops; k++) {
+        if (ops[k].kind == REBXAMD_OP_GR_FULL) return false;
+        if (ops[k].kind == REBXAMD_OP_GR && ++ngr > 1) return false;
+        if (ops[k].kind == REBXAMD_OP_MOF && ops[k].iarg != REBX_COORDINATES_PARTICLE && ++ncom > 1) return false;
+    }
+    return true;
+}
+
 static int check_step_view(rebxamd_ctx* ctx, const rebxamd_view* v, const char* who, bool need_pos, bool need_acc) {
     if (!ctx) return REBXAMD_ERR_ARG;
     if (!v || v->n < 0) return fail(ctx, REBXAMD_ERR_ARG, who);
@@ -451,12 +473,46 @@ extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* vie
     const bool exact = mode == REBXAMD_MODE_EXACT;
     const long long n = view->n;
     HIP_TRY(hipSetDevice(ctx->device));
-    // integrate_force.c:46 -- the simulation's accelerations are cleared first, whatever the scheme
-    rc = rebxamd_reset_accelerations(ctx, view, stream);
-    if (rc != REBXAMD_OK || n == 0) return rc;
-    if (integrator != REBXAMD_INTEGRATOR_EULER && integrator != REBXAMD_INTEGRATOR_RK2 && integrator != REBXAMD_INTEGRATOR_RK4 &&
-        integrator != REBXAMD_INTEGRATOR_IMPLICIT_MIDPOINT)
-        return REBXAMD_OK;                       // REBX_INTEGRATOR_NONE and unknown values do nothing (integrate_force.c:69-76)
+    const bool known = integrator == REBXAMD_INTEGRATOR_EULER || integrator == REBXAMD_INTEGRATOR_RK2 || integrator == REBXAMD_INTEGRATOR_RK4 ||
+                       integrator == REBXAMD_INTEGRATOR_IMPLICIT_MIDPOINT;
+    // Massive bodies in a short prefix, massless bodies behind it, the stack one streaming run: the
+    // prefix goes through the separate passes below (on a view of the prefix alone, one head table
+    // per stage), and ONE pass over the massless bodies evaluates every stage of their update in
+    // registers: they are read once and only their velocities and first-stage accelerations written.
+    const long long K = view->n_head < n ? view->n_head : n;
+    bool carried = known && ctx->carried_steps && integrator != REBXAMD_INTEGRATOR_IMPLICIT_MIDPOINT && one_streaming_run(ops, nops) &&
+                   view->tail_massless != 0 && K >= 1 && K <= REBXAMD_MAX_HEAD && K < n && view->m != nullptr;
+    for (int k = 0; k < nops && carried; k++) {
+        const bool com = ops[k].kind == REBXAMD_OP_MOF && ops[k].iarg != REBX_COORDINATES_PARTICLE;
+        const int src = (ops[k].kind == REBXAMD_OP_GR || ops[k].kind == REBXAMD_OP_GR_POTENTIAL) ? 0 : ops[k].src;
+        if (!com && (src < 0 || src >= K)) carried = false;
+    }
+    if (!carried) {
+        // integrate_force.c:46 -- the simulation's accelerations are cleared first, whatever the scheme
+        // (the carried pass overwrites those of the massless bodies, the prefix clears its own)
+        rc = rebxamd_reset_accelerations(ctx, view, stream);
+        if (rc != REBXAMD_OK || n == 0) return rc;
+    }
+    if (!known) return REBXAMD_OK;               // REBX_INTEGRATOR_NONE and unknown values do nothing (integrate_force.c:69-76)
+
+    {
+        if (carried) {
+            rebxamd_view head = *view;
+            head.n = K; head.n_head = K;
+            const bool saved = ctx->carried_steps;
+            ctx->carried_steps = false;                        // the prefix itself takes the separate passes
+            rc = rebxamd_integrate_force(ctx, &head, ops, nops, integrator, dt, mode, nullptr, stream);
+            ctx->carried_steps = saved;
+            ctx->hc_stage = 0;
+            if (rc != REBXAMD_OK) return rc;
+            StepArgs sa = {0., 0., nullptr, EPI_EULER, dt, 0., 0.};
+            if (integrator == REBXAMD_INTEGRATOR_RK2) { sa.epi = EPI_RK2; sa.c0 = 2. * dt / 3.; sa.c1 = dt / 4.; sa.c2 = 3. * dt / 4.; }
+            if (integrator == REBXAMD_INTEGRATOR_RK4) { sa.epi = EPI_RK4; sa.c0 = dt / 2.; sa.c1 = dt; sa.c2 = dt / 6.; }
+            rc = run_streaming(ctx, view, ops, 0, nops, mode, st, -1, nullptr, false, &sa);
+            if (rc != STEP_NOT_CARRIED) return rc;
+            return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_integrate_force: layout changed between passes");
+        }
+    }
 
     double* const v[3] = {const_cast<double*>(view->vx), const_cast<double*>(view->vy), const_cast<double*>(view->vz)};
     const double* const cv[3] = {view->vx, view->vy, view->vz};
@@ -487,10 +543,13 @@ extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* vie
     // the reference copies the particle array after the reset: stage accelerations start at zero
     HIP_TRY(hipMemsetAsync(ka[0], 0, 6 * stride * sizeof(double), st));
 
+    // each stage's head tables are kept (ctx->hc[stage]) for a pass that evaluates all stages at once
+    struct StageReset { rebxamd_ctx* c; ~StageReset() { c->hc_stage = 0; } } stage_reset{ctx};
     if (integrator == REBXAMD_INTEGRATOR_RK2) {                // integrator_rk2.c:38-67
         rc = rebxamd_apply(ctx, view, ops, nops, mode, stream);
         if (rc != REBXAMD_OK) return rc;
         HIP_TRY(launch_lincomb(sv, cv, ca1, 2. * dt / 3., n, exact, st));
+        ctx->hc_stage = 1;
         rc = rebxamd_apply(ctx, &sa, ops, nops, mode, stream);
         if (rc != REBXAMD_OK) return rc;
         HIP_TRY(launch_rk2_final(v, ca1, cka, dt / 4., 3. * dt / 4., n, exact, st));
@@ -501,12 +560,15 @@ extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* vie
         rc = rebxamd_apply(ctx, view, ops, nops, mode, stream);                 // k1
         if (rc != REBXAMD_OK) return rc;
         HIP_TRY(launch_lincomb(sv, cv, ca1, dt2, n, exact, st));
+        ctx->hc_stage = 1;
         rc = rebxamd_apply(ctx, &sa, ops, nops, mode, stream);                  // k2 -> ka
         if (rc != REBXAMD_OK) return rc;
         HIP_TRY(launch_lincomb(sv, cv, cka, dt2, n, exact, st));
+        ctx->hc_stage = 2;
         rc = rebxamd_apply(ctx, &sb, ops, nops, mode, stream);                  // k3 -> kb
         if (rc != REBXAMD_OK) return rc;
         HIP_TRY(launch_rk4_mid(sv, cv, ka, kb, dt, n, exact, st));              // kb = k3 + k2, ka = 0
+        ctx->hc_stage = 3;
         rc = rebxamd_apply(ctx, &sa, ops, nops, mode, stream);                  // k4 -> ka
         if (rc != REBXAMD_OK) return rc;
         HIP_TRY(launch_rk4_final(v, ca1, cka, ckb, dt / 6., n, exact, st));
@@ -579,17 +641,11 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
     if (rc != REBXAMD_OK) return rc;
     // When the whole stack is one streaming run, the pass over the massless bodies carries the
     // kick and the drift as well: their accelerations never leave registers.
-    bool carried = ctx->carried_steps && nops > 0 && nops <= REBXAMD_MAX_OPS;
-    int ngr = 0, ncom = 0;
-    for (int k = 0; k < nops && carried; k++) {
-        if (ops[k].kind == REBXAMD_OP_GR_FULL) carried = false;
-        if (ops[k].kind == REBXAMD_OP_GR && ++ngr > 1) carried = false;
-        if (ops[k].kind == REBXAMD_OP_MOF && ops[k].iarg != REBX_COORDINATES_PARTICLE && ++ncom > 1) carried = false;
-    }
+    bool carried = ctx->carried_steps && one_streaming_run(ops, nops);
     for (int64_t k = 0; k < nsteps; k++) {
         const double h = k + 1 < nsteps ? dt : 0.5 * dt;
         if (carried) {
-            const StepArgs sa = {h, dt, ctx->star};
+            const StepArgs sa = {h, dt, ctx->star, EPI_WH, 0., 0., 0.};
             rc = run_streaming(ctx, view, ops, 0, nops, mode, st, -1, nullptr, false, &sa);
             if (rc == REBXAMD_OK) continue;
             if (rc != STEP_NOT_CARRIED) return rc;

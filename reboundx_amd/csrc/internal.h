@@ -60,10 +60,18 @@ struct HeadConsts {
     double bary[REBXAMD_MAX_HEAD][3];   // massratio_i * a_i for i = nbary-1 .. 0 (application order)
 };
 
-// Wisdom-Holman kick and drift carried by the streaming pass behind the head (tail bodies
-// massless): drift length, kick length, and the record of body 0 (its state before the drift, its
-// position after it, its acceleration, its mass parameter G*m_0).
-struct StepArgs { double h, dtk; const double* star; };
+// What the streaming pass behind the head (tail bodies massless) does with the forces it has
+// computed, besides or instead of adding them to the acceleration columns:
+//   EPI_WH    a whole Wisdom-Holman step: kick by dtk, Kepler drift over h about body 0, whose record
+//             (state before the drift, position after it, acceleration, G*m_0) is `star`;
+//   EPI_EULER / EPI_RK2 / EPI_RK4   a whole "integrate the force across dt" update of the velocities
+//             (reference src/integrator_euler.c, integrator_rk2.c, integrator_rk4.c): every stage is
+//             evaluated on the body while it sits in registers, against the head tables of that stage
+//             (tab[0], tab[1], ...); the new velocities and the first-stage accelerations are written.
+//             c0, c1, c2: Euler dt; RK2 2dt/3, dt/4, 3dt/4; RK4 dt/2, dt, dt/6 (formed on the host
+//             exactly as the separate passes form them).
+enum { EPI_NONE = 0, EPI_WH = 1, EPI_EULER = 2, EPI_RK2 = 3, EPI_RK4 = 4 };
+struct StepArgs { double h, dtk; const double* star; int epi; double c0, c1, c2; };
 
 enum { WARN_GR_ITER = 1u, WARN_GRFULL_SWEEPS = 2u, WARN_IM_ITER = 4u };
 

@@ -6,6 +6,7 @@
 #include "internal.h"
 #include "effects.h"
 #include "kepler.h"
+#include "updates.h"
 
 namespace rebxamd {
 
@@ -13,16 +14,6 @@ static constexpr int TB = 256;
 
 struct Cols3 { double *x, *y, *z; };
 struct CCols3 { const double *x, *y, *z; };
-
-template <bool EXACT>
-__device__ __forceinline__ double axpy1(double v, double c, double a) {
-    if (EXACT) {
-#pragma clang fp contract(off)
-        return v + c * a;
-    } else {
-        return fma(c, a, v);
-    }
-}
 
 // out = v + coef * a   (out may alias v: kick, drift, euler)
 template <bool EXACT>
@@ -39,16 +30,9 @@ template <bool EXACT>
 __global__ __launch_bounds__(TB) void rk2_final_kernel(Cols3 v, CCols3 a1, CCols3 a2, double b1, double b2, long long n) {
     const long long i = (long long)blockIdx.x * TB + threadIdx.x;
     if (i >= n) return;
-    if (EXACT) {
-#pragma clang fp contract(off)
-        v.x[i] += b1 * a1.x[i] + b2 * a2.x[i];
-        v.y[i] += b1 * a1.y[i] + b2 * a2.y[i];
-        v.z[i] += b1 * a1.z[i] + b2 * a2.z[i];
-    } else {
-        v.x[i] += b1 * a1.x[i] + b2 * a2.x[i];
-        v.y[i] += b1 * a1.y[i] + b2 * a2.y[i];
-        v.z[i] += b1 * a1.z[i] + b2 * a2.z[i];
-    }
+    v.x[i] = rk2_combine<EXACT>(v.x[i], b1, a1.x[i], b2, a2.x[i]);
+    v.y[i] = rk2_combine<EXACT>(v.y[i], b1, a1.y[i], b2, a2.y[i]);
+    v.z[i] = rk2_combine<EXACT>(v.z[i], b1, a1.z[i], b2, a2.z[i]);
 }
 
 // integrator_rk4.c:74-82:  stage velocity for k4 = v + dt*k3;  k3 += k2;  k2's accelerations reset
@@ -69,16 +53,9 @@ template <bool EXACT>
 __global__ __launch_bounds__(TB) void rk4_final_kernel(Cols3 v, CCols3 a1, CCols3 a4, CCols3 k23, double dt6, long long n) {
     const long long i = (long long)blockIdx.x * TB + threadIdx.x;
     if (i >= n) return;
-    if (EXACT) {
-#pragma clang fp contract(off)
-        v.x[i] += dt6 * (a1.x[i] + a4.x[i] + 2. * k23.x[i]);
-        v.y[i] += dt6 * (a1.y[i] + a4.y[i] + 2. * k23.y[i]);
-        v.z[i] += dt6 * (a1.z[i] + a4.z[i] + 2. * k23.z[i]);
-    } else {
-        v.x[i] += dt6 * (a1.x[i] + a4.x[i] + 2. * k23.x[i]);
-        v.y[i] += dt6 * (a1.y[i] + a4.y[i] + 2. * k23.y[i]);
-        v.z[i] += dt6 * (a1.z[i] + a4.z[i] + 2. * k23.z[i]);
-    }
+    v.x[i] = rk4_combine<EXACT>(v.x[i], dt6, a1.x[i], a4.x[i], k23.x[i]);
+    v.y[i] = rk4_combine<EXACT>(v.y[i], dt6, a1.y[i], a4.y[i], k23.y[i]);
+    v.z[i] = rk4_combine<EXACT>(v.z[i], dt6, a1.z[i], a4.z[i], k23.z[i]);
 }
 
 // integrator_implicit_midpoint.c:101-114: new estimate of the final velocities from the

@@ -21,6 +21,7 @@
 #include "internal.h"
 #include "effects.h"
 #include "kepler.h"
+#include "updates.h"
 
 namespace rebxamd {
 
@@ -543,14 +544,47 @@ __device__ __forceinline__ void general_fixed(const Program& prog, const HeadCon
     }
 }
 
-// STEP (tail pass only): the pass carries a whole Wisdom-Holman step of the massless bodies.  The
-// forces start from zero instead of the acceleration columns, the body is kicked with them and
-// drifted on its Kepler orbit about body 0, and positions and velocities are written back; the
-// acceleration columns are neither read nor written.
-template <bool EXACT, bool BACKREACT, bool VEC2, int COLS, Sig SIG = 0ull, bool STEP = false>
+// The remaining stages of a Runge-Kutta update of one body behind the head, given its first-stage
+// accelerations k1: each stage evaluates the stack at the stage velocity against that stage's head
+// tables.  Arithmetic of the separate passes (lincomb / rk2_final / rk4_mid / rk4_final kernels).
+template <bool EXACT, Sig SIG, int EPI>
+__device__ __forceinline__ void integrate_tail(const Program& prog, const HeadConsts* __restrict__ tab, Part& p, const V3& k1, const StepArgs& sa, unsigned* status) {
+    const double vx = p.vx, vy = p.vy, vz = p.vz;
+    if (EPI == EPI_EULER) {
+        p.vx = axpy1<EXACT>(vx, sa.c0, k1.x); p.vy = axpy1<EXACT>(vy, sa.c0, k1.y); p.vz = axpy1<EXACT>(vz, sa.c0, k1.z);
+    } else if (EPI == EPI_RK2) {
+        V3 k2 = {0., 0., 0.};
+        p.vx = axpy1<EXACT>(vx, sa.c0, k1.x); p.vy = axpy1<EXACT>(vy, sa.c0, k1.y); p.vz = axpy1<EXACT>(vz, sa.c0, k1.z);
+        tail_particle<EXACT, SIG>(prog, tab + 1, p, k2, status);
+        p.vx = rk2_combine<EXACT>(vx, sa.c1, k1.x, sa.c2, k2.x);
+        p.vy = rk2_combine<EXACT>(vy, sa.c1, k1.y, sa.c2, k2.y);
+        p.vz = rk2_combine<EXACT>(vz, sa.c1, k1.z, sa.c2, k2.z);
+    } else {
+        V3 k2 = {0., 0., 0.}, k3 = {0., 0., 0.}, k4 = {0., 0., 0.};
+        p.vx = axpy1<EXACT>(vx, sa.c0, k1.x); p.vy = axpy1<EXACT>(vy, sa.c0, k1.y); p.vz = axpy1<EXACT>(vz, sa.c0, k1.z);
+        tail_particle<EXACT, SIG>(prog, tab + 1, p, k2, status);
+        p.vx = axpy1<EXACT>(vx, sa.c0, k2.x); p.vy = axpy1<EXACT>(vy, sa.c0, k2.y); p.vz = axpy1<EXACT>(vz, sa.c0, k2.z);
+        tail_particle<EXACT, SIG>(prog, tab + 2, p, k3, status);
+        p.vx = axpy1<EXACT>(vx, sa.c1, k3.x); p.vy = axpy1<EXACT>(vy, sa.c1, k3.y); p.vz = axpy1<EXACT>(vz, sa.c1, k3.z);
+        const double sx = k3.x + k2.x, sy = k3.y + k2.y, sz = k3.z + k2.z;
+        tail_particle<EXACT, SIG>(prog, tab + 3, p, k4, status);
+        p.vx = rk4_combine<EXACT>(vx, sa.c2, k1.x, k4.x, sx);
+        p.vy = rk4_combine<EXACT>(vy, sa.c2, k1.y, k4.y, sy);
+        p.vz = rk4_combine<EXACT>(vz, sa.c2, k1.z, k4.z, sz);
+    }
+}
+
+// EPI (tail pass only; see StepArgs).  EPI_WH: the pass carries a whole Wisdom-Holman step of the
+// massless bodies -- the forces start from zero instead of the acceleration columns, the body is
+// kicked with them and drifted on its Kepler orbit about body 0, and positions and velocities are
+// written back; the acceleration columns are neither read nor written.  EPI_EULER/RK2/RK4: the
+// pass carries a whole velocity update of a force integrator; velocities and the first-stage
+// accelerations are written.
+template <bool EXACT, bool BACKREACT, bool VEC2, int COLS, Sig SIG = 0ull, int EPI = EPI_NONE>
 __global__ __launch_bounds__(BLOCK, (!EXACT && !BACKREACT && COLS != COL_ALL) ? 4 : 3) void stream_kernel(View v, Program prog, long long lo, long long base,
                                                        const HeadConsts* __restrict__ tab, double* partials, unsigned* status, StepArgs step) {
-    static_assert(!STEP || (!BACKREACT && (COLS & COL_VEL)), "a stepping pass streams massless bodies and needs their velocities");
+    static_assert(EPI == EPI_NONE || (!BACKREACT && (COLS & COL_VEL)), "a stepping pass streams massless bodies and needs their velocities");
+    constexpr bool STEP = EPI != EPI_NONE;        // forces start from zero
     const int tid = threadIdx.x;
     const long long i0 = base + 2 * ((long long)blockIdx.x * BLOCK + tid);
     const bool in0 = i0 < v.n, in1 = i0 + 1 < v.n;
@@ -620,7 +654,25 @@ __global__ __launch_bounds__(BLOCK, (!EXACT && !BACKREACT && COLS != COL_ALL) ? 
         }
     }
 
-    if (STEP) {
+    if (EPI >= EPI_EULER) {
+        double* const pvx = const_cast<double*>(v.vx); double* const pvy = const_cast<double*>(v.vy); double* const pvz = const_cast<double*>(v.vz);
+        if (act0) integrate_tail<EXACT, SIG, EPI>(prog, tab, p[0], acc[0], step, status);
+        if (act1) integrate_tail<EXACT, SIG, EPI>(prog, tab, p[1], acc[1], step, status);
+        if (full) {
+            d2v t;
+            t.x = p[0].vx; t.y = p[1].vx; *reinterpret_cast<d2v*>(pvx + i0) = t;
+            t.x = p[0].vy; t.y = p[1].vy; *reinterpret_cast<d2v*>(pvy + i0) = t;
+            t.x = p[0].vz; t.y = p[1].vz; *reinterpret_cast<d2v*>(pvz + i0) = t;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                if (!(k ? act1 : act0)) continue;
+                pvx[i0 + k] = p[k].vx; pvy[i0 + k] = p[k].vy; pvz[i0 + k] = p[k].vz;
+            }
+        }
+        // the first-stage accelerations go to the acceleration columns below
+    }
+    if (EPI == EPI_WH) {
         double* const px = const_cast<double*>(v.x); double* const py = const_cast<double*>(v.y); double* const pz = const_cast<double*>(v.z);
         double* const pvx = const_cast<double*>(v.vx); double* const pvy = const_cast<double*>(v.vy); double* const pvz = const_cast<double*>(v.vz);
         double s[2][6];
@@ -770,20 +822,30 @@ hipError_t launch_head(const View& v, const Program& prog, HeadConsts* hc, unsig
 template <bool EXACT, bool BACKREACT>
 static void launch_stream_cols(dim3 g, dim3 b, hipStream_t st, bool vec2, bool fixed, int cols, const View& v, const Program& prog, long long lo,
                                long long base, const HeadConsts* hc, double* partials, unsigned* status, const StepArgs* step) {
-    const StepArgs sa = step ? *step : StepArgs{0., 0., nullptr};
+    const StepArgs sa = step ? *step : StepArgs{0., 0., nullptr, EPI_NONE, 0., 0., 0.};
     Sig sig = 0ull;
     if (fixed && vec2 && prog.nops <= 8) for (int o = 0; o < prog.nops; o++) sig |= (Sig)(prog.ops[o].kind & 15) << (4 * o);
     if (step) {
-        // a whole Wisdom-Holman step in the pass (massless tail only)
+        // a whole Wisdom-Holman step or force-integrator update in the pass (massless tail only)
         if constexpr (!BACKREACT) {
-#define FIXED_STEP(...) \
+#define EPILOGUE(E) \
+    { FIXED_EPI(E, REBXAMD_OP_RADIATION, REBXAMD_OP_J2, REBXAMD_OP_J4, REBXAMD_OP_GR) \
+      FIXED_EPI(E, REBXAMD_OP_RADIATION, REBXAMD_OP_J2, REBXAMD_OP_J4, REBXAMD_OP_GR_POTENTIAL, REBXAMD_OP_TIDES, REBXAMD_OP_MOF) \
+      if (vec2) hipLaunchKernelGGL((stream_kernel<EXACT, false, true, COL_ALL, 0ull, E>), g, b, 0, st, v, prog, lo, base, hc, partials, status, sa); \
+      else hipLaunchKernelGGL((stream_kernel<EXACT, false, false, COL_ALL, 0ull, E>), g, b, 0, st, v, prog, lo, base, hc, partials, status, sa); \
+      return; }
+#define FIXED_EPI(E, ...) \
     { constexpr Sig S_ = sig_of(__VA_ARGS__); \
-      if (sig == S_) { hipLaunchKernelGGL((stream_kernel<EXACT, false, true, sig_cols(S_, true) | COL_VEL, S_, true>), g, b, 0, st, v, prog, lo, base, hc, partials, status, sa); return; } }
-            FIXED_STEP(REBXAMD_OP_RADIATION, REBXAMD_OP_J2, REBXAMD_OP_J4, REBXAMD_OP_GR)
-            FIXED_STEP(REBXAMD_OP_RADIATION, REBXAMD_OP_J2, REBXAMD_OP_J4, REBXAMD_OP_GR_POTENTIAL, REBXAMD_OP_TIDES, REBXAMD_OP_MOF)
-#undef FIXED_STEP
-            if (vec2) hipLaunchKernelGGL((stream_kernel<EXACT, false, true, COL_ALL, 0ull, true>), g, b, 0, st, v, prog, lo, base, hc, partials, status, sa);
-            else hipLaunchKernelGGL((stream_kernel<EXACT, false, false, COL_ALL, 0ull, true>), g, b, 0, st, v, prog, lo, base, hc, partials, status, sa);
+      if (sig == S_) { hipLaunchKernelGGL((stream_kernel<EXACT, false, true, sig_cols(S_, true) | COL_VEL, S_, E>), g, b, 0, st, v, prog, lo, base, hc, partials, status, sa); return; } }
+            switch (sa.epi) {
+            case EPI_WH: EPILOGUE(EPI_WH)
+            case EPI_EULER: EPILOGUE(EPI_EULER)
+            case EPI_RK2: EPILOGUE(EPI_RK2)
+            case EPI_RK4: EPILOGUE(EPI_RK4)
+            default: break;
+            }
+#undef FIXED_EPI
+#undef EPILOGUE
         }
         return;
     }

@@ -3,11 +3,14 @@ integrate_force schemes, kick/drift, the potential reductions, the gr Hamiltonia
 prefix-sum path of gr / Jacobi modify_orbits_forces.
 usage: python scripts/bench_next_rows.py [n] [reps]
 
-Algorithmic bytes per particle (fp64 columns, C5 stack = 152 B per force pass with the
-accelerations read and written, 128 B when they are only written):
-  euler  = 1 pass + kick (v r/w 48 + a 24)
-  rk2    = 2 passes + stage (v 24 + a 24 + out 24) + final (v 48 + 2a 48)
-  rk4    = 4 passes + 2 stages + mid (v 24, k3 48, k2 48, out 24) + final (v 48 + 3a 72)
+Algorithmic bytes per particle (fp64 columns, C5 stack).  With massless bodies behind the star
+one pass evaluates every stage of a scheme in registers: positions, velocities, mass and the six
+parameters read (104 B), velocities and first-stage accelerations written (48 B) = 152 B for
+euler, rk2 and rk4 alike.  As separate passes (CARRIED=0 in the environment; 152 B per force
+pass with the accelerations read and written):
+  euler  = 1 pass + kick (v r/w 48 + a 24)                                          = 224 B
+  rk2    = 2 passes + stage (v 24 + a 24 + out 24) + final (v 48 + 2a 48)           = 472 B
+  rk4    = 4 passes + 2 stages + mid (v 24, k3 48, k2 48, out 24) + final (v 48 + 3a 72) = 1016 B
 """
 import os
 import sys
@@ -27,6 +30,8 @@ n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 C = synthetic.C_DEFAULT
 ctx = Context(0)
+CARRIED = os.environ.get("CARRIED") != "0"
+ctx.carried_steps(CARRIED)
 C5 = [("radiation_forces", {"c": C}), ("gravitational_harmonics", {}), ("gr_potential", {"c": C}), ("tides_precession", {}),
       ("modify_orbits_forces", {"coordinates": 2})]
 
@@ -53,7 +58,8 @@ view = dp.view()
 print("n = %d, C5 stack (5 effects)" % n)
 t = timed(lambda: ctx.apply(view, ops, 0))
 print("  force pass                 %9.1f us   %6.2f TB/s algorithmic (152 B)" % (t * 1e6, 152 * n / t / 1e12))
-BYTES = {"euler": 152 + 72, "rk2": 2 * 152 + 72 + 96, "rk4": 4 * 152 + 2 * 72 + 144 + 120, "implicit_midpoint": None}
+BYTES = ({"euler": 152, "rk2": 152, "rk4": 152, "implicit_midpoint": None} if CARRIED else
+         {"euler": 152 + 72, "rk2": 2 * 152 + 72 + 96, "rk4": 4 * 152 + 2 * 72 + 144 + 120, "implicit_midpoint": None})
 for integ in ("euler", "rk2", "rk4", "implicit_midpoint"):
     for mode in (0, 1):
         its = []

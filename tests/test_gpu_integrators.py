@@ -77,6 +77,41 @@ def test_five_effect_stack_star_planets_dust(ctx, integrator, mode):
         assert 1 <= n_dev < 10 and not ad.any() and not ar.any()
 
 
+C2_STACK = [("radiation_forces", {"c": C}), ("gravitational_harmonics", {}), ("gr", {"c": C})]
+MIXED_STACK = [("modify_orbits_forces", {"coordinates": 1}), ("radiation_forces", {"c": C}), ("gr", {"c": C}), ("tides_precession", {})]
+
+
+@pytest.mark.parametrize("mode", [EXACT, FAST])
+@pytest.mark.parametrize("integrator", ["euler", "rk2", "rk4"])
+@pytest.mark.parametrize("forces", [C5_STACK, C2_STACK, MIXED_STACK], ids=["five-effects", "rad+harmonics+gr", "walked-op-list"])
+@pytest.mark.parametrize("n,planets", [(2, 0), (5, 1), (4099, 2), (6002, 3)])
+def test_update_carried_by_one_pass_equals_separate_passes(ctx, n, planets, forces, integrator, mode):
+    """With massless bodies behind a short massive prefix, one pass over them evaluates every
+    stage of the scheme in registers (the prefix runs the separate passes, one head table per
+    stage).  Switched off, every stage is a force pass plus an elementwise pass.  Same
+    expressions: bit-equal velocities and left-over accelerations in reference-order arithmetic."""
+    cols, pp, _ = synthetic.disk(n, planets)
+    ops = build_ops(forces, pp)
+    out = []
+    for carried in (True, False):
+        dp = device_state(cols, pp)
+        try:
+            ctx.carried_steps(carried)
+            ctx.integrate_force(dp.view(), ops, integrator, 0.01, mode)
+        finally:
+            ctx.carried_steps(True)
+        out.append((vel(dp), np.array(dp.acc_host())))
+    (v1, a1), (v2, a2) = out
+    assert np.isfinite(v1).all() and np.isfinite(a1).all()
+    if mode == EXACT:
+        assert np.array_equal(v1, v2) and np.array_equal(a1, a2)
+    else:
+        v0 = np.array([cols[k] for k in ("vx", "vy", "vz")])
+        assert dv_err(v0, v2, v1) <= TOL
+        big = np.abs(a2).max(axis=0)
+        assert (np.abs(a1 - a2) / np.where(big == 0., 1., big)[None, :]).max() <= TOL
+
+
 @pytest.mark.parametrize("integrator", ["rk4", "implicit_midpoint"])
 def test_every_particle_massive_uses_reductions(ctx, integrator):
     n = 20011
