@@ -493,11 +493,14 @@ int rebxamd_timing_enable(rebxamd_ctx* ctx, int on);
  * Both compute the same expressions.  on = 0 makes this context always walk the list
  * (default: 1). */
 int rebxamd_fixed_stacks(rebxamd_ctx* ctx, int on);
-/* Kernel selection for rebxamd_wh_steps (no counterpart in the reference).  When the force stack
- * is one streaming run, the pass over the massless bodies also kicks and drifts them, so that
- * their accelerations never go through memory (the acceleration columns stay zero).  on = 0 makes
- * this context run force pass and kick+drift pass separately (default: 1).  Both compute the
- * same expressions. */
+/* Kernel selection for rebxamd_wh_steps and rebxamd_integrate_force (no counterpart in the
+ * reference).  When the massive bodies are a short prefix, the bodies behind it massless and the
+ * force stack one streaming run, the pass over the massless bodies carries the whole update:
+ * rebxamd_wh_steps -- forces, kick and Kepler drift (their accelerations never go through memory;
+ * the acceleration columns stay zero); rebxamd_integrate_force with the Euler, RK2 or RK4 scheme
+ * -- every stage evaluated in registers, velocities and first-stage accelerations written.
+ * on = 0 makes this context run force passes and elementwise passes separately (default: 1).
+ * Both compute the same expressions. */
 int rebxamd_carried_steps(rebxamd_ctx* ctx, int on);
 int rebxamd_timing_read(rebxamd_ctx* ctx, double* total_ms, int* launches);
 
