@@ -28,20 +28,45 @@ static constexpr int SCHUNK = SB * ST;
 
 enum ScanKind { SCAN_GR = 0, SCAN_MOF_JACOBI = 1, SCAN_MOF_BARY = 2 };
 
+// Wavefront scans.  Within each row of 16 lanes: four data-parallel-primitive shifts (row_shr /
+// row_shl by 1, 2, 4, 8; lanes the shift leaves empty read zero), which run at VALU rate instead
+// of going through the LDS crossbar; across the four rows: the row totals are read with
+// v_readlane and added to the rows behind (in front, for the suffix scan).
+template <int CTRL>
+__device__ __forceinline__ double dpp_shift(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
+__device__ __forceinline__ double lane_value(double v, int lane) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __device__ __forceinline__ double wave_incl_scan(double v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double t = __shfl_up(v, off, 64);
-        if (lane >= off) v += t;
-    }
+    v += dpp_shift<0x111>(v);       // row_shr:1
+    v += dpp_shift<0x112>(v);       // row_shr:2
+    v += dpp_shift<0x114>(v);       // row_shr:4
+    v += dpp_shift<0x118>(v);       // row_shr:8
+    const int row = lane >> 4;
+    const double t0 = lane_value(v, 15), t2 = lane_value(v, 47);
+    v += (row == 1) ? t0 : ((row == 3) ? t2 : 0.);
+    const double t01 = lane_value(v, 31);
+    v += (row >= 2) ? t01 : 0.;
     return v;
 }
 __device__ __forceinline__ double wave_incl_scan_rev(double v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double t = __shfl_down(v, off, 64);
-        if (lane + off < 64) v += t;
-    }
+    v += dpp_shift<0x101>(v);       // row_shl:1
+    v += dpp_shift<0x102>(v);       // row_shl:2
+    v += dpp_shift<0x104>(v);       // row_shl:4
+    v += dpp_shift<0x108>(v);       // row_shl:8
+    const int row = lane >> 4;
+    const double t1 = lane_value(v, 16), t3 = lane_value(v, 48);
+    v += (row == 0) ? t1 : ((row == 2) ? t3 : 0.);
+    const double t23 = lane_value(v, 32);
+    v += (row <= 1) ? t23 : 0.;
     return v;
 }
 
@@ -92,13 +117,16 @@ __device__ __forceinline__ void block_total(double (&v)[C], double (*lds)[C]) {
 }
 
 // ---- per-element quantities that get scanned
+// read-once streams carry the nontemporal hint (they would only push useful lines out of the caches)
+__device__ __forceinline__ double ldnt(const double* col, long long i) { return __builtin_nontemporal_load(col + i); }
+
 template <int C>
 __device__ __forceinline__ void weighted_state(const View& v, const double* nax, const double* nay, const double* naz, long long i, double (&q)[C]) {
-    const double m = v.m[i];
+    const double m = ldnt(v.m, i);
     q[0] = m;
-    q[1] = m * v.x[i]; q[2] = m * v.y[i]; q[3] = m * v.z[i];
-    q[4] = m * v.vx[i]; q[5] = m * v.vy[i]; q[6] = m * v.vz[i];
-    if constexpr (C == 10) { q[7] = m * nax[i]; q[8] = m * nay[i]; q[9] = m * naz[i]; }
+    q[1] = m * ldnt(v.x, i); q[2] = m * ldnt(v.y, i); q[3] = m * ldnt(v.z, i);
+    q[4] = m * ldnt(v.vx, i); q[5] = m * ldnt(v.vy, i); q[6] = m * ldnt(v.vz, i);
+    if constexpr (C == 10) { q[7] = m * ldnt(nax, i); q[8] = m * ldnt(nay, i); q[9] = m * ldnt(naz, i); }
 }
 
 // pass 1: workgroup totals of the weighted state (a workgroup covers ST tiles of SB bodies)
@@ -124,12 +152,14 @@ __global__ __launch_bounds__(SB) void scan_block_totals(View v, const double* na
     }
 }
 
+// (512 threads: ten running sums per thread in three copies fit the register file without spilling)
+static constexpr int SOT = 512;
 // pass 2: exclusive scan of the workgroup totals, in place, by ONE workgroup; totals[c] = grand total.
 template <int C, bool REVERSE>
-__global__ __launch_bounds__(1024) void scan_of_totals(double* blocksums, long long nb, double* totals) {
-    __shared__ double lds[16][C];
+__global__ __launch_bounds__(SOT) void scan_of_totals(double* blocksums, long long nb, double* totals) {
+    __shared__ double lds[SOT / 64][C];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const long long chunk = (nb + 1023) / 1024;
+    const long long chunk = (nb + SOT - 1) / SOT;
     long long b0 = (long long)tid * chunk, b1 = b0 + chunk;
     if (b0 > nb) b0 = nb;
     if (b1 > nb) b1 = nb;
@@ -153,7 +183,7 @@ __global__ __launch_bounds__(1024) void scan_of_totals(double* blocksums, long l
 #pragma unroll
     for (int c = 0; c < C; c++) {
         double before = 0., all = 0.;
-        for (int w = 0; w < 16; w++) { const double t = lds[w][c]; all += t; if (w < wave) before += t; }
+        for (int w = 0; w < SOT / 64; w++) { const double t = lds[w][c]; all += t; if (w < wave) before += t; }
         run[c] = incl[c] - local[c] + before;
         if (tid == 0) totals[c] = all;
     }
@@ -202,9 +232,9 @@ __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, cons
             }
             const double eta = S[0], mi = own[0];
             Part p;
-            p.x = v.x[i]; p.y = v.y[i]; p.z = v.z[i]; p.vx = v.vx[i]; p.vy = v.vy[i]; p.vz = v.vz[i]; p.m = mi;
+            p.x = ldnt(v.x, i); p.y = ldnt(v.y, i); p.z = ldnt(v.z, i); p.vx = ldnt(v.vx, i); p.vy = ldnt(v.vy, i); p.vz = ldnt(v.vz, i); p.m = mi;
             p.beta = p.Rt = p.k1 = __builtin_nan("");
-            p.ta = v.ta ? v.ta[i] : __builtin_nan(""); p.te = v.te ? v.te[i] : __builtin_nan(""); p.ti = v.ti ? v.ti[i] : __builtin_nan("");
+            p.ta = v.ta ? ldnt(v.ta, i) : __builtin_nan(""); p.te = v.te ? ldnt(v.te, i) : __builtin_nan(""); p.ti = v.ti ? ldnt(v.ti, i) : __builtin_nan("");
             if constexpr (KIND == SCAN_GR) {
                 if (i >= first_acting) {
                     const double ei = 1. / eta;
@@ -230,8 +260,8 @@ __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, cons
                     w[0] = f * a.x; w[1] = f * a.y; w[2] = f * a.z;
                 }
             }
-            ajx[i] = a.x; ajy[i] = a.y; ajz[i] = a.z;
-            wx[i] = w[0]; wy[i] = w[1]; wz[i] = w[2];
+            __builtin_nontemporal_store(a.x, ajx + i); __builtin_nontemporal_store(a.y, ajy + i); __builtin_nontemporal_store(a.z, ajz + i);
+            __builtin_nontemporal_store(w[0], wx + i); __builtin_nontemporal_store(w[1], wy + i); __builtin_nontemporal_store(w[2], wz + i);
             wacc[0] += w[0]; wacc[1] += w[1]; wacc[2] += w[2];
         }
 #pragma unroll
@@ -252,7 +282,7 @@ __global__ __launch_bounds__(SB) void scan_apply(View v, const double* ajx, cons
         const long long i = (long long)blockIdx.x * SCHUNK + t * SB + threadIdx.x;
         const bool live = i < v.n;
         double w[3] = {0., 0., 0.}, wt[3] = {0., 0., 0.};
-        if (live && !TOTAL) { w[0] = wx[i]; w[1] = wy[i]; w[2] = wz[i]; }
+        if (live && !TOTAL) { w[0] = ldnt(wx, i); w[1] = ldnt(wy, i); w[2] = ldnt(wz, i); }
         if (!TOTAL) block_scan<3, true>(w, wt, lds3);
         if (live) {
             double s0, s1, s2;
@@ -263,7 +293,7 @@ __global__ __launch_bounds__(SB) void scan_apply(View v, const double* ajx, cons
                 s2 = w[2] + carry[2] + wsums_excl[(long long)blockIdx.x * 3 + 2];
                 if (suf != nullptr) { s0 += suf[0]; s1 += suf[1]; s2 += suf[2]; }     // bodies that follow this view
             }
-            v.ax[i] += ajx[i] - s0; v.ay[i] += ajy[i] - s1; v.az[i] += ajz[i] - s2;
+            v.ax[i] += ldnt(ajx, i) - s0; v.ay[i] += ldnt(ajy, i) - s1; v.az[i] += ldnt(ajz, i) - s2;
         }
         carry[0] += wt[0]; carry[1] += wt[1]; carry[2] += wt[2];
     }
@@ -488,21 +518,21 @@ hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, 
     if (op.kind == REBXAMD_OP_MOF) kind = (op.iarg == REBX_COORDINATES_BARYCENTRIC) ? SCAN_MOF_BARY : SCAN_MOF_JACOBI;
     if (kind == SCAN_GR) {
         hipLaunchKernelGGL(massive_flag_totals, g, b, 0, st, v, fl);
-        hipLaunchKernelGGL((scan_of_totals<1, false>), dim3(1), dim3(1024), 0, st, fl, nb, count);
+        hipLaunchKernelGGL((scan_of_totals<1, false>), dim3(1), dim3(SOT), 0, st, fl, nb, count);
         hipLaunchKernelGGL(massive_compact, g, b, 0, st, v, fl, cx, cy, cz, cgm, cidx, G);
         if (exact) hipLaunchKernelGGL(newton_from_compact<true>, g, b, 0, st, v, cx, cy, cz, cgm, cidx, count, nax, nay, naz);
         else hipLaunchKernelGGL(newton_from_compact<false>, g, b, 0, st, v, cx, cy, cz, cgm, cidx, count, nax, nay, naz);
         hipLaunchKernelGGL(scan_block_totals<10>, gs, b, 0, st, v, nax, nay, naz, bs);
-        hipLaunchKernelGGL((scan_of_totals<10, false>), dim3(1), dim3(1024), 0, st, bs, nbs, totals);
+        hipLaunchKernelGGL((scan_of_totals<10, false>), dim3(1), dim3(SOT), 0, st, bs, nbs, totals);
         if (exact) hipLaunchKernelGGL((scan_main<SCAN_GR, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL, v.m);
         else hipLaunchKernelGGL((scan_main<SCAN_GR, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL, v.m);
     } else {
         hipLaunchKernelGGL(scan_block_totals<7>, gs, b, 0, st, v, nax, nay, naz, bs);
-        hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(1024), 0, st, bs, nbs, totals);
+        hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(SOT), 0, st, bs, nbs, totals);
         if (kind == SCAN_MOF_JACOBI) hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL, v.m);
         else hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL, v.m);
     }
-    hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(1), dim3(1024), 0, st, wsum, nbs, wtot);
+    hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(1), dim3(SOT), 0, st, wsum, nbs, wtot);
     if (kind == SCAN_MOF_BARY) hipLaunchKernelGGL(scan_apply<true>, gs, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, wsum, wtot, (const double*)nullptr);
     else hipLaunchKernelGGL(scan_apply<false>, gs, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, wsum, wtot, (const double*)nullptr);
     return hipGetLastError();
@@ -525,7 +555,7 @@ hipError_t launch_range_sums(const View& v, double* ws, double* sums7, hipStream
     const long long nb = blocks_of(v.n);
     double* bs = ws + 6 * v.n;
     hipLaunchKernelGGL(scan_block_totals<7>, dim3((unsigned)nb), dim3(SB), 0, st, v, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, bs);
-    hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(1024), 0, st, bs, nb, sums7);
+    hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(SOT), 0, st, bs, nb, sums7);
     return hipGetLastError();
 }
 
@@ -542,14 +572,14 @@ hipError_t launch_range_mof_forces(const View& v, const DevOp& op, double G, boo
     const dim3 g((unsigned)nb), b(SB);
     const double* none = nullptr;
     hipLaunchKernelGGL(scan_block_totals<7>, g, b, 0, st, v, none, none, none, bs);
-    hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(1024), 0, st, bs, nb, scratch);
+    hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(SOT), 0, st, bs, nb, scratch);
     if (barycentric)
         hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), g, b, 0, st, v, op, G, none, none, none, (const double*)bs, before7, ajx, ajy, ajz, wx, wy, wz, wsum,
                            (unsigned*)nullptr, none, 0LL, v.m);
     else
         hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), g, b, 0, st, v, op, G, none, none, none, (const double*)bs, (const double*)scratch, ajx, ajy, ajz, wx, wy, wz, wsum,
                            (unsigned*)nullptr, before7, starts_at_origin ? 1LL : 0LL, v.m);
-    hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(1), dim3(1024), 0, st, wsum, nb, push3);
+    hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(1), dim3(SOT), 0, st, wsum, nb, push3);
     return hipGetLastError();
 }
 
@@ -584,7 +614,7 @@ hipError_t launch_range_massive(const View& v, double G, double id0, double* ws,
     const GrRange r = gr_range(ws, v.n);
     const long long nb = (v.n + SB - 1) / SB;
     hipLaunchKernelGGL(massive_flag_totals, dim3((unsigned)nb), dim3(SB), 0, st, v, r.fl);
-    hipLaunchKernelGGL((scan_of_totals<1, false>), dim3(1), dim3(1024), 0, st, r.fl, nb, count);
+    hipLaunchKernelGGL((scan_of_totals<1, false>), dim3(1), dim3(SOT), 0, st, r.fl, nb, count);
     hipLaunchKernelGGL(massive_records, dim3((unsigned)nb), dim3(SB), 0, st, v, (const double*)r.fl, rec, G, id0);
     return hipGetLastError();
 }
@@ -599,7 +629,7 @@ hipError_t launch_range_gr_newton(const View& v, const double* rec, long long M,
     else hipLaunchKernelGGL(newton_from_records<false>, g, b, 0, st, v, rec, M, id0, r.nax, r.nay, r.naz);
     const long long nb = blocks_of(v.n);
     hipLaunchKernelGGL(scan_block_totals<10>, dim3((unsigned)nb), b, 0, st, v, (const double*)r.nax, (const double*)r.nay, (const double*)r.naz, r.bs);
-    hipLaunchKernelGGL((scan_of_totals<10, false>), dim3(1), dim3(1024), 0, st, r.bs, nb, sums10);
+    hipLaunchKernelGGL((scan_of_totals<10, false>), dim3(1), dim3(SOT), 0, st, r.bs, nb, sums10);
     return hipGetLastError();
 }
 
@@ -618,7 +648,7 @@ hipError_t launch_range_gr_forces(const View& v, const DevOp& op, double G, bool
                                   (const double*)r.scratch, r.ajx, r.ajy, r.ajz, r.wx, r.wy, r.wz, r.wsum, status, before10, first, m0);
     else hipLaunchKernelGGL((scan_main<SCAN_GR, false>), g, b, 0, st, v, op, G, (const double*)r.nax, (const double*)r.nay, (const double*)r.naz, (const double*)r.bs,
                             (const double*)r.scratch, r.ajx, r.ajy, r.ajz, r.wx, r.wy, r.wz, r.wsum, status, before10, first, m0);
-    hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(1), dim3(1024), 0, st, r.wsum, nb, push3);
+    hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(1), dim3(SOT), 0, st, r.wsum, nb, push3);
     return hipGetLastError();
 }
 
@@ -647,13 +677,13 @@ hipError_t launch_gr_hamiltonian(const View& v, double G, double c, double* ws, 
     const long long nbs = (n + SCHUNK - 1) / SCHUNK;
     const dim3 g((unsigned)nb), gs((unsigned)nbs), b(SB);
     hipLaunchKernelGGL(massive_flag_totals, g, b, 0, st, v, fl);
-    hipLaunchKernelGGL((scan_of_totals<1, false>), dim3(1), dim3(1024), 0, st, fl, nb, count);
+    hipLaunchKernelGGL((scan_of_totals<1, false>), dim3(1), dim3(SOT), 0, st, fl, nb, count);
     hipLaunchKernelGGL(massive_compact, g, b, 0, st, v, fl, cx, cy, cz, cgm, cidx, G);
     hipLaunchKernelGGL(newton_pot_from_compact, g, b, 0, st, v, cx, cy, cz, cgm, cidx, count, pot);
     hipLaunchKernelGGL(scan_block_totals<7>, gs, b, 0, st, v, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, bs);
-    hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(1024), 0, st, bs, nbs, totals);
+    hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(SOT), 0, st, bs, nbs, totals);
     hipLaunchKernelGGL(gr_hamiltonian_main, gs, b, 0, st, v, G, c * c, pot, bs, totals, part);
-    hipLaunchKernelGGL((scan_of_totals<3, false>), dim3(1), dim3(1024), 0, st, part, nbs, out);
+    hipLaunchKernelGGL((scan_of_totals<3, false>), dim3(1), dim3(SOT), 0, st, part, nbs, out);
     return hipGetLastError();
 }
 
