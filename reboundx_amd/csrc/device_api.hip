@@ -326,6 +326,25 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
             return fail(ctx, REBXAMD_ERR_UNSUPPORTED, "gr and Jacobi/barycentric modify_orbits_forces on particle shards that hold massive bodies run through the rebxamd_shard_* entry points");
         const int rcw = ensure(ctx, &ctx->scan, &ctx->scan_cap, scan_workspace_doubles(v.n) * sizeof(double), st);
         if (rcw != REBXAMD_OK) return rcw;
+        if (!exact) {
+            // default arithmetic: the streaming ops run as ONE pass ahead of the prefix-sum ops (one
+            // pass over the particles less when a prefix-sum op sits in the middle of the stack; the
+            // order in which the terms reach a_i changes, which the rounding-level bar of this mode covers)
+            rebxamd_op rest[REBXAMD_MAX_OPS];
+            int nrest = 0;
+            for (int k = lo; k < hi; k++)
+                if (k - lo != prog.gr_op && k - lo != prog.mofcom_op) rest[nrest++] = ops[k];
+            if (nrest > 0) {
+                const int rc = run_streaming(ctx, u, rest, 0, nrest, mode, st);
+                if (rc != REBXAMD_OK) return rc;
+            }
+            for (int k = lo; k < hi; k++) {
+                if (k - lo != prog.gr_op && k - lo != prog.mofcom_op) continue;
+                TimedLaunch tl(ctx, st);
+                HIP_TRY(launch_scan_op(v, prog.ops[k - lo], prog.G, exact, ctx->scan, ctx->status, st));
+            }
+            return REBXAMD_OK;
+        }
         int a = lo;
         for (int k = lo; k <= hi; k++) {
             const bool scan = k < hi && (k - lo == prog.gr_op || k - lo == prog.mofcom_op);

@@ -865,6 +865,7 @@ static void launch_stream_cols(dim3 g, dim3 b, hipStream_t st, bool vec2, bool f
         FIXED(REBXAMD_OP_MOF)
     } else {
         FIXED(REBXAMD_OP_TIDES, REBXAMD_OP_MOF, REBXAMD_OP_GR_POTENTIAL)
+        FIXED(REBXAMD_OP_TIDES, REBXAMD_OP_GR_POTENTIAL)
         FIXED(REBXAMD_OP_J2, REBXAMD_OP_J4)
         FIXED(REBXAMD_OP_GR_POTENTIAL)
         FIXED(REBXAMD_OP_TIDES)

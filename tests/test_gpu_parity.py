@@ -98,7 +98,8 @@ C5_STACK = [("radiation_forces", {"c": C}), ("gravitational_harmonics", {}), ("g
             ("tides_precession", {}), ("modify_orbits_forces", {"coordinates": 2})]
 FIXED_STACKS = [C2_STACK, C5_STACK, [("radiation_forces", {"c": C})], [("gravitational_harmonics", {})], [("gr", {"c": C})],
                 [("gr_potential", {"c": C})], [("tides_precession", {})], [("modify_orbits_forces", {"coordinates": 2})],
-                [("tides_precession", {}), ("modify_orbits_forces", {"coordinates": 2}), ("gr_potential", {"c": C})]]
+                [("tides_precession", {}), ("modify_orbits_forces", {"coordinates": 2}), ("gr_potential", {"c": C})],
+                [("tides_precession", {}), ("gr_potential", {"c": C})]]
 
 
 @pytest.mark.parametrize("mode", [EXACT, FAST])
