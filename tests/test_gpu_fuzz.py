@@ -1,0 +1,96 @@
+"""Randomised parity sweep of the streaming forces on the GPU against the CPU checker: random
+stacks, mass layouts, unset parameters, extra sources and incoming accelerations, both
+arithmetic modes and both kernel selections (instances built for a stack / walking the op
+list).  Seeds are fixed: every run tests the same cases.
+
+Bar: 1e-12 of the size of the particle's update vector (plus, for massive bodies, the size of
+the pushes they collect from the others, which arrive as parallel sums); stacks that go through
+the prefix-sum passes (gr or Jacobi/barycentric modify_orbits_forces with massive bodies beyond
+the head) get the allowance of those passes, n/1e4."""
+import numpy as np
+import pytest
+
+from gpu_common import TOL, run_device, run_oracle
+from reboundx_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+C = synthetic.C_DEFAULT
+FORCES = [("radiation_forces", {"c": C}), ("gravitational_harmonics", {}), ("gr", {"c": C}), ("gr", {"c": 200.0, "max_iterations": 5}),
+          ("gr_potential", {"c": C}), ("central_force", {}), ("tides_precession", {}), ("modify_orbits_forces", {}),
+          ("modify_orbits_forces", {"coordinates": 1}), ("modify_orbits_forces", {"coordinates": 2})]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from reboundx_amd.device import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def random_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([2, 3, 7, 130, 1025, 4100, 9001]))
+    planets = int(rng.integers(0, min(5, n - 1) + 1))
+    layout = rng.choice(["massless-tail", "all-massive", "scattered"])
+    dust = {"massless-tail": 0.0, "all-massive": 10.0 ** rng.uniform(-14, -9), "scattered": 0.0}[layout]
+    cols, pp, _ = synthetic.disk(n, planets, seed=int(rng.integers(1, 100)), dust_mass=dust)
+    h = 1 + planets
+    if layout == "scattered" and n > h + 2:
+        for i in rng.choice(np.arange(h, n), size=min(4, n - h), replace=False):
+            cols["m"][i] = 10.0 ** rng.uniform(-8, -4)
+    # unset parameters here and there
+    for key in ("beta", "tau_a", "tau_e", "tau_inc", "R_tides", "k1"):
+        if key in pp and n > 4 and rng.random() < 0.6:
+            pp[key] = pp[key].copy()
+            pp[key][rng.choice(np.arange(1, n), size=max(1, n // 7), replace=False)] = np.nan
+    pp["primary"] = np.zeros(n, dtype=np.uint8)
+    pp["primary"][int(rng.integers(0, h))] = 1
+    pp["Acentral"] = np.full(n, np.nan); pp["gammacentral"] = np.full(n, np.nan)
+    pp["Acentral"][0], pp["gammacentral"][0] = 1e-4, float(rng.choice([-1.0, -2.0, 0.5]))
+    if planets >= 1 and rng.random() < 0.5:                # a second oblate body / radiation source / tidal primary in the head
+        for key, val in (("J2", 2e-3), ("J4", -1e-4), ("R_eq", 2e-3)):
+            pp[key] = pp[key].copy(); pp[key][1] = val
+        pp["radiation_source"] = np.zeros(n, dtype=np.uint8); pp["radiation_source"][[0, 1]] = 1
+    if rng.random() < 0.5:
+        synthetic.add_newtonian(cols, n_head=h)
+    k = int(rng.integers(1, 6))
+    picks = sorted(rng.choice(len(FORCES), size=k, replace=False))
+    stack, seen_gr, seen_com = [], False, False
+    for j in rng.permutation(picks):
+        name, ep = FORCES[j]
+        com = name == "modify_orbits_forces" and ep.get("coordinates", 0) in (0, 1)
+        if (name == "gr" and seen_gr) or (com and seen_com):
+            continue
+        seen_gr |= name == "gr"
+        seen_com |= com
+        stack.append((name, ep))
+    scan = layout != "massless-tail" and any(f[0] == "gr" or (f[0] == "modify_orbits_forces" and f[1].get("coordinates", 0) in (0, 1)) for f in stack)
+    return cols, pp, stack, n, scan
+
+
+@pytest.mark.parametrize("mode", [1, 0], ids=["exact", "fast"])
+@pytest.mark.parametrize("seed", range(150))
+def test_random_stack_layout_and_parameters(ctx, seed, mode):
+    cols, pp, stack, n, scan = random_case(seed)
+    ref = run_oracle(cols, pp, stack)
+    base = np.stack([cols["ax"], cols["ay"], cols["az"]])
+    upd = np.abs(ref - base).max(axis=0)
+    m = cols["m"]
+    # massive bodies collect pushes from the others: sum_j m_j |update_j| / m_i bounds their size
+    total = float((m * upd).sum())
+    react = np.where(m > 0, (total - m * upd) / np.where(m > 0, m, 1.0), 0.0)
+    # floor: the reference adds up to n terms one after the other into a_i (barycentric reactions, pushes
+    # on a source), each addition rounding at the size of a_i; a regrouped sum differs by ~sqrt(n) such roundings
+    den = np.maximum(upd + react, np.abs(ref).max(axis=0) * (4 + np.sqrt(n)) * np.finfo(float).eps / TOL)
+    den = np.where(den == 0.0, 1.0, den)
+    bar = TOL * (max(1.0, n / 1e4) if scan else 1.0) * (16 if any(f[0] == "central_force" for f in stack) else 1)
+    for fixed in (True, False):
+        try:
+            ctx.fixed_stacks(fixed)
+            got, _ = run_device(ctx, cols, pp, stack, 1.0, mode)
+        finally:
+            ctx.fixed_stacks(True)
+        assert np.isfinite(got).all(), (seed, stack)
+        err = np.abs(got - ref).max(axis=0) / den
+        assert err.max() <= bar, "seed %d stack %s: %.3e at particle %d (n=%d)" % (seed, [f[0] for f in stack], err.max(), int(err.argmax()), n)
