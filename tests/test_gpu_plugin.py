@@ -261,6 +261,55 @@ def test_larger_host_array_round_trip_and_timings():
     sim.free_particle_params()
 
 
+def test_parameter_lists_spread_over_a_large_array_are_flattened_by_several_host_threads():
+    """Above 1e5 particles the host side converts arrays and walks the parameter lists on several
+    threads, each over its own range of particles.  Parameters set on particles of every range, a
+    second radiation source and a second oblate body far from the first (found by different
+    threads, merged in index order) must give what the checker computes from the same columns."""
+    n = 160_000
+    cols, pp, _ = synthetic.disk(n, 1)
+    far = 150_001
+    cols["m"][far] = 3e-4
+    sim = Simulation()
+    arr = (Particle * n)()
+    view = np.frombuffer(arr, dtype=np.float64).reshape(n, 16)
+    for j, k in enumerate(("x", "y", "z", "vx", "vy", "vz", "ax", "ay", "az", "m")):
+        view[:, j] = cols[k]
+    sim._store = arr
+    sim._particles = ctypes.cast(arr, ctypes.POINTER(Particle))
+    sim.N = n
+    rebx = Extras(sim)
+    rebx.set_mode("exact")
+    f = rebx.load_force("radiation_forces"); f.params["c"] = C
+    rebx.add_force(f)
+    rebx.add_force(rebx.load_force("gravitational_harmonics"))
+    chosen = np.arange(5, n, 131)
+    beta = np.full(n, np.nan); beta[chosen] = pp["beta"][chosen]
+    J2 = np.full(n, np.nan); J4 = np.full(n, np.nan); Req = np.full(n, np.nan)
+    src = np.zeros(n, dtype=np.uint8)
+    for i in (0, far):
+        arr[i]._sim = ctypes.pointer(sim)
+        arr[i].params["radiation_source"] = 1
+        arr[i].params["J2"] = 1e-3 * (1 + i % 7); arr[i].params["R_eq"] = 1e-3
+        J2[i], Req[i], src[i] = 1e-3 * (1 + i % 7), 1e-3, 1
+    arr[far].params["J4"] = -2e-4; J4[far] = -2e-4
+    for i in chosen:
+        arr[i]._sim = ctypes.pointer(sim)
+        arr[i].params["beta"] = float(beta[i])
+    sim.call_additional_forces()
+    ref = oracle.Sim(cols)
+    oracle.apply_forces(ref, [("gravitational_harmonics", {}), ("radiation_forces", {"c": C})],
+                        {"beta": beta, "J2": J2, "J4": J4, "R_eq": Req, "radiation_source": src})
+    got = np.array([view[:, 6], view[:, 7], view[:, 8]])
+    want = np.array(ref.acc)
+    # the oblate bodies collect the pushes of every body with mass as parallel sums
+    massive = np.nonzero(cols["m"])[0]
+    rest = np.setdiff1d(np.arange(n), massive)
+    assert ulp_diff(got[:, rest], want[:, rest]).max() == 0
+    assert rel_err(got[:, massive], want[:, massive]).max() <= TOL
+    sim.free_particle_params()
+
+
 def test_gr_and_jacobi_drag_with_massive_bodies_anywhere_through_the_hook():
     """Planets behind massless particles (no massive prefix): the hook must still run gr and
     Jacobi-coordinate modify_orbits_forces on the device (prefix-sum path).  Tolerance: 1e-12
