@@ -498,7 +498,9 @@ int rebxamd_fixed_stacks(rebxamd_ctx* ctx, int on);
  * force stack one streaming run, the pass over the massless bodies carries the whole update:
  * rebxamd_wh_steps -- forces, kick and Kepler drift (their accelerations never go through memory;
  * the acceleration columns stay zero); rebxamd_integrate_force with the Euler, RK2 or RK4 scheme
- * -- every stage evaluated in registers, velocities and first-stage accelerations written.
+ * -- every stage evaluated in registers, velocities and first-stage accelerations written; with
+ * the implicit-midpoint scheme -- one pass per round (mean velocity, forces, new estimate, partial
+ * sums of the convergence test).
  * on = 0 makes this context run force passes and elementwise passes separately (default: 1).
  * Both compute the same expressions. */
 int rebxamd_carried_steps(rebxamd_ctx* ctx, int on);

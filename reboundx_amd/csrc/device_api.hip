@@ -499,22 +499,75 @@ extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* vie
     // per stage), and ONE pass over the massless bodies evaluates every stage of their update in
     // registers: they are read once and only their velocities and first-stage accelerations written.
     const long long K = view->n_head < n ? view->n_head : n;
-    bool carried = known && ctx->carried_steps && integrator != REBXAMD_INTEGRATOR_IMPLICIT_MIDPOINT && one_streaming_run(ops, nops) &&
+    bool carried = known && ctx->carried_steps && one_streaming_run(ops, nops) &&
                    view->tail_massless != 0 && K >= 1 && K <= REBXAMD_MAX_HEAD && K < n && view->m != nullptr;
     for (int k = 0; k < nops && carried; k++) {
         const bool com = ops[k].kind == REBXAMD_OP_MOF && ops[k].iarg != REBX_COORDINATES_PARTICLE;
         const int src = (ops[k].kind == REBXAMD_OP_GR || ops[k].kind == REBXAMD_OP_GR_POTENTIAL) ? 0 : ops[k].src;
         if (!com && (src < 0 || src >= K)) carried = false;
     }
-    if (!carried) {
+    if (!carried || integrator == REBXAMD_INTEGRATOR_IMPLICIT_MIDPOINT) {
         // integrate_force.c:46 -- the simulation's accelerations are cleared first, whatever the scheme
-        // (the carried pass overwrites those of the massless bodies, the prefix clears its own)
+        // (the carried pass of an explicit scheme overwrites those of the massless bodies, and the prefix
+        // clears its own; the implicit scheme leaves them cleared)
         rc = rebxamd_reset_accelerations(ctx, view, stream);
         if (rc != REBXAMD_OK || n == 0) return rc;
     }
     if (!known) return REBXAMD_OK;               // REBX_INTEGRATOR_NONE and unknown values do nothing (integrate_force.c:69-76)
 
     {
+        if (carried && integrator == REBXAMD_INTEGRATOR_IMPLICIT_MIDPOINT) {
+            // Implicit midpoint: per round, the prefix takes the separate passes (force pass at the
+            // averaged state, update + averaged state for the next round) and ONE pass over the massless
+            // bodies forms their averaged velocities, evaluates the stack and updates their estimate.
+            const int nb = stream_block_count(K, n, true);
+            const size_t stride = ((size_t)n + 1) & ~(size_t)1;
+            const size_t hs = ((size_t)K + 1) & ~(size_t)1;
+            rc = ensure(ctx, &ctx->integ, &ctx->integ_cap, (3 * stride + 6 * hs + 2 * (size_t)(nb + 1) + 2) * sizeof(double), st);
+            if (rc != REBXAMD_OK) return rc;
+            double* w = ctx->integ;
+            double* const fin[3] = {w, w + stride, w + 2 * stride};                  // estimate of the final velocities, every body
+            double* const hv[3] = {w + 3 * stride, w + 3 * stride + hs, w + 3 * stride + 2 * hs};          // prefix: averaged velocities
+            double* const ha[3] = {w + 3 * stride + 3 * hs, w + 3 * stride + 4 * hs, w + 3 * stride + 5 * hs};   // prefix: accelerations there
+            double* partials = w + 3 * stride + 6 * hs;                              // pair 0: the prefix; pairs 1..nb: the pass behind it
+            double* sums = partials + 2 * (size_t)(nb + 1);
+            const double* const cv3[3] = {view->vx, view->vy, view->vz};
+            double* const v3[3] = {const_cast<double*>(view->vx), const_cast<double*>(view->vy), const_cast<double*>(view->vz)};
+            for (int k = 0; k < 3; k++) {
+                HIP_TRY(hipMemcpyAsync(fin[k], cv3[k], (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(hv[k], cv3[k], (size_t)K * sizeof(double), hipMemcpyDeviceToDevice, st));
+            }
+            HIP_TRY(hipMemsetAsync(ha[0], 0, 3 * hs * sizeof(double), st));
+            rebxamd_view head = *view;
+            head.n = K; head.n_head = K;
+            head.vx = hv[0]; head.vy = hv[1]; head.vz = hv[2]; head.ax = ha[0]; head.ay = ha[1]; head.az = ha[2];
+            StepArgs sa = {0., 0., nullptr, EPI_IM, dt, 0., 0., {fin[0], fin[1], fin[2]}, partials + 2};
+            int it = 0;
+            for (it = 0; it < 10; it++) {
+                ctx->hc_stage = 0;
+                rc = rebxamd_apply(ctx, &head, ops, nops, mode, stream);                 // prefix forces + head table at the averaged state
+                if (rc != REBXAMD_OK) return rc;
+                rc = run_streaming(ctx, view, ops, 0, nops, mode, st, -1, nullptr, false, &sa);
+                if (rc != REBXAMD_OK) return rc == STEP_NOT_CARRIED ? fail(ctx, REBXAMD_ERR_ARG, "rebxamd_integrate_force: layout changed between passes") : rc;
+                HIP_TRY(launch_im_update(fin, cv3, hv, ha, dt, K, partials, nullptr, exact, st));
+                HIP_TRY(launch_im_sum(partials, nb + 1, sums, st));
+                double h[2] = {0., 0.};
+                HIP_TRY(hipMemcpyAsync(h, sums, sizeof(h), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                if (h[0] / h[1] < 2.220446049250313e-16 * 2.220446049250313e-16) break;   // compare(), :57
+            }
+            if (it == 10) {
+                unsigned cur = 0;
+                HIP_TRY(hipMemcpyAsync(&cur, ctx->status, sizeof(cur), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                cur |= WARN_IM_ITER;
+                HIP_TRY(hipMemcpyAsync(ctx->status, &cur, sizeof(cur), hipMemcpyHostToDevice, st));
+                HIP_TRY(hipStreamSynchronize(st));
+            }
+            for (int k = 0; k < 3; k++) HIP_TRY(hipMemcpyAsync(v3[k], fin[k], (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+            if (iterations) *iterations = it;
+            return REBXAMD_OK;
+        }
         if (carried) {
             rebxamd_view head = *view;
             head.n = K; head.n_head = K;
@@ -524,7 +577,7 @@ extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* vie
             ctx->carried_steps = saved;
             ctx->hc_stage = 0;
             if (rc != REBXAMD_OK) return rc;
-            StepArgs sa = {0., 0., nullptr, EPI_EULER, dt, 0., 0.};
+            StepArgs sa = {0., 0., nullptr, EPI_EULER, dt, 0., 0., {nullptr, nullptr, nullptr}, nullptr};
             if (integrator == REBXAMD_INTEGRATOR_RK2) { sa.epi = EPI_RK2; sa.c0 = 2. * dt / 3.; sa.c1 = dt / 4.; sa.c2 = 3. * dt / 4.; }
             if (integrator == REBXAMD_INTEGRATOR_RK4) { sa.epi = EPI_RK4; sa.c0 = dt / 2.; sa.c1 = dt; sa.c2 = dt / 6.; }
             rc = run_streaming(ctx, view, ops, 0, nops, mode, st, -1, nullptr, false, &sa);
@@ -664,7 +717,7 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
     for (int64_t k = 0; k < nsteps; k++) {
         const double h = k + 1 < nsteps ? dt : 0.5 * dt;
         if (carried) {
-            const StepArgs sa = {h, dt, ctx->star, EPI_WH, 0., 0., 0.};
+            const StepArgs sa = {h, dt, ctx->star, EPI_WH, 0., 0., 0., {nullptr, nullptr, nullptr}, nullptr};
             rc = run_streaming(ctx, view, ops, 0, nops, mode, st, -1, nullptr, false, &sa);
             if (rc == REBXAMD_OK) continue;
             if (rc != STEP_NOT_CARRIED) return rc;

@@ -70,8 +70,13 @@ struct HeadConsts {
 //             (tab[0], tab[1], ...); the new velocities and the first-stage accelerations are written.
 //             c0, c1, c2: Euler dt; RK2 2dt/3, dt/4, 3dt/4; RK4 dt/2, dt, dt/6 (formed on the host
 //             exactly as the separate passes form them).
-enum { EPI_NONE = 0, EPI_WH = 1, EPI_EULER = 2, EPI_RK2 = 3, EPI_RK4 = 4 };
-struct StepArgs { double h, dtk; const double* star; int epi; double c0, c1, c2; };
+//   EPI_IM    one round of the implicit-midpoint iteration (src/integrator_implicit_midpoint.c:83-124):
+//             the stack is evaluated at the mean of the velocity columns and of the current estimate
+//             of the final velocities (aux), the new estimate orig + c0*a replaces the old one, and
+//             the squared change and squared size (compare(), :47-62) are left as one pair of partial
+//             sums per workgroup in `partials`.  Velocity and acceleration columns are not written.
+enum { EPI_NONE = 0, EPI_WH = 1, EPI_EULER = 2, EPI_RK2 = 3, EPI_RK4 = 4, EPI_IM = 5 };
+struct StepArgs { double h, dtk; const double* star; int epi; double c0, c1, c2; double* aux[3]; double* partials; };
 
 enum { WARN_GR_ITER = 1u, WARN_GRFULL_SWEEPS = 2u, WARN_IM_ITER = 4u };
 
@@ -116,6 +121,7 @@ hipError_t launch_wh_drift(double* const x[3], double* const v[3], double* const
 long long im_partial_count(long long n);
 hipError_t launch_im_update(double* const fin[3], const double* const orig[3], double* const avgv[3], double* const avga[3], double dt,
                             long long n, double* partials, double* sums, bool exact, hipStream_t st);
+hipError_t launch_im_sum(const double* partials, long long nb, double* sums, hipStream_t st);
 
 // operators modify_mass and modify_orbits_direct (operator_kernels.hip)
 long long operator_partial_doubles(long long n);

@@ -194,7 +194,13 @@ hipError_t launch_im_update(double* const fin[3], const double* const orig[3], d
     const CCols3 o = {orig[0], orig[1], orig[2]};
     if (exact) hipLaunchKernelGGL(im_update_kernel<true>, grid_for(n), dim3(TB), 0, st, f, o, av, aa, dt, n, partials);
     else hipLaunchKernelGGL(im_update_kernel<false>, grid_for(n), dim3(TB), 0, st, f, o, av, aa, dt, n, partials);
-    hipLaunchKernelGGL(im_sum_kernel, dim3(1), dim3(1024), 0, st, partials, im_partial_count(n), sums);
+    if (sums != nullptr) hipLaunchKernelGGL(im_sum_kernel, dim3(1), dim3(1024), 0, st, partials, im_partial_count(n), sums);
+    return hipGetLastError();
+}
+
+// sums[0..1] <- fixed-order sums of nb (squared change, squared size) pairs
+hipError_t launch_im_sum(const double* partials, long long nb, double* sums, hipStream_t st) {
+    hipLaunchKernelGGL(im_sum_kernel, dim3(1), dim3(1024), 0, st, partials, nb, sums);
     return hipGetLastError();
 }
 

@@ -628,6 +628,24 @@ __global__ __launch_bounds__(BLOCK, (!EXACT && !BACKREACT && COLS != COL_ALL) ? 
         }
     }
 
+    double orig[2][3], fin[2][3];           // implicit midpoint: velocities at the start of the step, current estimate of the final ones
+    if (EPI == EPI_IM) {
+        if (full) {
+            ldpair(step.aux[0], i0, fin[0][0], fin[1][0]); ldpair(step.aux[1], i0, fin[0][1], fin[1][1]); ldpair(step.aux[2], i0, fin[0][2], fin[1][2]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                fin[k][0] = fin[k][1] = fin[k][2] = 0.;
+                if (k ? act1 : act0) { fin[k][0] = step.aux[0][i0 + k]; fin[k][1] = step.aux[1][i0 + k]; fin[k][2] = step.aux[2][i0 + k]; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            orig[k][0] = p[k].vx; orig[k][1] = p[k].vy; orig[k][2] = p[k].vz;
+            p[k].vx = 0.5 * (orig[k][0] + fin[k][0]); p[k].vy = 0.5 * (orig[k][1] + fin[k][1]); p[k].vz = 0.5 * (orig[k][2] + fin[k][2]);
+        }
+    }
+
     if (!BACKREACT) {
         // one particle after the other keeps the live register set small
         if (act0) tail_particle<EXACT, SIG>(prog, tab, p[0], acc[0], status);
@@ -654,7 +672,43 @@ __global__ __launch_bounds__(BLOCK, (!EXACT && !BACKREACT && COLS != COL_ALL) ? 
         }
     }
 
-    if (EPI >= EPI_EULER) {
+    if (EPI == EPI_IM) {
+        __shared__ double red[2][WAVES];
+        double d2 = 0., t2 = 0.;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (!(k ? act1 : act0)) continue;
+            const double fx = axpy1<EXACT>(orig[k][0], step.c0, acc[k].x), fy = axpy1<EXACT>(orig[k][1], step.c0, acc[k].y), fz = axpy1<EXACT>(orig[k][2], step.c0, acc[k].z);
+            const double dx = fx - fin[k][0], dy = fy - fin[k][1], dz = fz - fin[k][2];
+            d2 += dx * dx + dy * dy + dz * dz;
+            t2 += fx * fx + fy * fy + fz * fz;
+            fin[k][0] = fx; fin[k][1] = fy; fin[k][2] = fz;
+        }
+        if (full) {
+            d2v t;
+            t.x = fin[0][0]; t.y = fin[1][0]; *reinterpret_cast<d2v*>(step.aux[0] + i0) = t;
+            t.x = fin[0][1]; t.y = fin[1][1]; *reinterpret_cast<d2v*>(step.aux[1] + i0) = t;
+            t.x = fin[0][2]; t.y = fin[1][2]; *reinterpret_cast<d2v*>(step.aux[2] + i0) = t;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                if (!(k ? act1 : act0)) continue;
+                step.aux[0][i0 + k] = fin[k][0]; step.aux[1][i0 + k] = fin[k][1]; step.aux[2][i0 + k] = fin[k][2];
+            }
+        }
+        d2 = wave_sum(d2); t2 = wave_sum(t2);
+        if ((tid & 63) == 0) { red[0][tid >> 6] = d2; red[1][tid >> 6] = t2; }
+        __syncthreads();
+        if (tid == 0) {
+            double a = 0., b = 0.;
+#pragma unroll
+            for (int w = 0; w < WAVES; w++) { a += red[0][w]; b += red[1][w]; }
+            step.partials[2 * (long long)blockIdx.x] = a;
+            step.partials[2 * (long long)blockIdx.x + 1] = b;
+        }
+        return;
+    }
+    if (EPI >= EPI_EULER && EPI <= EPI_RK4) {
         double* const pvx = const_cast<double*>(v.vx); double* const pvy = const_cast<double*>(v.vy); double* const pvz = const_cast<double*>(v.vz);
         if (act0) integrate_tail<EXACT, SIG, EPI>(prog, tab, p[0], acc[0], step, status);
         if (act1) integrate_tail<EXACT, SIG, EPI>(prog, tab, p[1], acc[1], step, status);
@@ -822,7 +876,7 @@ hipError_t launch_head(const View& v, const Program& prog, HeadConsts* hc, unsig
 template <bool EXACT, bool BACKREACT>
 static void launch_stream_cols(dim3 g, dim3 b, hipStream_t st, bool vec2, bool fixed, int cols, const View& v, const Program& prog, long long lo,
                                long long base, const HeadConsts* hc, double* partials, unsigned* status, const StepArgs* step) {
-    const StepArgs sa = step ? *step : StepArgs{0., 0., nullptr, EPI_NONE, 0., 0., 0.};
+    const StepArgs sa = step ? *step : StepArgs{0., 0., nullptr, EPI_NONE, 0., 0., 0., {nullptr, nullptr, nullptr}, nullptr};
     Sig sig = 0ull;
     if (fixed && vec2 && prog.nops <= 8) for (int o = 0; o < prog.nops; o++) sig |= (Sig)(prog.ops[o].kind & 15) << (4 * o);
     if (step) {
@@ -842,6 +896,7 @@ static void launch_stream_cols(dim3 g, dim3 b, hipStream_t st, bool vec2, bool f
             case EPI_EULER: EPILOGUE(EPI_EULER)
             case EPI_RK2: EPILOGUE(EPI_RK2)
             case EPI_RK4: EPILOGUE(EPI_RK4)
+            case EPI_IM: EPILOGUE(EPI_IM)
             default: break;
             }
 #undef FIXED_EPI

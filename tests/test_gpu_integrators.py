@@ -82,26 +82,30 @@ MIXED_STACK = [("modify_orbits_forces", {"coordinates": 1}), ("radiation_forces"
 
 
 @pytest.mark.parametrize("mode", [EXACT, FAST])
-@pytest.mark.parametrize("integrator", ["euler", "rk2", "rk4"])
+@pytest.mark.parametrize("integrator", ["euler", "rk2", "rk4", "implicit_midpoint"])
 @pytest.mark.parametrize("forces", [C5_STACK, C2_STACK, MIXED_STACK], ids=["five-effects", "rad+harmonics+gr", "walked-op-list"])
 @pytest.mark.parametrize("n,planets", [(2, 0), (5, 1), (4099, 2), (6002, 3)])
 def test_update_carried_by_one_pass_equals_separate_passes(ctx, n, planets, forces, integrator, mode):
     """With massless bodies behind a short massive prefix, one pass over them evaluates every
     stage of the scheme in registers (the prefix runs the separate passes, one head table per
     stage).  Switched off, every stage is a force pass plus an elementwise pass.  Same
-    expressions: bit-equal velocities and left-over accelerations in reference-order arithmetic."""
+    expressions: bit-equal velocities and left-over accelerations in reference-order arithmetic.
+    The implicit scheme is carried round by round (same number of rounds either way)."""
     cols, pp, _ = synthetic.disk(n, planets)
     ops = build_ops(forces, pp)
-    out = []
+    out, rounds = [], []
     for carried in (True, False):
         dp = device_state(cols, pp)
         try:
             ctx.carried_steps(carried)
-            ctx.integrate_force(dp.view(), ops, integrator, 0.01, mode)
+            rounds.append(ctx.integrate_force(dp.view(), ops, integrator, 0.01, mode))
         finally:
             ctx.carried_steps(True)
         out.append((vel(dp), np.array(dp.acc_host())))
     (v1, a1), (v2, a2) = out
+    assert rounds[0] == rounds[1]
+    if integrator == "implicit_midpoint":
+        assert 1 <= rounds[0] < 10 and not a1.any() and not a2.any()
     assert np.isfinite(v1).all() and np.isfinite(a1).all()
     if mode == EXACT:
         assert np.array_equal(v1, v2) and np.array_equal(a1, a2)
