@@ -91,6 +91,8 @@ struct Bridge {
     unsigned long long generation = 1;      // bumped by every API call that can change a parameter list
     // staging
     size_t cap = 0;
+    double* h_slab = nullptr;               // pinned host slab and device slab holding the columns below, `cap` apart
+    double* d_slab = nullptr;
     double* h_dyn[H_NDYN] = {};             // pinned host columns
     double* d_dyn[H_NDYN] = {};
     double* h_par[P_NPAR] = {};             // pageable host columns (rebuilt rarely)
@@ -129,11 +131,10 @@ void touch(const rebx_extras* rebx) {
 }
 
 void release_buffers(Bridge* b) {
-    for (int k = 0; k < H_NDYN; k++) {
-        if (b->h_dyn[k]) (void)hipHostFree(b->h_dyn[k]);
-        if (b->d_dyn[k]) (void)hipFree(b->d_dyn[k]);
-        b->h_dyn[k] = b->d_dyn[k] = nullptr;
-    }
+    if (b->h_slab) (void)hipHostFree(b->h_slab);
+    if (b->d_slab) (void)hipFree(b->d_slab);
+    b->h_slab = b->d_slab = nullptr;
+    for (int k = 0; k < H_NDYN; k++) b->h_dyn[k] = b->d_dyn[k] = nullptr;
     for (int k = 0; k < P_NPAR; k++) {
         free(b->h_par[k]);
         if (b->d_par[k]) (void)hipFree(b->d_par[k]);
@@ -177,6 +178,12 @@ int host_threads(int N) {
 }
 
 // fn(lo, hi, k) on nt contiguous chunks of [0, N); chunk k runs on its own thread
+// Systems this small move as one slab per direction and skip the synchronisations that only
+// separate the phases of rebxamd_last_timings (their enqueue times are reported instead: what
+// matters at this size is the latency of the call).
+// (Buffers that once held a large system keep their size: then the columns are copied one by one.)
+bool small_system(const Bridge* b, int N) { return N <= 16384 && b->cap <= 32768; }
+
 template <class Fn> void parallel_chunks(int N, int nt, Fn fn) {
     if (nt <= 1) { fn(0, N, 0); return; }
     std::vector<std::thread> pool;
@@ -613,15 +620,15 @@ bool ensure_capacity(struct rebx_extras* rebx, Bridge* b, size_t n) {
     }
     if (n <= b->cap) return true;
     release_buffers(b);
-    const size_t cap = n + n / 8 + 64;
-    for (int k = 0; k < H_NDYN; k++) {
-        if (hipHostMalloc((void**)&b->h_dyn[k], cap * sizeof(double), hipHostMallocDefault) != hipSuccess ||
-            hipMalloc((void**)&b->d_dyn[k], cap * sizeof(double)) != hipSuccess) {
-            rebx_error(rebx, "REBOUNDx (MI355X) Error: could not allocate staging buffers.\n");
-            release_buffers(b);
-            return false;
-        }
+    const size_t cap = (n + n / 8 + 64 + 1) & ~(size_t)1;       // even: every column stays 16-byte aligned
+    // one slab each side, so that small systems move in one copy per direction
+    if (hipHostMalloc((void**)&b->h_slab, H_NDYN * cap * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void**)&b->d_slab, H_NDYN * cap * sizeof(double)) != hipSuccess) {
+        rebx_error(rebx, "REBOUNDx (MI355X) Error: could not allocate staging buffers.\n");
+        release_buffers(b);
+        return false;
     }
+    for (int k = 0; k < H_NDYN; k++) { b->h_dyn[k] = b->h_slab + k * cap; b->d_dyn[k] = b->d_slab + k * cap; }
     for (int k = 0; k < P_NPAR; k++) {
         b->h_par[k] = (double*)malloc(cap * sizeof(double));
         if (!b->h_par[k] || hipMalloc((void**)&b->d_par[k], cap * sizeof(double)) != hipSuccess) {
@@ -786,13 +793,15 @@ bool stage_in(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* b, c
     hipStream_t st = nullptr;
     const size_t bytes = (size_t)N * sizeof(double);
     bool ok = true;
-    for (int k = 0; k < H_NDYN && ok; k++) ok = hipMemcpyAsync(b->d_dyn[k], b->h_dyn[k], bytes, hipMemcpyHostToDevice, st) == hipSuccess;
+    if (small_system(b, N)) ok = hipMemcpyAsync(b->d_slab, b->h_slab, H_NDYN * b->cap * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess;
+    else for (int k = 0; k < H_NDYN && ok; k++) ok = hipMemcpyAsync(b->d_dyn[k], b->h_dyn[k], bytes, hipMemcpyHostToDevice, st) == hipSuccess;
     if (rebuild) {
         for (int k = 0; k < P_NPAR && ok; k++)
             if (b->par_used[k]) ok = hipMemcpyAsync(b->d_par[k], b->h_par[k], bytes, hipMemcpyHostToDevice, st) == hipSuccess;
         b->built_generation = b->generation; b->built_n = N; b->built_checksum = sum;
     }
-    ok = ok && hipStreamSynchronize(st) == hipSuccess;
+    // (small systems: the copy is left queued ahead of the kernels; the wait is not worth its latency)
+    if (!small_system(b, N)) ok = ok && hipStreamSynchronize(st) == hipSuccess;
     t[2] = now_ms();
     if (!ok) { rebx_error(rebx, "REBOUNDx (MI355X) Error: host to device copy failed.\n"); return false; }
 
@@ -846,13 +855,15 @@ void run_builtin(struct reb_simulation* sim, struct rebx_extras* rebx, const std
         reb_error(sim, str);
         return;
     }
-    bool ok = hipStreamSynchronize(st) == hipSuccess;
+    bool ok = small_system(b, N) || hipStreamSynchronize(st) == hipSuccess;
     const double t3 = now_ms();
 
     // ---- device -> host, columns -> array-of-structs
     const size_t bytes = (size_t)N * sizeof(double);
     double* const* h = b->h_dyn;
-    for (int k = H_AX; k <= H_AZ && ok; k++) ok = hipMemcpyAsync(b->h_dyn[k], b->d_dyn[k], bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
+    static_assert(H_AY == H_AX + 1 && H_AZ == H_AX + 2, "the acceleration columns are neighbours in the slab");
+    if (small_system(b, N)) ok = hipMemcpyAsync(b->h_dyn[H_AX], b->d_dyn[H_AX], (2 * b->cap + (size_t)N) * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess;
+    else for (int k = H_AX; k <= H_AZ && ok; k++) ok = hipMemcpyAsync(b->h_dyn[k], b->d_dyn[k], bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
     uint32_t bits = 0;
     ok = ok && rebxamd_fetch_warnings(b->ctx, &bits, st) == REBXAMD_OK;     // synchronises the stream
     if (!ok) { rebx_error(rebx, "REBOUNDx (MI355X) Error: device to host copy failed.\n"); return; }
