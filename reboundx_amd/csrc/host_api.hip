@@ -108,6 +108,7 @@ struct Bridge {
     std::vector<SourceJ> j2, j4;
     std::vector<SourceC> central;
     double timings[4] = {0, 0, 0, 0};
+    std::vector<hipEvent_t> block_done;     // one per block of the download/unpack pipeline
 };
 
 std::mutex g_mu;
@@ -131,6 +132,8 @@ void touch(const rebx_extras* rebx) {
 }
 
 void release_buffers(Bridge* b) {
+    for (hipEvent_t e : b->block_done) (void)hipEventDestroy(e);
+    b->block_done.clear();
     if (b->h_slab) (void)hipHostFree(b->h_slab);
     if (b->d_slab) (void)hipFree(b->d_slab);
     b->h_slab = b->d_slab = nullptr;
@@ -178,6 +181,8 @@ int host_threads(int N) {
 }
 
 // fn(lo, hi, k) on nt contiguous chunks of [0, N); chunk k runs on its own thread
+constexpr int kPipelineBlock = 1 << 20;     // particles per block of the pack/upload and download/unpack pipelines
+
 // Systems this small move as one slab per direction and skip the synchronisations that only
 // separate the phases of rebxamd_last_timings (their enqueue times are reported instead: what
 // matters at this size is the latency of the call).
@@ -762,39 +767,52 @@ bool stage_in(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* b, c
     if (!ensure_capacity(rebx, b, (size_t)N)) return false;
     t[0] = now_ms();
     double* const* h = b->h_dyn;
-    const int nt = host_threads(N);
-    unsigned long long chunk_sum[64];
-    long long chunk_last[64];
-    parallel_chunks(N, nt, [&](int lo, int hi, int k) {
-        unsigned long long cs = 1469598103934665603ull;
-        long long lm = -1;
-        for (int i = lo; i < hi; i++) {
-            const struct reb_particle& p = particles[i];
-            h[H_X][i] = p.x; h[H_Y][i] = p.y; h[H_Z][i] = p.z;
-            h[H_VX][i] = p.vx; h[H_VY][i] = p.vy; h[H_VZ][i] = p.vz;
-            h[H_M][i] = p.m;
-            h[H_AX][i] = p.ax; h[H_AY][i] = p.ay; h[H_AZ][i] = p.az;
-            if (p.m != 0.) lm = i;
-            cs = (cs ^ (unsigned long long)(uintptr_t)p.ap) * 1099511628211ull;
-        }
-        chunk_sum[k] = cs; chunk_last[k] = lm;
-    });
-    // fold of the per-chunk folds, in chunk order: changes whenever any list head changes
-    unsigned long long sum = 1469598103934665603ull ^ (unsigned long long)nt;
+    hipStream_t st = nullptr;
+    bool ok = true;
+    // Large arrays go block by block: while the copy engine uploads one block of the columns, the host
+    // threads pack the next one.
+    const int block = small_system(b, N) ? N : kPipelineBlock;
+    unsigned long long sum = 1469598103934665603ull;
     long long last_massive = -1;
-    for (int k = 0; k < nt; k++) {
-        sum = (sum ^ chunk_sum[k]) * 1099511628211ull;
-        if (chunk_last[k] > last_massive) last_massive = chunk_last[k];
+    double pack_ms = 0.;
+    for (int b0 = 0; b0 < N; b0 += block) {
+        const int b1 = (N - b0 > block) ? b0 + block : N;
+        const double tp = now_ms();
+        const int nt = host_threads(b1 - b0);
+        unsigned long long chunk_sum[64];
+        long long chunk_last[64];
+        parallel_chunks(b1 - b0, nt, [&](int lo, int hi, int k) {
+            unsigned long long cs = 1469598103934665603ull;
+            long long lm = -1;
+            for (int i = b0 + lo; i < b0 + hi; i++) {
+                const struct reb_particle& p = particles[i];
+                h[H_X][i] = p.x; h[H_Y][i] = p.y; h[H_Z][i] = p.z;
+                h[H_VX][i] = p.vx; h[H_VY][i] = p.vy; h[H_VZ][i] = p.vz;
+                h[H_M][i] = p.m;
+                h[H_AX][i] = p.ax; h[H_AY][i] = p.ay; h[H_AZ][i] = p.az;
+                if (p.m != 0.) lm = i;
+                cs = (cs ^ (unsigned long long)(uintptr_t)p.ap) * 1099511628211ull;
+            }
+            chunk_sum[k] = cs; chunk_last[k] = lm;
+        });
+        // fold of the per-chunk folds, in order: changes whenever any list head changes
+        sum = (sum ^ (unsigned long long)nt) * 1099511628211ull;
+        for (int k = 0; k < nt; k++) {
+            sum = (sum ^ chunk_sum[k]) * 1099511628211ull;
+            if (chunk_last[k] > last_massive) last_massive = chunk_last[k];
+        }
+        pack_ms += now_ms() - tp;
+        if (small_system(b, N)) ok = hipMemcpyAsync(b->d_slab, b->h_slab, H_NDYN * b->cap * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess;
+        else for (int k = 0; k < H_NDYN && ok; k++)
+            ok = hipMemcpyAsync(b->d_dyn[k] + b0, b->h_dyn[k] + b0, (size_t)(b1 - b0) * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess;
     }
     const bool rebuild = b->built_generation != b->generation || b->built_n != N || b->built_checksum != sum;
+    const double tf = now_ms();
     if (rebuild) flatten_params(rebx, b, particles, N);
-    t[1] = now_ms();
+    pack_ms += now_ms() - tf;
+    t[1] = t[0] + pack_ms;              // time spent packing and flattening; the uploads ran underneath
 
-    hipStream_t st = nullptr;
     const size_t bytes = (size_t)N * sizeof(double);
-    bool ok = true;
-    if (small_system(b, N)) ok = hipMemcpyAsync(b->d_slab, b->h_slab, H_NDYN * b->cap * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess;
-    else for (int k = 0; k < H_NDYN && ok; k++) ok = hipMemcpyAsync(b->d_dyn[k], b->h_dyn[k], bytes, hipMemcpyHostToDevice, st) == hipSuccess;
     if (rebuild) {
         for (int k = 0; k < P_NPAR && ok; k++)
             if (b->par_used[k]) ok = hipMemcpyAsync(b->d_par[k], b->h_par[k], bytes, hipMemcpyHostToDevice, st) == hipSuccess;
@@ -859,17 +877,40 @@ void run_builtin(struct reb_simulation* sim, struct rebx_extras* rebx, const std
     const double t3 = now_ms();
 
     // ---- device -> host, columns -> array-of-structs
-    const size_t bytes = (size_t)N * sizeof(double);
     double* const* h = b->h_dyn;
     static_assert(H_AY == H_AX + 1 && H_AZ == H_AX + 2, "the acceleration columns are neighbours in the slab");
-    if (small_system(b, N)) ok = hipMemcpyAsync(b->h_dyn[H_AX], b->d_dyn[H_AX], (2 * b->cap + (size_t)N) * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess;
-    else for (int k = H_AX; k <= H_AZ && ok; k++) ok = hipMemcpyAsync(b->h_dyn[k], b->d_dyn[k], bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
     uint32_t bits = 0;
-    ok = ok && rebxamd_fetch_warnings(b->ctx, &bits, st) == REBXAMD_OK;     // synchronises the stream
-    if (!ok) { rebx_error(rebx, "REBOUNDx (MI355X) Error: device to host copy failed.\n"); return; }
-    parallel_chunks(N, host_threads(N), [&](int lo, int hi, int) {
-        for (int i = lo; i < hi; i++) { particles[i].ax = h[H_AX][i]; particles[i].ay = h[H_AY][i]; particles[i].az = h[H_AZ][i]; }
-    });
+    if (small_system(b, N)) {
+        ok = hipMemcpyAsync(b->h_dyn[H_AX], b->d_dyn[H_AX], (2 * b->cap + (size_t)N) * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess;
+        ok = ok && rebxamd_fetch_warnings(b->ctx, &bits, st) == REBXAMD_OK;     // synchronises the stream
+        if (!ok) { rebx_error(rebx, "REBOUNDx (MI355X) Error: device to host copy failed.\n"); return; }
+        for (int i = 0; i < N; i++) { particles[i].ax = h[H_AX][i]; particles[i].ay = h[H_AY][i]; particles[i].az = h[H_AZ][i]; }
+    } else {
+        // block by block: the host threads scatter one block into the array of structs while the copy
+        // engine downloads the next ones (one event per block marks its arrival)
+        const int nblocks = (N + kPipelineBlock - 1) / kPipelineBlock;
+        while ((int)b->block_done.size() < nblocks && ok) {
+            hipEvent_t e = nullptr;
+            ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+            if (ok) b->block_done.push_back(e);
+        }
+        for (int blk = 0; blk < nblocks && ok; blk++) {
+            const int b0 = blk * kPipelineBlock, b1 = (N - b0 > kPipelineBlock) ? b0 + kPipelineBlock : N;
+            for (int k = H_AX; k <= H_AZ && ok; k++)
+                ok = hipMemcpyAsync(b->h_dyn[k] + b0, b->d_dyn[k] + b0, (size_t)(b1 - b0) * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess;
+            ok = ok && hipEventRecord(b->block_done[blk], st) == hipSuccess;
+        }
+        for (int blk = 0; blk < nblocks && ok; blk++) {
+            const int b0 = blk * kPipelineBlock, b1 = (N - b0 > kPipelineBlock) ? b0 + kPipelineBlock : N;
+            ok = hipEventSynchronize(b->block_done[blk]) == hipSuccess;
+            if (!ok) break;
+            parallel_chunks(b1 - b0, host_threads(b1 - b0), [&](int lo, int hi, int) {
+                for (int i = b0 + lo; i < b0 + hi; i++) { particles[i].ax = h[H_AX][i]; particles[i].ay = h[H_AY][i]; particles[i].az = h[H_AZ][i]; }
+            });
+        }
+        ok = ok && rebxamd_fetch_warnings(b->ctx, &bits, st) == REBXAMD_OK;     // synchronises the stream
+        if (!ok) { rebx_error(rebx, "REBOUNDx (MI355X) Error: device to host copy failed.\n"); return; }
+    }
     const double t4 = now_ms();
     report_warnings(sim, bits);
     b->timings[0] = t[1] - t[0]; b->timings[1] = t[2] - t[1]; b->timings[2] = t3 - t[2]; b->timings[3] = t4 - t3;

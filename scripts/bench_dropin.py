@@ -39,5 +39,7 @@ for k in range(4):
     sim.call_additional_forces()
     wall = time.perf_counter() - t0
     t = rebx.last_timings()
-    print("call %d  n=%d  wall %8.2f ms | pack %7.2f  h2d %7.2f  kernels %6.3f  d2h+unpack %7.2f ms | %.3e evals/s end to end, %.2f GB/s over PCIe (80 B in, 24 B out per particle)" % (
-        k, n, wall * 1e3, t["pack_ms"], t["h2d_ms"], t["kernel_ms"], t["d2h_unpack_ms"], n / wall, 104 * n / ((t["h2d_ms"] + t["d2h_unpack_ms"]) * 1e-3) / 1e9), flush=True)
+    # pack and upload overlap block by block, as do download and unpack: "h2d" is what remains of the upload after
+    # the last block is packed
+    print("call %d  n=%d  wall %8.2f ms | pack %7.2f  h2d wait %7.2f  kernels %6.3f  d2h+unpack %7.2f ms | %.3e evals/s end to end (80 B in, 24 B out per particle)" % (
+        k, n, wall * 1e3, t["pack_ms"], t["h2d_ms"], t["kernel_ms"], t["d2h_unpack_ms"], n / wall), flush=True)
