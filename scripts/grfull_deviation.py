@@ -1,0 +1,22 @@
+"""Deviation of the default-arithmetic gr_full from the CPU checker on virialised clusters (development aid)."""
+import sys, numpy as np
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import oracle
+from reboundx_amd import synthetic
+from reboundx_amd.device import Context, DeviceParticles
+from gpu_common import rel_err
+ctx = Context(0)
+for n in (257, 700, 2000):
+    cl = synthetic.cluster(n)
+    s = oracle.Sim(cl); oracle.newtonian_gravity(s)
+    cl["ax"], cl["ay"], cl["az"] = [a.copy() for a in s.acc]
+    base = np.array(s.acc)
+    ref = oracle.Sim(cl); oracle.gr_full(ref, 1e2, 0)
+    dp = DeviceParticles.from_host(cl)
+    sw = ctx.grfull(dp.view(), 1e2, 0, 0)
+    got = np.array(dp.acc_host())
+    corr_ref = np.array(ref.acc) - base
+    corr_got = got - base
+    print(n, "max rel err of the correction", rel_err(corr_got, corr_ref).max(), "of the full acceleration", rel_err(got, np.array(ref.acc)).max())
