@@ -150,6 +150,35 @@ def c5_section(ctx, n, steps, mode, device):
                          "frac": bytes_per_step / queued / 1e9 / HBM_PEAK_GBS}}
 
 
+def c3_section(ctx, n, mode, device):
+    """Secondary metric (BASELINE config 3 on this GPU's share): tides_precession + modify_orbits_forces +
+    gr_potential with every grain massive, so the pushes on the star are parallel reductions; PARTICLE
+    coordinates (one streaming pass) and the reference's default Jacobi coordinates (prefix-sum passes)."""
+    cols, pp, _ = synthetic.disk(n, 0, dust_mass=1e-15)
+    pp["primary"] = np.zeros(n, dtype=np.uint8)
+    pp["primary"][0] = 1
+    host = dict(cols)
+    for k in ("R_tides", "k1", "tau_a", "tau_e", "tau_inc"):
+        host[k] = pp[k]
+    dp = DeviceParticles.from_host(host, device=device, n_head=1, tail_massless=False)
+    view = dp.view()
+    out = {"n": n, "bytes_per_eval": 144}
+    for label, coords in (("particle", 2), ("jacobi", 0)):
+        stack = [("tides_precession", {}), ("modify_orbits_forces", {"coordinates": coords}), ("gr_potential", {"c": C})]
+        ops = build_ops(stack, {k: v[:1] for k, v in pp.items()})
+        for _ in range(3):
+            ctx.apply(view, ops, mode)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            ctx.apply(view, ops, mode)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        out[label] = {"us_per_eval": dt * 1e6, "evals_per_s": n / dt,
+                      "roofline": {"bound": "hbm", "achieved": 144 * n / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 144 * n / dt / 1e9 / HBM_PEAK_GBS}}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,6 +192,7 @@ def main():
     ap.add_argument("--grfull-n", type=int, default=65536, help="0 disables the gr_full section")
     ap.add_argument("--c5-n", type=int, default=1_000_000, help="0 disables the device-resident stepping section")
     ap.add_argument("--c5-steps", type=int, default=10_000)
+    ap.add_argument("--c3-n", type=int, default=10_000_000, help="0 disables the all-massive stack section")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -263,6 +293,11 @@ def main():
                 out["resident_run"] = c5_section(ctx, args.c5_n, args.c5_steps, mode, "cuda:%d" % local_rank)
             except Exception as e:  # noqa: BLE001
                 out["resident_run"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if args.c3_n > 0:
+            try:
+                out["massive_stack"] = c3_section(ctx, args.c3_n, mode, "cuda:%d" % local_rank)
+            except Exception as e:  # noqa: BLE001
+                out["massive_stack"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if gr is not None:
             out["gr_full"] = gr
         print(json.dumps(out), flush=True)

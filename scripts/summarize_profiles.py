@@ -45,7 +45,7 @@ def traffic():
     algo = json.loads(line)["roofline"]["algorithmic_bytes_per_launch"]
     out = {
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 5 --warmup 2 --no-cpu "
-                  "--grfull-n 0 --c5-n 0`, stream_kernel dispatches averaged (%d / %d dispatches)" % (nf, nw),
+                  "--grfull-n 0 --c5-n 0 --c3-n 0`, stream_kernel dispatches averaged (%d / %d dispatches)" % (nf, nw),
         "FETCH_SIZE_KB_raw": fetch,
         "WRITE_SIZE_KB_raw": write,
         "correction": "FETCH_SIZE doubled (gfx950 tallies 128-B requests of wide coalesced loads at 64 B); WRITE_SIZE as is",
