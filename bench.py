@@ -201,10 +201,19 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
     dist = None
+    # REBXAMD_DIST_BACKEND=gloo rehearses a multi-rank launch on a box with fewer GPUs than ranks (ranks share
+    # devices; RCCL refuses that).  The driver's runs use the default: nccl = RCCL, one rank per GPU.
+    backend = os.environ.get("REBXAMD_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    red_dev = "cuda" if backend == "nccl" else "cpu"       # where the two scalar reductions of the timing live
 
     def barrier():
         if dist is not None:
@@ -235,10 +244,10 @@ def main():
     ctx.timing_enable(False)
 
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        cnt = torch.tensor([n_local], dtype=torch.float64, device="cuda")
+        cnt = torch.tensor([n_local], dtype=torch.float64, device=red_dev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         n_job = float(cnt.item())
     else:
