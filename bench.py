@@ -100,7 +100,7 @@ def grfull_section(ctx, n, mode=0, dist=None, device="cuda:0"):
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     pairs = n * (n - 1.0) * (2 + sweeps)

@@ -15,6 +15,18 @@ library (:class:`HipGrFullEngine`) and, in tests, on the CPU checker.
 import torch
 
 
+def _all_gather_into(out, inp, group=None):
+    """dist.all_gather_into_tensor; device tensors under the gloo backend (rehearsals with several
+    ranks on one GPU, where RCCL refuses to run) are staged through the host."""
+    import torch.distributed as dist
+    if out.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, inp.contiguous().cpu(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, inp.contiguous(), group=group)
+
+
 def row_shard(n, world, rank):
     """Contiguous, equal-size (padded) row ranges.  Returns (row0, row1, rows_per_rank)."""
     per = (n + world - 1) // world
@@ -54,7 +66,12 @@ def apply_forces_sharded(ctx, particles, ops, mode=0, group=None):
     sums = torch.zeros(3 * len(ops), dtype=torch.float64, device=particles.cols["x"].device)
     ctx.apply_targets(view, ops, particles.n_head, sums, mode)    # forces on the slice; pushes -> sums
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        if sums.is_cuda and dist.get_backend(group) == "gloo":      # rehearsal on a shared GPU: through the host
+            host = sums.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            sums.copy_(host)
+        else:
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
     ctx.add_pushes(view, ops, sums)
     return sums
 
@@ -75,7 +92,7 @@ def mof_com_sharded(ctx, particles, coordinates, group=None, exchange=None):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             world, rank = dist.get_world_size(group), dist.get_rank(group)
             out = torch.empty(world * vec.numel(), dtype=vec.dtype, device=vec.device)
-            dist.all_gather_into_tensor(out, vec.contiguous(), group=group)
+            _all_gather_into(out, vec, group)
             return out.view(world, -1), rank
         return vec.view(1, -1), 0
 
@@ -112,7 +129,7 @@ def _gatherer(group, exchange):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             world, rank = dist.get_world_size(group), dist.get_rank(group)
             out = torch.empty(world * vec.numel(), dtype=vec.dtype, device=vec.device)
-            dist.all_gather_into_tensor(out, vec.contiguous(), group=group)
+            _all_gather_into(out, vec, group)
             return out.view(world, -1), rank
         return vec.reshape(1, -1), 0
     return gather
@@ -229,7 +246,7 @@ def grfull_sharded(engine, c, gravity_ignore_10=0, group=None):
     engine.newton(gravity_ignore_10, an, [ao3[0], ao3[1], ao3[2]])   # replicated: every rank holds the full incoming field
     engine.pot(c, r0, r1, pot)
     if use_dist:
-        dist.all_gather_into_tensor(pot, pot[rank * per:(rank + 1) * per].clone(), group=group)
+        _all_gather_into(pot, pot[rank * per:(rank + 1) * per].clone(), group)
     engine.const(c, r0, r1, pot, ac)
     sweeps = 0
     for k in range(10):                             # reference loop bound (gr_full.c:173)
@@ -239,7 +256,7 @@ def grfull_sharded(engine, c, gravity_ignore_10=0, group=None):
         if use_dist:
             send[:3 * per].view(3, per).copy_(out3.view(3, world, per)[:, rank, :])
             send[3 * per:].copy_(flag)
-            dist.all_gather_into_tensor(recv_flat, send, group=group)
+            _all_gather_into(recv_flat, send, group)
             out3.view(3, world, per).copy_(recv[:, :3 * per].view(world, 3, per).permute(1, 0, 2))
             unconverged = float(recv[:, 3 * per].max().item()) != 0.0
         else:

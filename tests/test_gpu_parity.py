@@ -506,6 +506,51 @@ def test_multi_gpu_drivers_over_a_one_rank_rccl_group():
     assert r.returncode == 0 and "rccl one-rank ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+def test_two_ranks_sharing_this_gpu_run_the_sharded_drivers(ctx, tmp_path):
+    """Two processes (gloo; collectives staged through the host) run the row-sharded gr_full driver
+    and the particle-sharded per-particle driver, including gr and Jacobi modify_orbits_forces with
+    massive slices, against the one-process evaluation on the same GPU (child processes:
+    tests/gloo_two_ranks.py)."""
+    import os
+    import subprocess
+    import sys
+    from reboundx_amd.device import DeviceParticles
+    from reboundx_amd.dist import HipGrFullEngine, grfull_sharded
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gloo_two_ranks.py")
+    port = 29700 + os.getpid() % 200
+    outs = [str(tmp_path / ("rank%d.npz" % r)) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, "-u", script, str(r), "2", str(port), outs[r]], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    logs = [p.communicate(timeout=140)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
+    res = [np.load(o) for o in outs]
+    # gr_full: every rank ends with all rows; against the unsharded run on this GPU
+    cl = synthetic.cluster(1500)
+    for k, s in (("ax", "x"), ("ay", "y"), ("az", "z")):
+        cl[k] = -cl[s]
+    dp = DeviceParticles.from_host(cl, n_head=1500, tail_massless=False)
+    sweeps = grfull_sharded(HipGrFullEngine(ctx, dp, EXACT), 1e2, 0)
+    one = np.array(dp.acc_host())
+    base = np.stack([cl["ax"], cl["ay"], cl["az"]])
+    for r in res:
+        assert int(r["sweeps"]) == sweeps
+        assert rel_err(r["acc"] - base, one - base).max() <= 1e-12
+    assert np.array_equal(res[0]["acc"], res[1]["acc"])
+    # per-particle stack: assemble the slices, compare with the unsharded device run
+    n, h = 20001, 2
+    cols, pp, _ = synthetic.disk(n, h - 1, dust_mass=1e-12)
+    pp["primary"] = np.zeros(n, dtype=np.uint8); pp["primary"][0] = 1
+    stack = [("tides_precession", {}), ("modify_orbits_forces", {}), ("gr_potential", {"c": C}), ("gr", {"c": C})]
+    whole, _ = run_device(ctx, cols, pp, stack, 1.0, EXACT)
+    got = np.zeros((3, n))
+    for r in res:
+        got[:, r["idx"][h:]] = r["slice_acc"][:, h:]
+    assert np.array_equal(res[0]["slice_acc"][:, :h], res[1]["slice_acc"][:, :h])
+    got[:, :h] = res[0]["slice_acc"][:, :h]
+    big = np.abs(whole).max(axis=0)
+    assert (np.abs(got - whole) / big[None, :]).max() <= 1e-12
+
+
 @pytest.mark.parametrize("mode", [EXACT, FAST])
 def test_particle_sharded_run_with_massive_slices_matches_unsharded_checker(ctx, mode):
     """Config C3 on several devices: every grain has mass, so each shard's pushes on the star
