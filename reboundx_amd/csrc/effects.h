@@ -237,10 +237,44 @@ __device__ __forceinline__ void mof_exact(const Part& p, const Src& ref, V3& a) 
         a.z += prefac * dz + 2. * dvz / tau_inc;
     }
 }
-// The damping terms routinely cancel against each other (da/dt term vs. the radial term), so
-// a reciprocal-multiply version loses digits on exactly the components that matter; the five
-// divisions are cheap next to the memory traffic, so both modes use the same arithmetic.
-__device__ __forceinline__ void mof_fast(const Part& p, const Src& ref, V3& a) { mof_exact(p, ref, a); }
+// a / b from y = fast_rcp(b): the quotient estimate is corrected with its exact residual, which
+// leaves it within an ulp of the IEEE quotient (nearly always equal to it) at a third of the cost
+// of the hardware division sequence; y is shared by the quotients over the same b.
+__device__ __forceinline__ double div_refined(double a, double b, double y) {
+    const double q = a * y;
+    return fma(fma(-b, q, a), y, q);
+}
+
+// Default arithmetic: the reference's seven quotients, each formed by div_refined (four
+// reciprocals shared among them) instead of IEEE division sequences.  The terms along dv and
+// along d can cancel, so each quotient has to be good to the last bit or so: plain
+// reciprocal-multiply forms cost 1e-12 of the update after cancellation.  An unset timescale
+// acts as +infinity (its term is exactly zero).
+__device__ __forceinline__ void mof_fast(const Part& p, const Src& ref, V3& a) {
+#pragma clang fp contract(off)
+    // (no contraction here either: after cancellation between the terms, a differently rounded
+    // product shows at 1e-12 of the update even when it is the more accurate one)
+    const double tau_a = is_set(p.ta) ? p.ta : INFINITY;
+    const double tau_e = is_set(p.te) ? p.te : INFINITY;
+    const double tau_inc = is_set(p.ti) ? p.ti : INFINITY;
+    const double dvx = p.vx - ref.vx, dvy = p.vy - ref.vy, dvz = p.vz - ref.vz;
+    const double dx = p.x - ref.x, dy = p.y - ref.y, dz = p.z - ref.z;
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    a.x = a.y = a.z = 0.;
+    if (tau_a < INFINITY && tau_a > -INFINITY) {
+        const double ta2 = 2. * tau_a, ya = fast_rcp(ta2);
+        a.x = div_refined(dvx, ta2, ya); a.y = div_refined(dvy, ta2, ya); a.z = div_refined(dvz, ta2, ya);
+    }
+    if (tau_e < INFINITY || tau_inc < INFINITY) {
+        const double vdotr = dx * dvx + dy * dvy + dz * dvz;
+        double prefac = 0., zi = 0.;
+        if (tau_e < INFINITY && tau_e > -INFINITY) prefac = div_refined(div_refined(2 * vdotr, r2, fast_rcp(r2)), tau_e, fast_rcp(tau_e));
+        if (tau_inc < INFINITY && tau_inc > -INFINITY) zi = div_refined(2. * dvz, tau_inc, fast_rcp(tau_inc));
+        a.x += prefac * dx;
+        a.y += prefac * dy;
+        a.z += prefac * dz + zi;
+    }
+}
 
 // ---------------------------------------------------------------- gr (1PN, single dominant mass)
 // Jacobi-coordinate state of one body: position, velocity, Newtonian acceleration.
