@@ -1,7 +1,7 @@
 """Deviation of the default-arithmetic gr_full from the CPU checker on virialised clusters (development aid)."""
 import sys, numpy as np
 import os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import oracle
 from reboundx_amd import synthetic
