@@ -94,3 +94,81 @@ def test_random_stack_layout_and_parameters(ctx, seed, mode):
         assert np.isfinite(got).all(), (seed, stack)
         err = np.abs(got - ref).max(axis=0) / den
         assert err.max() <= bar, "seed %d stack %s: %.3e at particle %d (n=%d)" % (seed, [f[0] for f in stack], err.max(), int(err.argmax()), n)
+
+
+def random_tail_case(seed, planets_max):
+    """Star (+ planets) + massless grains, random stack of forces that act on such a layout."""
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.choice([2, 3, 66, 513, 2050]))
+    planets = int(rng.integers(0, min(planets_max, n - 1) + 1))
+    cols, pp, _ = synthetic.disk(n, planets, seed=int(rng.integers(1, 100)))
+    h = 1 + planets
+    for key in ("beta", "tau_a", "tau_e", "tau_inc"):
+        if n > 4 and rng.random() < 0.5:
+            pp[key] = pp[key].copy()
+            pp[key][rng.choice(np.arange(1, n), size=max(1, n // 5), replace=False)] = np.nan
+    pp["primary"] = np.zeros(n, dtype=np.uint8)
+    pp["primary"][int(rng.integers(0, h))] = 1
+    k = int(rng.integers(1, 6))
+    stack, seen_gr, seen_com = [], False, False
+    for j in rng.permutation(sorted(rng.choice(len(FORCES), size=k, replace=False))):
+        name, ep = FORCES[j]
+        com = name == "modify_orbits_forces" and ep.get("coordinates", 0) in (0, 1)
+        if name == "central_force" or (name == "gr" and seen_gr) or (com and seen_com):
+            continue
+        seen_gr |= name == "gr"
+        seen_com |= com
+        stack.append((name, ep))
+    if not stack:
+        stack = [FORCES[0]]
+    return cols, pp, stack, n
+
+
+@pytest.mark.parametrize("mode", [1, 0], ids=["exact", "fast"])
+@pytest.mark.parametrize("seed", range(40))
+def test_random_stack_through_the_force_integrators(ctx, seed, mode):
+    """integrate_force (every scheme) on a random stack: reference-order arithmetic carries the
+    checker's bits for the explicit schemes; the default arithmetic meets 1e-12 of the velocity change."""
+    import oracle
+    from reboundx_amd.device import DeviceParticles
+    from reboundx_amd.program import build_ops
+    cols, pp, stack, n = random_tail_case(seed, 4)
+    integrator = ["euler", "rk2", "rk4", "implicit_midpoint"][seed % 4]
+    ref = oracle.Sim(cols)
+    oracle.integrate_force(ref, integrator, 0.01, stack, pp)
+    host = dict(cols)
+    for k in ("beta", "R_tides", "k1", "tau_a", "tau_e", "tau_inc"):
+        host[k] = pp[k]
+    dp = DeviceParticles.from_host(host)
+    ctx.integrate_force(dp.view(), build_ops(stack, pp), integrator, 0.01, mode)
+    v0 = np.array([cols[k] for k in ("vx", "vy", "vz")])
+    vr = np.array([ref.cols[k] for k in ("vx", "vy", "vz")])
+    vd = np.array([dp.cols[k].cpu().numpy() for k in ("vx", "vy", "vz")])
+    assert np.isfinite(vd).all()
+    if mode == 1 and integrator != "implicit_midpoint":
+        assert np.array_equal(vd, vr), (seed, integrator, [f[0] for f in stack])
+    scale = np.abs(vr - v0).max(axis=0)
+    den = np.maximum(np.where(scale == 0., 1., scale), 4 * np.finfo(float).eps * np.abs(vr).max(axis=0) / TOL)
+    assert (np.abs(vd - vr) / den[None, :]).max() <= TOL, (seed, integrator, [f[0] for f in stack])
+
+
+@pytest.mark.parametrize("mode", [1, 0], ids=["exact", "fast"])
+@pytest.mark.parametrize("seed", range(24))
+def test_random_stack_through_wisdom_holman_steps(ctx, seed, mode):
+    """rebxamd_wh_steps (star + massless grains) on a random stack against the checker's Wisdom-Holman restatement."""
+    import oracle
+    from reboundx_amd.device import DeviceParticles
+    from reboundx_amd.program import build_ops
+    cols, pp, stack, n = random_tail_case(seed, 0)
+    cols["vx"][0], cols["vy"][0] = 2e-3, -1e-3
+    ref = oracle.Sim(cols)
+    oracle.whfast_steps(ref, 0.04, 9, stack, pp)
+    want = np.array([ref.cols[k] for k in ("x", "y", "z", "vx", "vy", "vz")])
+    host = dict(cols)
+    for k in ("beta", "R_tides", "k1", "tau_a", "tau_e", "tau_inc"):
+        host[k] = pp[k]
+    dp = DeviceParticles.from_host(host, n_head=1, tail_massless=True)
+    ctx.wh_steps(dp.view(), build_ops(stack, pp), 0.04, 9, mode)
+    got = np.array([dp.cols[k].cpu().numpy() for k in ("x", "y", "z", "vx", "vy", "vz")])
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max(), (seed, [f[0] for f in stack])
