@@ -23,7 +23,7 @@ struct rebxamd_ctx {
     size_t gf_cap = 0;
     unsigned* gf_flag = nullptr;
     double* chunk_sums = nullptr;       // second-stage scratch of the back-reaction reduction
-    double* star = nullptr;             // 16 doubles: state of body 0 around a Wisdom-Holman drift
+    double* star = nullptr;             // 2 x 16 doubles: records of body 0 around Wisdom-Holman drifts
     double* integ = nullptr;            // stage columns of the force integrators
     size_t integ_cap = 0;
     double* shard = nullptr;            // per-range forces and reactions of the sharded Jacobi/barycentric modify_orbits_forces
@@ -84,7 +84,7 @@ extern "C" int rebxamd_create(int device, rebxamd_ctx** out) {
         hipMalloc((void**)&ctx->status, sizeof(unsigned)) != hipSuccess ||
         hipMalloc((void**)&ctx->ll, sizeof(long long)) != hipSuccess ||
         hipMalloc((void**)&ctx->gf_flag, sizeof(unsigned)) != hipSuccess ||
-        hipMalloc((void**)&ctx->star, 16 * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&ctx->star, 32 * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&ctx->chunk_sums, sizeof(double) * REBXAMD_MAX_OPS * 64 * 3) != hipSuccess ||
         hipMemset(ctx->hc, 0, 4 * sizeof(HeadConsts)) != hipSuccess ||
         hipMemset(ctx->status, 0, sizeof(unsigned)) != hipSuccess) {
@@ -541,7 +541,7 @@ extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* vie
             rebxamd_view head = *view;
             head.n = K; head.n_head = K;
             head.vx = hv[0]; head.vy = hv[1]; head.vz = hv[2]; head.ax = ha[0]; head.ay = ha[1]; head.az = ha[2];
-            StepArgs sa = {0., 0., nullptr, EPI_IM, dt, 0., 0., {fin[0], fin[1], fin[2]}, partials + 2};
+            StepArgs sa = {0., 0., nullptr, EPI_IM, dt, 0., 0., {fin[0], fin[1], fin[2]}, partials + 2, nullptr, 0.};
             int it = 0;
             for (it = 0; it < 10; it++) {
                 ctx->hc_stage = 0;
@@ -577,7 +577,7 @@ extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* vie
             ctx->carried_steps = saved;
             ctx->hc_stage = 0;
             if (rc != REBXAMD_OK) return rc;
-            StepArgs sa = {0., 0., nullptr, EPI_EULER, dt, 0., 0., {nullptr, nullptr, nullptr}, nullptr};
+            StepArgs sa = {0., 0., nullptr, EPI_EULER, dt, 0., 0., {nullptr, nullptr, nullptr}, nullptr, nullptr, 0.};
             if (integrator == REBXAMD_INTEGRATOR_RK2) { sa.epi = EPI_RK2; sa.c0 = 2. * dt / 3.; sa.c1 = dt / 4.; sa.c2 = 3. * dt / 4.; }
             if (integrator == REBXAMD_INTEGRATOR_RK4) { sa.epi = EPI_RK4; sa.c0 = dt / 2.; sa.c1 = dt; sa.c2 = dt / 6.; }
             rc = run_streaming(ctx, view, ops, 0, nops, mode, st, -1, nullptr, false, &sa);
@@ -706,23 +706,32 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
     double* const a[3] = {view->ax, view->ay, view->az};
     // Consecutive half drifts of neighbouring steps are one Kepler drift of a whole step (the
     // flow of the two-body problem composes exactly); only the ends of the run are half steps.
-    // The kick rides in the drift kernel that follows it, which also clears the accelerations
-    // for the next force pass.
-    HIP_TRY(launch_wh_drift(x, v, nullptr, view->m, view->G, 0.5 * dt, 0., view->n, ctx->star, exact, st));
+    // When the whole stack is one streaming run whose sources are body 0, the pass over the massless
+    // bodies carries the kick and the drift as well (their accelerations never leave registers), and
+    // in the first step also the leading half drift: one head pass and one pass per step.
+    bool carried = ctx->carried_steps && one_streaming_run(ops, nops) && view->n_head == 1 && view->n > 1;
+    for (int k = 0; k < nops && carried; k++) {
+        const bool com = ops[k].kind == REBXAMD_OP_MOF && ops[k].iarg != REBX_COORDINATES_PARTICLE;
+        const int src = (ops[k].kind == REBXAMD_OP_GR || ops[k].kind == REBXAMD_OP_GR_POTENTIAL) ? 0 : ops[k].src;
+        if (!com && src != 0) carried = false;
+    }
     rc = rebxamd_reset_accelerations(ctx, view, stream);
     if (rc != REBXAMD_OK) return rc;
-    // When the whole stack is one streaming run, the pass over the massless bodies carries the
-    // kick and the drift as well: their accelerations never leave registers.
-    bool carried = ctx->carried_steps && one_streaming_run(ops, nops);
+    if (carried) {
+        double* const star0 = ctx->star + 16;
+        HIP_TRY(launch_wh_star(x, v, view->m, view->G, 0.5 * dt, star0, st));       // body 0 to mid-step; the others follow inside the pass
+        for (int64_t k = 0; k < nsteps; k++) {
+            const double h = k + 1 < nsteps ? dt : 0.5 * dt;
+            const StepArgs sa = {h, dt, ctx->star, EPI_WH, 0., 0., 0., {nullptr, nullptr, nullptr}, nullptr, k == 0 ? star0 : nullptr, 0.5 * dt};
+            rc = run_streaming(ctx, view, ops, 0, nops, mode, st, -1, nullptr, false, &sa);
+            if (rc == STEP_NOT_CARRIED) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_steps: the force stack cannot ride in one pass over this layout");
+            if (rc != REBXAMD_OK) return rc;
+        }
+        return REBXAMD_OK;
+    }
+    HIP_TRY(launch_wh_drift(x, v, nullptr, view->m, view->G, 0.5 * dt, 0., view->n, ctx->star, exact, st));
     for (int64_t k = 0; k < nsteps; k++) {
         const double h = k + 1 < nsteps ? dt : 0.5 * dt;
-        if (carried) {
-            const StepArgs sa = {h, dt, ctx->star, EPI_WH, 0., 0., 0., {nullptr, nullptr, nullptr}, nullptr};
-            rc = run_streaming(ctx, view, ops, 0, nops, mode, st, -1, nullptr, false, &sa);
-            if (rc == REBXAMD_OK) continue;
-            if (rc != STEP_NOT_CARRIED) return rc;
-            carried = false;
-        }
         if (nops > 0) {
             rc = rebxamd_apply(ctx, view, ops, nops, mode, stream);
             if (rc != REBXAMD_OK) return rc;

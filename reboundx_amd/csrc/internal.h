@@ -63,7 +63,8 @@ struct HeadConsts {
 // What the streaming pass behind the head (tail bodies massless) does with the forces it has
 // computed, besides or instead of adding them to the acceleration columns:
 //   EPI_WH    a whole Wisdom-Holman step: kick by dtk, Kepler drift over h about body 0, whose record
-//             (state before the drift, position after it, acceleration, G*m_0) is `star`;
+//             (state before the drift, position after it, acceleration, G*m_0) is `star`; the first step of
+//             a run also carries its leading half drift (over h0 about the record star0) ahead of the forces;
 //   EPI_EULER / EPI_RK2 / EPI_RK4   a whole "integrate the force across dt" update of the velocities
 //             (reference src/integrator_euler.c, integrator_rk2.c, integrator_rk4.c): every stage is
 //             evaluated on the body while it sits in registers, against the head tables of that stage
@@ -76,7 +77,8 @@ struct HeadConsts {
 //             the squared change and squared size (compare(), :47-62) are left as one pair of partial
 //             sums per workgroup in `partials`.  Velocity and acceleration columns are not written.
 enum { EPI_NONE = 0, EPI_WH = 1, EPI_EULER = 2, EPI_RK2 = 3, EPI_RK4 = 4, EPI_IM = 5 };
-struct StepArgs { double h, dtk; const double* star; int epi; double c0, c1, c2; double* aux[3]; double* partials; };
+struct StepArgs { double h, dtk; const double* star; int epi; double c0, c1, c2; double* aux[3]; double* partials;
+                  const double* star0; double h0; };   // EPI_WH: a leading Kepler drift over h0 about the record star0 (nullptr: none)
 
 enum { WARN_GR_ITER = 1u, WARN_GRFULL_SWEEPS = 2u, WARN_IM_ITER = 4u };
 
@@ -116,6 +118,8 @@ hipError_t launch_lincomb(double* const out[3], const double* const v[3], const 
 hipError_t launch_rk2_final(double* const v[3], const double* const a1[3], const double* const a2[3], double b1, double b2, long long n, bool exact, hipStream_t st);
 hipError_t launch_rk4_mid(double* const sv[3], const double* const v[3], double* const k2a[3], double* const k3a[3], double dt, long long n, bool exact, hipStream_t st);
 hipError_t launch_rk4_final(double* const v[3], const double* const a1[3], const double* const a4[3], const double* const k23[3], double dt6, long long n, bool exact, hipStream_t st);
+// body 0 alone: records it in `star` and drifts it over h
+hipError_t launch_wh_star(double* const x[3], double* const v[3], const double* m, double G, double h, double* star, hipStream_t st);
 hipError_t launch_wh_drift(double* const x[3], double* const v[3], double* const a[3], const double* m, double G, double h, double dtk, long long n,
                            double* star, bool exact, hipStream_t st);
 long long im_partial_count(long long n);

@@ -204,6 +204,14 @@ hipError_t launch_im_sum(const double* partials, long long nb, double* sums, hip
     return hipGetLastError();
 }
 
+hipError_t launch_wh_star(double* const x[3], double* const v[3], const double* m, double G, double h, double* star, hipStream_t st) {
+    const Cols3 cx = {x[0], x[1], x[2]};
+    const Cols3 ca = {nullptr, nullptr, nullptr};
+    const CCols3 ccv = {v[0], v[1], v[2]};
+    hipLaunchKernelGGL(wh_star_drift_kernel, dim3(1), dim3(64), 0, st, cx, ccv, ca, m, G, h, star);
+    return hipGetLastError();
+}
+
 // a == nullptr: drift only.  Otherwise kick by dtk with the accelerations in `a` (which are cleared), then drift.
 hipError_t launch_wh_drift(double* const x[3], double* const v[3], double* const a[3], const double* m, double G, double h, double dtk, long long n,
                            double* star, bool exact, hipStream_t st) {

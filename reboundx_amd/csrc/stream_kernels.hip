@@ -628,6 +628,16 @@ __global__ __launch_bounds__(BLOCK, (!EXACT && !BACKREACT && COLS != COL_ALL) ? 
         }
     }
 
+    if (EPI == EPI_WH && step.star0 != nullptr) {
+        // first step of a run: the leading half drift, ahead of the forces
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (!(k ? act1 : act0)) continue;
+            double s[6] = {p[k].x, p[k].y, p[k].z, p[k].vx, p[k].vy, p[k].vz};
+            wh_kick_drift<EXACT, false>(s, 0., 0., 0., step.h0, 0., step.star0);
+            p[k].x = s[0]; p[k].y = s[1]; p[k].z = s[2]; p[k].vx = s[3]; p[k].vy = s[4]; p[k].vz = s[5];
+        }
+    }
     double orig[2][3], fin[2][3];           // implicit midpoint: velocities at the start of the step, current estimate of the final ones
     if (EPI == EPI_IM) {
         if (full) {
@@ -876,7 +886,7 @@ hipError_t launch_head(const View& v, const Program& prog, HeadConsts* hc, unsig
 template <bool EXACT, bool BACKREACT>
 static void launch_stream_cols(dim3 g, dim3 b, hipStream_t st, bool vec2, bool fixed, int cols, const View& v, const Program& prog, long long lo,
                                long long base, const HeadConsts* hc, double* partials, unsigned* status, const StepArgs* step) {
-    const StepArgs sa = step ? *step : StepArgs{0., 0., nullptr, EPI_NONE, 0., 0., 0., {nullptr, nullptr, nullptr}, nullptr};
+    const StepArgs sa = step ? *step : StepArgs{0., 0., nullptr, EPI_NONE, 0., 0., 0., {nullptr, nullptr, nullptr}, nullptr, nullptr, 0.};
     Sig sig = 0ull;
     if (fixed && vec2 && prog.nops <= 8) for (int o = 0; o < prog.nops; o++) sig |= (Sig)(prog.ops[o].kind & 15) << (4 * o);
     if (step) {
