@@ -94,7 +94,7 @@ __device__ __forceinline__ void kepler_exact(double (&q)[6], double M, double dt
 }
 
 // Default arithmetic: refined hardware reciprocals, third-order starting guess and Halley's
-// method (cubic convergence): a step shorter than 1e-6 of X leaves an error below rounding, so
+// method (cubic convergence): a step shorter than 4e-6 of X leaves an error below rounding, so
 // the usual cost is two evaluations of the G functions plus the final one.  The bracket of the
 // root (the residual is monotonic in X: its derivative is r > 0) guards every step.
 __device__ __forceinline__ void kepler_fast(double (&q)[6], double M, double dt) {
@@ -123,7 +123,7 @@ __device__ __forceinline__ void kepler_fast(double (&q)[6], double M, double dt)
         double Xn = X + dX;
         const bool inside = Xn > lo && Xn < hi;
         if (!inside) Xn = (isfinite(lo) && isfinite(hi)) ? 0.5 * (lo + hi) : X - s * spi;
-        const bool done = (inside && fabs(dX) <= 1e-6 * fabs(Xn)) || Xn == X || Xn == prev;
+        const bool done = (inside && fabs(dX) <= 4e-6 * fabs(Xn)) || Xn == X || Xn == prev;
         prev = X; X = Xn;
         if (done) break;
     }
