@@ -364,6 +364,53 @@ __global__ __launch_bounds__(64) void head_kernel(View v, Program prog, HeadCons
     if (valid) { v.ax[t] = acc.x; v.ay[t] = acc.y; v.az[t] = acc.z; }
 }
 
+// The head pass when the head is ONE body (a star in front of massless bodies) and no op works in
+// barycentric coordinates: nothing acts on that body (every op has it as its source, and its
+// Jacobi frame is empty), so the pass only fills the tables -- with the arithmetic of head_kernel
+// for K = 1, rounding included -- and, in a Wisdom-Holman run, records and drifts the body.  A
+// fraction of head_kernel's latency: no loops over ops with barriers, no LDS.
+__global__ __launch_bounds__(64) void head_one_kernel(View v, Program prog, HeadConsts* hc, double* star, double h) {
+    const int t = threadIdx.x;
+    Src S;
+    load_src(v, 0, S);                                  // every lane reads the same body
+    if (t < prog.nops) {
+        int s = prog.ops[t].src;
+        if (prog.ops[t].kind == REBXAMD_OP_GR) s = 0;
+        if (s >= 0) hc->src[t] = S;
+    }
+    if (t != 0) return;
+    if (S.m != 0.) { hc->head[0][0] = S.x; hc->head[0][1] = S.y; hc->head[0][2] = S.z; hc->head[0][3] = S.m; }
+    hc->nheadm = S.m != 0. ? 1 : 0;
+    hc->head0 = S.m != 0. ? 0 : -1;
+    if (prog.gr_op >= 0) {
+#pragma clang fp contract(off)
+        const double eta = S.m, ei = 1. / eta;
+        hc->gr_c[0] = (eta * S.x) * ei;  hc->gr_c[1] = (eta * S.y) * ei;  hc->gr_c[2] = (eta * S.z) * ei;
+        hc->gr_c[3] = (eta * S.vx) * ei; hc->gr_c[4] = (eta * S.vy) * ei; hc->gr_c[5] = (eta * S.vz) * ei;
+        hc->gr_c[6] = (eta * 0.) * ei;   hc->gr_c[7] = (eta * 0.) * ei;   hc->gr_c[8] = (eta * 0.) * ei;
+        hc->gr_mu = prog.G * S.m;
+        // what the back-transformation of an empty Jacobi chain leaves on the body: zero (NaN for a massless one)
+        const double na0 = ((0. * eta) * ei);
+        v.ax[0] += na0; v.ay[0] += na0; v.az[0] += na0;
+    }
+    if (prog.mofcom_op >= 0) {
+        Com c = {0., 0., 0., 0., 0., 0., 0.};
+        com_add(c, S);
+        hc->com[0] = c.x; hc->com[1] = c.y; hc->com[2] = c.z;
+        hc->com[3] = c.vx; hc->com[4] = c.vy; hc->com[5] = c.vz; hc->com[6] = c.m;
+        hc->nbary = 0;
+    }
+    if (star != nullptr) {
+#pragma clang fp contract(off)
+        star[0] = S.x; star[1] = S.y; star[2] = S.z; star[3] = S.vx; star[4] = S.vy; star[5] = S.vz;
+        star[9] = v.ax[0]; star[10] = v.ay[0]; star[11] = v.az[0]; star[12] = prog.G * S.m;
+        v.ax[0] = 0.; v.ay[0] = 0.; v.az[0] = 0.;
+        const double nx = S.x + h * S.vx, ny = S.y + h * S.vy, nz = S.z + h * S.vz;
+        const_cast<double*>(v.x)[0] = nx; const_cast<double*>(v.y)[0] = ny; const_cast<double*>(v.z)[0] = nz;
+        star[6] = nx; star[7] = ny; star[8] = nz;
+    }
+}
+
 // ------------------------------------------------------------------ streaming kernel
 
 typedef double d2v __attribute__((ext_vector_type(2)));
@@ -878,6 +925,14 @@ int stream_block_count(long long lo, long long n, bool) {
 }
 
 hipError_t launch_head(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, bool exact, hipStream_t st, double* star, double h) {
+    const long long K = v.n_head < v.n ? v.n_head : v.n;
+    bool one = K == 1 && v.vx != nullptr && v.m != nullptr;
+    for (int o = 0; o < prog.nops && one; o++)
+        if (prog.ops[o].kind == REBXAMD_OP_MOF && prog.ops[o].iarg == REBX_COORDINATES_BARYCENTRIC) one = false;   // there body 0 acts on itself
+    if (one) {
+        hipLaunchKernelGGL(head_one_kernel, dim3(1), dim3(64), 0, st, v, prog, hc, star, h);
+        return hipGetLastError();
+    }
     if (exact) hipLaunchKernelGGL(head_kernel<true>, dim3(1), dim3(64), 0, st, v, prog, hc, status, star, h);
     else hipLaunchKernelGGL(head_kernel<false>, dim3(1), dim3(64), 0, st, v, prog, hc, status, star, h);
     return hipGetLastError();
