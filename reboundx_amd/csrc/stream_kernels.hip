@@ -771,9 +771,9 @@ __global__ __launch_bounds__(BLOCK, (!EXACT && !BACKREACT && COLS != COL_ALL) ? 
         if (act1) integrate_tail<EXACT, SIG, EPI>(prog, tab, p[1], acc[1], step, status);
         if (full) {
             d2v t;
-            t.x = p[0].vx; t.y = p[1].vx; *reinterpret_cast<d2v*>(pvx + i0) = t;
-            t.x = p[0].vy; t.y = p[1].vy; *reinterpret_cast<d2v*>(pvy + i0) = t;
-            t.x = p[0].vz; t.y = p[1].vz; *reinterpret_cast<d2v*>(pvz + i0) = t;
+            t.x = p[0].vx; t.y = p[1].vx; __builtin_nontemporal_store(t, reinterpret_cast<d2v*>(pvx + i0));
+            t.x = p[0].vy; t.y = p[1].vy; __builtin_nontemporal_store(t, reinterpret_cast<d2v*>(pvy + i0));
+            t.x = p[0].vz; t.y = p[1].vz; __builtin_nontemporal_store(t, reinterpret_cast<d2v*>(pvz + i0));
         } else {
 #pragma unroll
             for (int k = 0; k < 2; k++) {
@@ -795,12 +795,12 @@ __global__ __launch_bounds__(BLOCK, (!EXACT && !BACKREACT && COLS != COL_ALL) ? 
         }
         if (full) {
             d2v t;
-            t.x = s[0][0]; t.y = s[1][0]; *reinterpret_cast<d2v*>(px + i0) = t;
-            t.x = s[0][1]; t.y = s[1][1]; *reinterpret_cast<d2v*>(py + i0) = t;
-            t.x = s[0][2]; t.y = s[1][2]; *reinterpret_cast<d2v*>(pz + i0) = t;
-            t.x = s[0][3]; t.y = s[1][3]; *reinterpret_cast<d2v*>(pvx + i0) = t;
-            t.x = s[0][4]; t.y = s[1][4]; *reinterpret_cast<d2v*>(pvy + i0) = t;
-            t.x = s[0][5]; t.y = s[1][5]; *reinterpret_cast<d2v*>(pvz + i0) = t;
+            t.x = s[0][0]; t.y = s[1][0]; __builtin_nontemporal_store(t, reinterpret_cast<d2v*>(px + i0));
+            t.x = s[0][1]; t.y = s[1][1]; __builtin_nontemporal_store(t, reinterpret_cast<d2v*>(py + i0));
+            t.x = s[0][2]; t.y = s[1][2]; __builtin_nontemporal_store(t, reinterpret_cast<d2v*>(pz + i0));
+            t.x = s[0][3]; t.y = s[1][3]; __builtin_nontemporal_store(t, reinterpret_cast<d2v*>(pvx + i0));
+            t.x = s[0][4]; t.y = s[1][4]; __builtin_nontemporal_store(t, reinterpret_cast<d2v*>(pvy + i0));
+            t.x = s[0][5]; t.y = s[1][5]; __builtin_nontemporal_store(t, reinterpret_cast<d2v*>(pvz + i0));
         } else {
 #pragma unroll
             for (int k = 0; k < 2; k++) {
@@ -814,9 +814,15 @@ __global__ __launch_bounds__(BLOCK, (!EXACT && !BACKREACT && COLS != COL_ALL) ? 
     if (full) {
         d2v ax, ay, az;
         ax.x = acc[0].x; ax.y = acc[1].x; ay.x = acc[0].y; ay.y = acc[1].y; az.x = acc[0].z; az.y = acc[1].z;
-        *reinterpret_cast<d2v*>(v.ax + i0) = ax;
-        *reinterpret_cast<d2v*>(v.ay + i0) = ay;
-        *reinterpret_cast<d2v*>(v.az + i0) = az;
+        if (STEP) {         // first-stage accelerations of a carried update: written once, not read back by this pass
+            __builtin_nontemporal_store(ax, reinterpret_cast<d2v*>(v.ax + i0));
+            __builtin_nontemporal_store(ay, reinterpret_cast<d2v*>(v.ay + i0));
+            __builtin_nontemporal_store(az, reinterpret_cast<d2v*>(v.az + i0));
+        } else {
+            *reinterpret_cast<d2v*>(v.ax + i0) = ax;
+            *reinterpret_cast<d2v*>(v.ay + i0) = ay;
+            *reinterpret_cast<d2v*>(v.az + i0) = az;
+        }
     } else {
         if (act0) { v.ax[i0] = acc[0].x; v.ay[i0] = acc[0].y; v.az[i0] = acc[0].z; }
         if (act1) { v.ax[i0 + 1] = acc[1].x; v.ay[i0 + 1] = acc[1].y; v.az[i0 + 1] = acc[1].z; }
