@@ -18,6 +18,7 @@
 // rounding level (the 1e-12 bar), in either arithmetic mode.
 #include "internal.h"
 #include "effects.h"
+#include "wave_ops.h"
 
 namespace rebxamd {
 
@@ -27,48 +28,6 @@ static constexpr int ST = 8;            // tiles of SB elements per workgroup in
 static constexpr int SCHUNK = SB * ST;
 
 enum ScanKind { SCAN_GR = 0, SCAN_MOF_JACOBI = 1, SCAN_MOF_BARY = 2 };
-
-// Wavefront scans.  Within each row of 16 lanes: four data-parallel-primitive shifts (row_shr /
-// row_shl by 1, 2, 4, 8; lanes the shift leaves empty read zero), which run at VALU rate instead
-// of going through the LDS crossbar; across the four rows: the row totals are read with
-// v_readlane and added to the rows behind (in front, for the suffix scan).
-template <int CTRL>
-__device__ __forceinline__ double dpp_shift(double v) {
-    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
-    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
-}
-__device__ __forceinline__ double lane_value(double v, int lane) {
-    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-__device__ __forceinline__ double wave_incl_scan(double v, int lane) {
-    v += dpp_shift<0x111>(v);       // row_shr:1
-    v += dpp_shift<0x112>(v);       // row_shr:2
-    v += dpp_shift<0x114>(v);       // row_shr:4
-    v += dpp_shift<0x118>(v);       // row_shr:8
-    const int row = lane >> 4;
-    const double t0 = lane_value(v, 15), t2 = lane_value(v, 47);
-    v += (row == 1) ? t0 : ((row == 3) ? t2 : 0.);
-    const double t01 = lane_value(v, 31);
-    v += (row >= 2) ? t01 : 0.;
-    return v;
-}
-__device__ __forceinline__ double wave_incl_scan_rev(double v, int lane) {
-    v += dpp_shift<0x101>(v);       // row_shl:1
-    v += dpp_shift<0x102>(v);       // row_shl:2
-    v += dpp_shift<0x104>(v);       // row_shl:4
-    v += dpp_shift<0x108>(v);       // row_shl:8
-    const int row = lane >> 4;
-    const double t1 = lane_value(v, 16), t3 = lane_value(v, 48);
-    v += (row == 0) ? t1 : ((row == 2) ? t3 : 0.);
-    const double t23 = lane_value(v, 32);
-    v += (row <= 1) ? t23 : 0.;
-    return v;
-}
 
 // Workgroup-wide scan of C values per thread.  REVERSE: suffix instead of prefix.
 // On return v[c] holds the INCLUSIVE scan and tot[c] the workgroup total.

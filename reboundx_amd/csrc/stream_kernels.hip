@@ -22,6 +22,7 @@
 #include "effects.h"
 #include "kepler.h"
 #include "updates.h"
+#include "wave_ops.h"
 
 namespace rebxamd {
 
@@ -47,11 +48,8 @@ __device__ __forceinline__ void load_src(const View& v, int idx, Src& S) {
     S.inv_m = 1. / S.m;
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
+// sum over the wavefront (every lane of the wavefront must call it)
+__device__ __forceinline__ double wave_sum(double v) { return wave_total(v, (int)(threadIdx.x & 63)); }
 
 // One force on one particle.  Returns true when the particle was acted on; `d` is its own
 // update, `br` the push on the source (already signed).  Fast mode reuses the separation
