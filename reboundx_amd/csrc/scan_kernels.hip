@@ -214,7 +214,7 @@ __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, cons
                     Src ref;
                     const double inv = eta > 0. ? 1. / eta : 1.;
                     ref.x = S[1] * inv; ref.y = S[2] * inv; ref.z = S[3] * inv; ref.vx = S[4] * inv; ref.vy = S[5] * inv; ref.vz = S[6] * inv; ref.m = eta;
-                    mof_exact(p, ref, a);
+                    if (EXACT) mof_exact(p, ref, a); else mof_fast(p, ref, a);
                     const double f = (KIND == SCAN_MOF_BARY) ? mi / eta : mi / (eta + mi);
                     w[0] = f * a.x; w[1] = f * a.y; w[2] = f * a.z;
                 }
@@ -488,8 +488,13 @@ hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, 
     } else {
         hipLaunchKernelGGL(scan_block_totals<7>, gs, b, 0, st, v, nax, nay, naz, bs);
         hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(SOT), 0, st, bs, nbs, totals);
-        if (kind == SCAN_MOF_JACOBI) hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL, v.m);
-        else hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL, v.m);
+        if (kind == SCAN_MOF_JACOBI) {
+            if (exact) hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL, v.m);
+            else hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL, v.m);
+        } else {
+            if (exact) hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL, v.m);
+            else hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL, v.m);
+        }
     }
     hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(1), dim3(SOT), 0, st, wsum, nbs, wtot);
     if (kind == SCAN_MOF_BARY) hipLaunchKernelGGL(scan_apply<true>, gs, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, wsum, wtot, (const double*)nullptr);
