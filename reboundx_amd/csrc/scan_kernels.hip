@@ -88,15 +88,23 @@ __device__ __forceinline__ void weighted_state(const View& v, const double* nax,
     if constexpr (C == 10) { q[7] = m * ldnt(nax, i); q[8] = m * ldnt(nay, i); q[9] = m * ldnt(naz, i); }
 }
 
-// pass 1: workgroup totals of the weighted state (a workgroup covers ST tiles of SB bodies)
+// Element order inside the weighted-sum passes: a workgroup covers SCHUNK consecutive bodies, each of
+// its SW wavefronts a contiguous segment of 64*ST of them, tile by tile (64 consecutive bodies per
+// tile).  Scans then never leave the wavefront: no LDS, no barriers inside the tile loop.
+__device__ __forceinline__ long long segment_start(int wave) { return (long long)blockIdx.x * SCHUNK + (long long)wave * (64 * ST); }
+
+// pass 1: totals of the weighted state per wavefront segment (wavesums, may be null) and per workgroup
 template <int C>
-__global__ __launch_bounds__(SB) void scan_block_totals(View v, const double* nax, const double* nay, const double* naz, double* blocksums) {
+__global__ __launch_bounds__(SB) void scan_block_totals(View v, const double* nax, const double* nay, const double* naz, double* blocksums,
+                                                        double* wavesums) {
     __shared__ double lds[SW][C];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long seg = segment_start(wave);
     double acc[C];
 #pragma unroll
     for (int c = 0; c < C; c++) acc[c] = 0.;
     for (int t = 0; t < ST; t++) {
-        const long long i = (long long)blockIdx.x * SCHUNK + t * SB + threadIdx.x;
+        const long long i = seg + t * 64 + lane;
         if (i < v.n) {
             double q[C];
             weighted_state<C>(v, nax, nay, naz, i, q);
@@ -104,10 +112,23 @@ __global__ __launch_bounds__(SB) void scan_block_totals(View v, const double* na
             for (int c = 0; c < C; c++) acc[c] += q[c];
         }
     }
-    block_total<C>(acc, lds);
+#pragma unroll
+    for (int c = 0; c < C; c++) acc[c] = wave_total(acc[c], lane);
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            lds[wave][c] = acc[c];
+            if (wavesums != nullptr) wavesums[((long long)blockIdx.x * SW + wave) * C + c] = acc[c];
+        }
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int c = 0; c < C; c++) blocksums[(long long)blockIdx.x * C + c] = acc[c];
+        for (int c = 0; c < C; c++) {
+            double t = 0.;
+            for (int w = 0; w < SW; w++) t += lds[w][c];
+            blocksums[(long long)blockIdx.x * C + c] = t;
+        }
     }
 }
 
@@ -157,38 +178,43 @@ __global__ __launch_bounds__(SOT) void scan_of_totals(double* blocksums, long lo
     }
 }
 
-// pass 3: per-body force in its own frame (aJ) and its weighted reaction (w); workgroup totals of w
+// pass 3: per-body force in its own frame (aJ) and its weighted reaction (w); totals of w per
+// wavefront segment (wwave) and per workgroup (wsums)
 template <int KIND, bool EXACT>
 __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, const double* nax, const double* nay, const double* naz,
-                                                const double* blocksums, const double* totals,
+                                                const double* blocksums, const double* wavesums, const double* totals,
                                                 double* ajx, double* ajy, double* ajz, double* wx, double* wy, double* wz,
-                                                double* wsums, unsigned* status, const double* pre, long long first_acting, const double* m0) {
+                                                double* wsums, double* wwave, unsigned* status, const double* pre, long long first_acting, const double* m0) {
     constexpr int C = (KIND == SCAN_GR) ? 10 : 7;
-    __shared__ double lds[SW][C];
     __shared__ double lds3[SW][3];
-    double carry[C];            // sum over the tiles of this workgroup already passed
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long seg = segment_start(wave);
+    double base[C];             // sum over every body before the current tile
     double wacc[3] = {0., 0., 0.};
 #pragma unroll
-    for (int c = 0; c < C; c++) carry[c] = 0.;
+    for (int c = 0; c < C; c++) {
+        base[c] = 0.;
+        if (KIND != SCAN_MOF_BARY) {
+            base[c] = blocksums[(long long)blockIdx.x * C + c];
+            for (int w = 0; w < wave; w++) base[c] += wavesums[((long long)blockIdx.x * SW + w) * C + c];
+            if (pre != nullptr) base[c] += pre[c];          // bodies that precede this view (other shards, the head)
+        }
+    }
     for (int t = 0; t < ST; t++) {
-        const long long i = (long long)blockIdx.x * SCHUNK + t * SB + threadIdx.x;
+        const long long i = seg + t * 64 + lane;
         const bool live = i < v.n;
-        double q[C], own[C], tot[C];
+        double q[C], own[C];
 #pragma unroll
         for (int c = 0; c < C; c++) q[c] = 0.;
         if (live) weighted_state<C>(v, nax, nay, naz, i, q);
 #pragma unroll
-        for (int c = 0; c < C; c++) own[c] = q[c];
-        block_scan<C, false>(q, tot, lds);
+        for (int c = 0; c < C; c++) { own[c] = q[c]; if (KIND != SCAN_MOF_BARY) q[c] = wave_incl_scan(q[c], lane); }
         if (live) {
             V3 a = {0., 0., 0.};
             double w[3] = {0., 0., 0.};
             double S[C];        // exclusive prefix (bodies before i), or the grand total for barycentric
 #pragma unroll
-            for (int c = 0; c < C; c++) {
-                S[c] = (KIND == SCAN_MOF_BARY) ? totals[c] : blocksums[(long long)blockIdx.x * C + c] + carry[c] + (q[c] - own[c]);
-                if (KIND != SCAN_MOF_BARY && pre != nullptr) S[c] += pre[c];      // bodies that precede this view (other shards, the head)
-            }
+            for (int c = 0; c < C; c++) S[c] = (KIND == SCAN_MOF_BARY) ? totals[c] : base[c] + (q[c] - own[c]);
             const double eta = S[0], mi = own[0];
             Part p;
             p.x = ldnt(v.x, i); p.y = ldnt(v.y, i); p.z = ldnt(v.z, i); p.vx = ldnt(v.vx, i); p.vy = ldnt(v.vy, i); p.vz = ldnt(v.vz, i); p.m = mi;
@@ -223,38 +249,64 @@ __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, cons
             __builtin_nontemporal_store(w[0], wx + i); __builtin_nontemporal_store(w[1], wy + i); __builtin_nontemporal_store(w[2], wz + i);
             wacc[0] += w[0]; wacc[1] += w[1]; wacc[2] += w[2];
         }
+        if (KIND != SCAN_MOF_BARY) {
 #pragma unroll
-        for (int c = 0; c < C; c++) carry[c] += tot[c];
+            for (int c = 0; c < C; c++) base[c] += lane_value(q[c], 63);
+        }
     }
-    block_total<3>(wacc, lds3);
-    if (threadIdx.x == 0) { wsums[(long long)blockIdx.x * 3 + 0] = wacc[0]; wsums[(long long)blockIdx.x * 3 + 1] = wacc[1]; wsums[(long long)blockIdx.x * 3 + 2] = wacc[2]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) wacc[k] = wave_total(wacc[k], lane);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { lds3[wave][k] = wacc[k]; wwave[((long long)blockIdx.x * SW + wave) * 3 + k] = wacc[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            double t = 0.;
+            for (int w = 0; w < SW; w++) t += lds3[w][k];
+            wsums[(long long)blockIdx.x * 3 + k] = t;
+        }
+    }
 }
 
 // pass 5: a_i += aJ_i - (sum of w over bodies k >= i)   [barycentric: over all bodies]
 template <bool TOTAL>
 __global__ __launch_bounds__(SB) void scan_apply(View v, const double* ajx, const double* ajy, const double* ajz,
                                                  const double* wx, const double* wy, const double* wz,
-                                                 const double* wsums_excl, const double* wtotals, const double* suf) {
-    __shared__ double lds3[SW][3];
-    double carry[3] = {0., 0., 0.};         // reactions of the later tiles of this workgroup
+                                                 const double* wsums_excl, const double* wwave, const double* wtotals, const double* suf) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long seg = segment_start(wave);
+    double base[3] = {0., 0., 0.};          // reactions of every body behind the current tile
+    if (!TOTAL) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            base[k] = wsums_excl[(long long)blockIdx.x * 3 + k];
+            for (int w = SW - 1; w > wave; w--) base[k] += wwave[((long long)blockIdx.x * SW + w) * 3 + k];
+            if (suf != nullptr) base[k] += suf[k];          // bodies that follow this view
+        }
+    }
+#pragma unroll 4
     for (int t = ST - 1; t >= 0; t--) {
-        const long long i = (long long)blockIdx.x * SCHUNK + t * SB + threadIdx.x;
+        const long long i = seg + t * 64 + lane;
         const bool live = i < v.n;
-        double w[3] = {0., 0., 0.}, wt[3] = {0., 0., 0.};
-        if (live && !TOTAL) { w[0] = ldnt(wx, i); w[1] = ldnt(wy, i); w[2] = ldnt(wz, i); }
-        if (!TOTAL) block_scan<3, true>(w, wt, lds3);
+        double w[3] = {0., 0., 0.};
+        if (!TOTAL) {
+            if (live) { w[0] = ldnt(wx, i); w[1] = ldnt(wy, i); w[2] = ldnt(wz, i); }
+#pragma unroll
+            for (int k = 0; k < 3; k++) w[k] = wave_incl_scan_rev(w[k], lane);
+        }
         if (live) {
             double s0, s1, s2;
             if (TOTAL) { s0 = wtotals[0]; s1 = wtotals[1]; s2 = wtotals[2]; }
-            else {
-                s0 = w[0] + carry[0] + wsums_excl[(long long)blockIdx.x * 3 + 0];
-                s1 = w[1] + carry[1] + wsums_excl[(long long)blockIdx.x * 3 + 1];
-                s2 = w[2] + carry[2] + wsums_excl[(long long)blockIdx.x * 3 + 2];
-                if (suf != nullptr) { s0 += suf[0]; s1 += suf[1]; s2 += suf[2]; }     // bodies that follow this view
-            }
+            else { s0 = w[0] + base[0]; s1 = w[1] + base[1]; s2 = w[2] + base[2]; }
             v.ax[i] += ldnt(ajx, i) - s0; v.ay[i] += ldnt(ajy, i) - s1; v.az[i] += ldnt(ajz, i) - s2;
         }
-        carry[0] += wt[0]; carry[1] += wt[1]; carry[2] += wt[2];
+        if (!TOTAL) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) base[k] += lane_value(w[k], 0);
+        }
     }
 }
 
@@ -452,8 +504,10 @@ __global__ __launch_bounds__(SB) void gr_hamiltonian_main(View v, double G, doub
 // ------------------------------------------------------------------ host driver
 size_t scan_workspace_doubles(long long n) {
     const long long nb = (n + SB - 1) / SB;
+    const long long nbs = (n + SCHUNK - 1) / SCHUNK;
     // 9 body columns (newton, aJ, w) + compact list (4 doubles + 1 index) + workgroup sums (10 + 3 + 1) + totals
-    return (size_t)(9 * n + 5 * n + 14 * nb + 64);
+    // + wavefront sums of the weighted-sum passes
+    return (size_t)(9 * n + 5 * n + 14 * nb + 64 + 13 * SW * nbs);
 }
 
 hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, double* ws, unsigned* status, hipStream_t st) {
@@ -472,6 +526,8 @@ hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, 
     double* wtot = totals + 16;                             // 3
     double* count = wtot + 3;                               // 1
     const long long nbs = (n + SCHUNK - 1) / SCHUNK;        // workgroups of the weighted-sum passes
+    double* wavesums = count + 8;                           // nbs * SW * 10
+    double* wwave = wavesums + 10 * SW * nbs;               // nbs * SW * 3
     const dim3 g((unsigned)nb), gs((unsigned)nbs), b(SB);
     int kind = SCAN_GR;
     if (op.kind == REBXAMD_OP_MOF) kind = (op.iarg == REBX_COORDINATES_BARYCENTRIC) ? SCAN_MOF_BARY : SCAN_MOF_JACOBI;
@@ -481,24 +537,24 @@ hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, 
         hipLaunchKernelGGL(massive_compact, g, b, 0, st, v, fl, cx, cy, cz, cgm, cidx, G);
         if (exact) hipLaunchKernelGGL(newton_from_compact<true>, g, b, 0, st, v, cx, cy, cz, cgm, cidx, count, nax, nay, naz);
         else hipLaunchKernelGGL(newton_from_compact<false>, g, b, 0, st, v, cx, cy, cz, cgm, cidx, count, nax, nay, naz);
-        hipLaunchKernelGGL(scan_block_totals<10>, gs, b, 0, st, v, nax, nay, naz, bs);
+        hipLaunchKernelGGL(scan_block_totals<10>, gs, b, 0, st, v, nax, nay, naz, bs, wavesums);
         hipLaunchKernelGGL((scan_of_totals<10, false>), dim3(1), dim3(SOT), 0, st, bs, nbs, totals);
-        if (exact) hipLaunchKernelGGL((scan_main<SCAN_GR, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL, v.m);
-        else hipLaunchKernelGGL((scan_main<SCAN_GR, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL, v.m);
+        if (exact) hipLaunchKernelGGL((scan_main<SCAN_GR, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wx, wy, wz, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
+        else hipLaunchKernelGGL((scan_main<SCAN_GR, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wx, wy, wz, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
     } else {
-        hipLaunchKernelGGL(scan_block_totals<7>, gs, b, 0, st, v, nax, nay, naz, bs);
+        hipLaunchKernelGGL(scan_block_totals<7>, gs, b, 0, st, v, nax, nay, naz, bs, wavesums);
         hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(SOT), 0, st, bs, nbs, totals);
         if (kind == SCAN_MOF_JACOBI) {
-            if (exact) hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL, v.m);
-            else hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL, v.m);
+            if (exact) hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wx, wy, wz, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
+            else hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wx, wy, wz, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
         } else {
-            if (exact) hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL, v.m);
-            else hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, totals, ajx, ajy, ajz, wx, wy, wz, wsum, status, (const double*)nullptr, 1LL, v.m);
+            if (exact) hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wx, wy, wz, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
+            else hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wx, wy, wz, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
         }
     }
     hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(1), dim3(SOT), 0, st, wsum, nbs, wtot);
-    if (kind == SCAN_MOF_BARY) hipLaunchKernelGGL(scan_apply<true>, gs, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, wsum, wtot, (const double*)nullptr);
-    else hipLaunchKernelGGL(scan_apply<false>, gs, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, wsum, wtot, (const double*)nullptr);
+    if (kind == SCAN_MOF_BARY) hipLaunchKernelGGL(scan_apply<true>, gs, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, wsum, wwave, wtot, (const double*)nullptr);
+    else hipLaunchKernelGGL(scan_apply<false>, gs, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, wsum, wwave, wtot, (const double*)nullptr);
     return hipGetLastError();
 }
 
@@ -510,15 +566,17 @@ namespace rebxamd {
 // sub-view of one contiguous range (column pointers already offset, n = its length); `ws` is the
 // workspace slice that belongs to the same range (6 columns of v.n doubles, then block sums).
 static inline long long blocks_of(long long n) { return (n + SCHUNK - 1) / SCHUNK; }
-// (gr: 9 columns, 13 workgroup sums per weighted-sum workgroup, one flag total per compaction workgroup)
-size_t scan_range_doubles(long long n) { return (size_t)(9 * n + 13 * blocks_of(n) + (n + SB - 1) / SB + 32); }
+// (gr: 9 columns; per weighted-sum workgroup 10 + 3 sums and SW times as many wavefront sums; one flag total per
+// compaction workgroup)
+size_t scan_range_doubles(long long n) { return (size_t)(9 * n + 13 * (1 + SW) * blocks_of(n) + (n + SB - 1) / SB + 32); }
 
 // sums7 <- (m, m x, m y, m z, m vx, m vy, m vz) summed over the range
 hipError_t launch_range_sums(const View& v, double* ws, double* sums7, hipStream_t st) {
     if (v.n <= 0) return hipMemsetAsync(sums7, 0, 7 * sizeof(double), st);
     const long long nb = blocks_of(v.n);
     double* bs = ws + 6 * v.n;
-    hipLaunchKernelGGL(scan_block_totals<7>, dim3((unsigned)nb), dim3(SB), 0, st, v, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, bs);
+    hipLaunchKernelGGL(scan_block_totals<7>, dim3((unsigned)nb), dim3(SB), 0, st, v, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, bs,
+                       (double*)nullptr);
     hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(SOT), 0, st, bs, nb, sums7);
     return hipGetLastError();
 }
@@ -533,16 +591,18 @@ hipError_t launch_range_mof_forces(const View& v, const DevOp& op, double G, boo
     double* bs = wz + n;                    // nb * 7
     double* wsum = bs + 7 * nb;             // nb * 3
     double* scratch = wsum + 3 * nb;        // 16
+    double* wavesums = scratch + 16;        // nb * SW * 7
+    double* wwave = wavesums + 7 * SW * nb; // nb * SW * 3
     const dim3 g((unsigned)nb), b(SB);
     const double* none = nullptr;
-    hipLaunchKernelGGL(scan_block_totals<7>, g, b, 0, st, v, none, none, none, bs);
+    hipLaunchKernelGGL(scan_block_totals<7>, g, b, 0, st, v, none, none, none, bs, wavesums);
     hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(SOT), 0, st, bs, nb, scratch);
     if (barycentric)
-        hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), g, b, 0, st, v, op, G, none, none, none, (const double*)bs, before7, ajx, ajy, ajz, wx, wy, wz, wsum,
-                           (unsigned*)nullptr, none, 0LL, v.m);
+        hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), g, b, 0, st, v, op, G, none, none, none, (const double*)bs, (const double*)wavesums, before7, ajx, ajy, ajz, wx, wy, wz, wsum,
+                           wwave, (unsigned*)nullptr, none, 0LL, v.m);
     else
-        hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), g, b, 0, st, v, op, G, none, none, none, (const double*)bs, (const double*)scratch, ajx, ajy, ajz, wx, wy, wz, wsum,
-                           (unsigned*)nullptr, before7, starts_at_origin ? 1LL : 0LL, v.m);
+        hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), g, b, 0, st, v, op, G, none, none, none, (const double*)bs, (const double*)wavesums, (const double*)scratch, ajx, ajy, ajz, wx, wy, wz, wsum,
+                           wwave, (unsigned*)nullptr, before7, starts_at_origin ? 1LL : 0LL, v.m);
     hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(1), dim3(SOT), 0, st, wsum, nb, push3);
     return hipGetLastError();
 }
@@ -554,21 +614,23 @@ hipError_t launch_range_mof_apply(const View& v, bool barycentric, const double*
     const long long n = v.n, nb = blocks_of(n);
     double* ajx = ws; double* ajy = ajx + n; double* ajz = ajy + n; double* wx = ajz + n; double* wy = wx + n; double* wz = wy + n;
     double* wsum = wz + n + 7 * nb;
+    double* wwave = wsum + 3 * nb + 16 + 7 * SW * nb;
     const dim3 g((unsigned)nb), b(SB);
-    if (barycentric) hipLaunchKernelGGL(scan_apply<true>, g, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, (const double*)wsum, after3, (const double*)nullptr);
-    else hipLaunchKernelGGL(scan_apply<false>, g, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, (const double*)wsum, (const double*)nullptr, after3);
+    if (barycentric) hipLaunchKernelGGL(scan_apply<true>, g, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, (const double*)wsum, (const double*)wwave, after3, (const double*)nullptr);
+    else hipLaunchKernelGGL(scan_apply<false>, g, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, (const double*)wsum, (const double*)wwave, (const double*)nullptr, after3);
     return hipGetLastError();
 }
 
 // ---- pieces of gr for particle shards.  Range workspace: Newtonian acc (3 columns), own
 // post-Newtonian acc (3), weighted reactions (3), workgroup sums (10 + 3 per workgroup), flag totals.
-struct GrRange { double *nax, *nay, *naz, *ajx, *ajy, *ajz, *wx, *wy, *wz, *bs, *wsum, *fl, *scratch; };
+struct GrRange { double *nax, *nay, *naz, *ajx, *ajy, *ajz, *wx, *wy, *wz, *bs, *wsum, *fl, *scratch, *wavesums, *wwave; };
 static GrRange gr_range(double* ws, long long n) {
     GrRange r;
     const long long nb = blocks_of(n);
     r.nax = ws; r.nay = r.nax + n; r.naz = r.nay + n; r.ajx = r.naz + n; r.ajy = r.ajx + n; r.ajz = r.ajy + n;
     r.wx = r.ajz + n; r.wy = r.wx + n; r.wz = r.wy + n;
     r.bs = r.wz + n; r.wsum = r.bs + 10 * nb; r.fl = r.wsum + 3 * nb; r.scratch = r.fl + (n + SB - 1) / SB;
+    r.wavesums = r.scratch + 32; r.wwave = r.wavesums + 10 * SW * nb;
     return r;
 }
 
@@ -592,7 +654,7 @@ hipError_t launch_range_gr_newton(const View& v, const double* rec, long long M,
     if (exact) hipLaunchKernelGGL(newton_from_records<true>, g, b, 0, st, v, rec, M, id0, r.nax, r.nay, r.naz);
     else hipLaunchKernelGGL(newton_from_records<false>, g, b, 0, st, v, rec, M, id0, r.nax, r.nay, r.naz);
     const long long nb = blocks_of(v.n);
-    hipLaunchKernelGGL(scan_block_totals<10>, dim3((unsigned)nb), b, 0, st, v, (const double*)r.nax, (const double*)r.nay, (const double*)r.naz, r.bs);
+    hipLaunchKernelGGL(scan_block_totals<10>, dim3((unsigned)nb), b, 0, st, v, (const double*)r.nax, (const double*)r.nay, (const double*)r.naz, r.bs, r.wavesums);
     hipLaunchKernelGGL((scan_of_totals<10, false>), dim3(1), dim3(SOT), 0, st, r.bs, nb, sums10);
     return hipGetLastError();
 }
@@ -609,9 +671,9 @@ hipError_t launch_range_gr_forces(const View& v, const DevOp& op, double G, bool
     const dim3 g((unsigned)nb), b(SB);
     const long long first = starts_at_origin ? 1LL : 0LL;
     if (exact) hipLaunchKernelGGL((scan_main<SCAN_GR, true>), g, b, 0, st, v, op, G, (const double*)r.nax, (const double*)r.nay, (const double*)r.naz, (const double*)r.bs,
-                                  (const double*)r.scratch, r.ajx, r.ajy, r.ajz, r.wx, r.wy, r.wz, r.wsum, status, before10, first, m0);
+                                  (const double*)r.wavesums, (const double*)r.scratch, r.ajx, r.ajy, r.ajz, r.wx, r.wy, r.wz, r.wsum, r.wwave, status, before10, first, m0);
     else hipLaunchKernelGGL((scan_main<SCAN_GR, false>), g, b, 0, st, v, op, G, (const double*)r.nax, (const double*)r.nay, (const double*)r.naz, (const double*)r.bs,
-                            (const double*)r.scratch, r.ajx, r.ajy, r.ajz, r.wx, r.wy, r.wz, r.wsum, status, before10, first, m0);
+                            (const double*)r.wavesums, (const double*)r.scratch, r.ajx, r.ajy, r.ajz, r.wx, r.wy, r.wz, r.wsum, r.wwave, status, before10, first, m0);
     hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(1), dim3(SOT), 0, st, r.wsum, nb, push3);
     return hipGetLastError();
 }
@@ -621,7 +683,7 @@ hipError_t launch_range_gr_apply(const View& v, const double* after3, double* ws
     if (v.n <= 0) return hipSuccess;
     const GrRange r = gr_range(ws, v.n);
     hipLaunchKernelGGL(scan_apply<false>, dim3((unsigned)blocks_of(v.n)), dim3(SB), 0, st, v, (const double*)r.ajx, (const double*)r.ajy, (const double*)r.ajz,
-                       (const double*)r.wx, (const double*)r.wy, (const double*)r.wz, (const double*)r.wsum, (const double*)nullptr, after3);
+                       (const double*)r.wx, (const double*)r.wy, (const double*)r.wz, (const double*)r.wsum, (const double*)r.wwave, (const double*)nullptr, after3);
     return hipGetLastError();
 }
 
@@ -644,7 +706,7 @@ hipError_t launch_gr_hamiltonian(const View& v, double G, double c, double* ws, 
     hipLaunchKernelGGL((scan_of_totals<1, false>), dim3(1), dim3(SOT), 0, st, fl, nb, count);
     hipLaunchKernelGGL(massive_compact, g, b, 0, st, v, fl, cx, cy, cz, cgm, cidx, G);
     hipLaunchKernelGGL(newton_pot_from_compact, g, b, 0, st, v, cx, cy, cz, cgm, cidx, count, pot);
-    hipLaunchKernelGGL(scan_block_totals<7>, gs, b, 0, st, v, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, bs);
+    hipLaunchKernelGGL(scan_block_totals<7>, gs, b, 0, st, v, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, bs, (double*)nullptr);
     hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(SOT), 0, st, bs, nbs, totals);
     hipLaunchKernelGGL(gr_hamiltonian_main, gs, b, 0, st, v, G, c * c, pot, bs, totals, part);
     hipLaunchKernelGGL((scan_of_totals<3, false>), dim3(1), dim3(SOT), 0, st, part, nbs, out);
