@@ -178,6 +178,24 @@ __global__ __launch_bounds__(SOT) void scan_of_totals(double* blocksums, long lo
     }
 }
 
+// What the per-body pass reads of one body (zeros / unset behind the end of the view).
+template <bool WITH_ACC>
+struct ScanRaw {
+    double m, x, y, z, vx, vy, vz, ta, te, ti, nx, ny, nz;
+    __device__ __forceinline__ void load(const View& v, const double* nax, const double* nay, const double* naz, long long i) {
+        const double nan = __builtin_nan("");
+        m = x = y = z = vx = vy = vz = nx = ny = nz = 0.;
+        ta = te = ti = nan;
+        if (i < v.n) {
+            m = ldnt(v.m, i); x = ldnt(v.x, i); y = ldnt(v.y, i); z = ldnt(v.z, i); vx = ldnt(v.vx, i); vy = ldnt(v.vy, i); vz = ldnt(v.vz, i);
+            if (v.ta) ta = ldnt(v.ta, i);
+            if (v.te) te = ldnt(v.te, i);
+            if (v.ti) ti = ldnt(v.ti, i);
+            if (WITH_ACC) { nx = ldnt(nax, i); ny = ldnt(nay, i); nz = ldnt(naz, i); }
+        }
+    }
+};
+
 // pass 3: per-body force in its own frame (aJ) and its weighted reaction (w); totals of w per
 // wavefront segment (wwave) and per workgroup (wsums)
 template <int KIND, bool EXACT>
@@ -200,13 +218,19 @@ __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, cons
             if (pre != nullptr) base[c] += pre[c];          // bodies that precede this view (other shards, the head)
         }
     }
+    // the inputs of the next tile are requested before the current one is worked on
+    ScanRaw<KIND == SCAN_GR> cur, nxt;
+    cur.load(v, nax, nay, naz, seg + lane);
+    nxt = cur;
     for (int t = 0; t < ST; t++) {
         const long long i = seg + t * 64 + lane;
         const bool live = i < v.n;
+        if (t + 1 < ST) nxt.load(v, nax, nay, naz, i + 64);
         double q[C], own[C];
-#pragma unroll
-        for (int c = 0; c < C; c++) q[c] = 0.;
-        if (live) weighted_state<C>(v, nax, nay, naz, i, q);
+        q[0] = cur.m;
+        q[1] = cur.m * cur.x; q[2] = cur.m * cur.y; q[3] = cur.m * cur.z;
+        q[4] = cur.m * cur.vx; q[5] = cur.m * cur.vy; q[6] = cur.m * cur.vz;
+        if constexpr (C == 10) { q[7] = cur.m * cur.nx; q[8] = cur.m * cur.ny; q[9] = cur.m * cur.nz; }
 #pragma unroll
         for (int c = 0; c < C; c++) { own[c] = q[c]; if (KIND != SCAN_MOF_BARY) q[c] = wave_incl_scan(q[c], lane); }
         if (live) {
@@ -217,16 +241,16 @@ __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, cons
             for (int c = 0; c < C; c++) S[c] = (KIND == SCAN_MOF_BARY) ? totals[c] : base[c] + (q[c] - own[c]);
             const double eta = S[0], mi = own[0];
             Part p;
-            p.x = ldnt(v.x, i); p.y = ldnt(v.y, i); p.z = ldnt(v.z, i); p.vx = ldnt(v.vx, i); p.vy = ldnt(v.vy, i); p.vz = ldnt(v.vz, i); p.m = mi;
+            p.x = cur.x; p.y = cur.y; p.z = cur.z; p.vx = cur.vx; p.vy = cur.vy; p.vz = cur.vz; p.m = mi;
             p.beta = p.Rt = p.k1 = __builtin_nan("");
-            p.ta = v.ta ? ldnt(v.ta, i) : __builtin_nan(""); p.te = v.te ? ldnt(v.te, i) : __builtin_nan(""); p.ti = v.ti ? ldnt(v.ti, i) : __builtin_nan("");
+            p.ta = cur.ta; p.te = cur.te; p.ti = cur.ti;
             if constexpr (KIND == SCAN_GR) {
                 if (i >= first_acting) {
                     const double ei = 1. / eta;
                     Jac j;
                     j.x = p.x - S[1] * ei; j.y = p.y - S[2] * ei; j.z = p.z - S[3] * ei;
                     j.vx = p.vx - S[4] * ei; j.vy = p.vy - S[5] * ei; j.vz = p.vz - S[6] * ei;
-                    j.ax = nax[i] - S[7] * ei; j.ay = nay[i] - S[8] * ei; j.az = naz[i] - S[9] * ei;
+                    j.ax = cur.nx - S[7] * ei; j.ay = cur.ny - S[8] * ei; j.az = cur.nz - S[9] * ei;
                     const double mu = G * m0[0];       // body 0 of the whole system (the view may be a range behind it)
                     const int it = EXACT ? gr_term_exact(j, mu, op.c, op.iarg, a)
                                          : gr_term_fast(j, fast_rsqrt(j.x * j.x + j.y * j.y + j.z * j.z), mu, op.d, op.iarg, a);
@@ -253,6 +277,7 @@ __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, cons
 #pragma unroll
             for (int c = 0; c < C; c++) base[c] += lane_value(q[c], 63);
         }
+        cur = nxt;
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) wacc[k] = wave_total(wacc[k], lane);
