@@ -16,6 +16,7 @@
 //     the compact list in LDS tiles -> O(N * massive).
 // Sums are evaluated as parallel scans, so results differ from the sequential reference at
 // rounding level (the 1e-12 bar), in either arithmetic mode.
+#include <type_traits>
 #include "internal.h"
 #include "effects.h"
 #include "wave_ops.h"
@@ -132,50 +133,49 @@ __global__ __launch_bounds__(SB) void scan_block_totals(View v, const double* na
     }
 }
 
-// (512 threads: ten running sums per thread in three copies fit the register file without spilling)
 static constexpr int SOT = 512;
-// pass 2: exclusive scan of the workgroup totals, in place, by ONE workgroup; totals[c] = grand total.
+// pass 2: exclusive scan of the workgroup totals (rows of C doubles), in place; totals[c] = grand total.
+// One workgroup per component (grid = C): the scan of a column is a chain of rounds of SOT rows, and
+// a round costs instructions in proportion to the components it carries.  A thread owns one row of
+// the round; the next round's value is requested before the current one is scanned.
+// Scan order: row 0 first, or the last row first when REVERSE.
+// Whole rounds run without a branch around their load and store, and the first one stands outside
+// the loop: every way into the loop then has the same memory operations behind it, and the wait for
+// the requested value does not also wait for the stores issued after the request.
 template <int C, bool REVERSE>
-__global__ __launch_bounds__(SOT) void scan_of_totals(double* blocksums, long long nb, double* totals) {
-    __shared__ double lds[SOT / 64][C];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const long long chunk = (nb + SOT - 1) / SOT;
-    long long b0 = (long long)tid * chunk, b1 = b0 + chunk;
-    if (b0 > nb) b0 = nb;
-    if (b1 > nb) b1 = nb;
-    if (REVERSE) { const long long t0 = nb - b1, t1 = nb - b0; b0 = t0; b1 = t1; }     // thread 0 owns the last rows
-    double local[C];
-#pragma unroll
-    for (int c = 0; c < C; c++) local[c] = 0.;
-    for (long long b = b0; b < b1; b++)
-#pragma unroll
-        for (int c = 0; c < C; c++) local[c] += blocksums[b * C + c];
-    // exclusive scan of `local` over threads (thread order = scan order in both directions)
-    double incl[C];
-#pragma unroll
-    for (int c = 0; c < C; c++) incl[c] = wave_incl_scan(local[c], lane);
-    if (lane == 63) {
-#pragma unroll
-        for (int c = 0; c < C; c++) lds[wave][c] = incl[c];
-    }
-    __syncthreads();
-    double run[C];
-#pragma unroll
-    for (int c = 0; c < C; c++) {
+__global__ __launch_bounds__(SOT) void scan_of_totals(double* table, long long nb, double* totals) {
+    __shared__ double wtot[2][SOT / 64];
+    const int c = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long long nfull = nb / SOT;
+    const bool tail = nfull * SOT < nb;
+    // address of this thread's row in round s (the last row of the scan when there is none)
+    auto at = [&](long long s) -> double* {
+        long long r = s * SOT + tid;
+        if (r > nb - 1) r = nb - 1;
+        return table + (REVERSE ? nb - 1 - r : r) * C + c;
+    };
+    double carry = 0., ahead = 0.;
+    auto round = [&](long long s, auto whole) {
+        const bool live = decltype(whole)::value || s * SOT + tid < nb;
+        const double v = live ? ahead : 0.;
+        double* const mine = at(s);
+        ahead = *at(s + 1);
+        const double incl = wave_incl_scan(v, lane);
+        double* const wt = wtot[s & 1];                 // two copies: one barrier per round
+        if (lane == 63) wt[wave] = incl;
+        lds_barrier();
         double before = 0., all = 0.;
-        for (int w = 0; w < SOT / 64; w++) { const double t = lds[w][c]; all += t; if (w < wave) before += t; }
-        run[c] = incl[c] - local[c] + before;
-        if (tid == 0) totals[c] = all;
-    }
-    if (!REVERSE) {
-        for (long long b = b0; b < b1; b++)
 #pragma unroll
-            for (int c = 0; c < C; c++) { const double t = blocksums[b * C + c]; blocksums[b * C + c] = run[c]; run[c] += t; }
-    } else {
-        for (long long b = b1 - 1; b >= b0; b--)
-#pragma unroll
-            for (int c = 0; c < C; c++) { const double t = blocksums[b * C + c]; blocksums[b * C + c] = run[c]; run[c] += t; }
-    }
+        for (int w = 0; w < SOT / 64; w++) { const double t = wt[w]; all += t; if (w < wave) before += t; }
+        if (live) *mine = carry + before + (incl - v);
+        carry += all;
+    };
+    if (nb > 0) ahead = *at(0);
+    if (nfull > 0) round(0, std::true_type());
+#pragma unroll 1
+    for (long long s = 1; s < nfull; s++) round(s, std::true_type());
+    if (tail) round(nfull, std::false_type());
+    if (tid == 0) totals[c] = carry;
 }
 
 // What the per-body pass reads of one body (zeros / unset behind the end of the view).
@@ -563,12 +563,12 @@ hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, 
         if (exact) hipLaunchKernelGGL(newton_from_compact<true>, g, b, 0, st, v, cx, cy, cz, cgm, cidx, count, nax, nay, naz);
         else hipLaunchKernelGGL(newton_from_compact<false>, g, b, 0, st, v, cx, cy, cz, cgm, cidx, count, nax, nay, naz);
         hipLaunchKernelGGL(scan_block_totals<10>, gs, b, 0, st, v, nax, nay, naz, bs, wavesums);
-        hipLaunchKernelGGL((scan_of_totals<10, false>), dim3(1), dim3(SOT), 0, st, bs, nbs, totals);
+        hipLaunchKernelGGL((scan_of_totals<10, false>), dim3(10), dim3(SOT), 0, st, bs, nbs, totals);
         if (exact) hipLaunchKernelGGL((scan_main<SCAN_GR, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wx, wy, wz, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
         else hipLaunchKernelGGL((scan_main<SCAN_GR, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wx, wy, wz, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
     } else {
         hipLaunchKernelGGL(scan_block_totals<7>, gs, b, 0, st, v, nax, nay, naz, bs, wavesums);
-        hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(SOT), 0, st, bs, nbs, totals);
+        hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(7), dim3(SOT), 0, st, bs, nbs, totals);
         if (kind == SCAN_MOF_JACOBI) {
             if (exact) hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wx, wy, wz, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
             else hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wx, wy, wz, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
@@ -577,7 +577,7 @@ hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, 
             else hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wx, wy, wz, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
         }
     }
-    hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(1), dim3(SOT), 0, st, wsum, nbs, wtot);
+    hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(3), dim3(SOT), 0, st, wsum, nbs, wtot);
     if (kind == SCAN_MOF_BARY) hipLaunchKernelGGL(scan_apply<true>, gs, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, wsum, wwave, wtot, (const double*)nullptr);
     else hipLaunchKernelGGL(scan_apply<false>, gs, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, wsum, wwave, wtot, (const double*)nullptr);
     return hipGetLastError();
@@ -602,7 +602,7 @@ hipError_t launch_range_sums(const View& v, double* ws, double* sums7, hipStream
     double* bs = ws + 6 * v.n;
     hipLaunchKernelGGL(scan_block_totals<7>, dim3((unsigned)nb), dim3(SB), 0, st, v, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, bs,
                        (double*)nullptr);
-    hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(SOT), 0, st, bs, nb, sums7);
+    hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(7), dim3(SOT), 0, st, bs, nb, sums7);
     return hipGetLastError();
 }
 
@@ -621,14 +621,14 @@ hipError_t launch_range_mof_forces(const View& v, const DevOp& op, double G, boo
     const dim3 g((unsigned)nb), b(SB);
     const double* none = nullptr;
     hipLaunchKernelGGL(scan_block_totals<7>, g, b, 0, st, v, none, none, none, bs, wavesums);
-    hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(SOT), 0, st, bs, nb, scratch);
+    hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(7), dim3(SOT), 0, st, bs, nb, scratch);
     if (barycentric)
         hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), g, b, 0, st, v, op, G, none, none, none, (const double*)bs, (const double*)wavesums, before7, ajx, ajy, ajz, wx, wy, wz, wsum,
                            wwave, (unsigned*)nullptr, none, 0LL, v.m);
     else
         hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), g, b, 0, st, v, op, G, none, none, none, (const double*)bs, (const double*)wavesums, (const double*)scratch, ajx, ajy, ajz, wx, wy, wz, wsum,
                            wwave, (unsigned*)nullptr, before7, starts_at_origin ? 1LL : 0LL, v.m);
-    hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(1), dim3(SOT), 0, st, wsum, nb, push3);
+    hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(3), dim3(SOT), 0, st, wsum, nb, push3);
     return hipGetLastError();
 }
 
@@ -680,7 +680,7 @@ hipError_t launch_range_gr_newton(const View& v, const double* rec, long long M,
     else hipLaunchKernelGGL(newton_from_records<false>, g, b, 0, st, v, rec, M, id0, r.nax, r.nay, r.naz);
     const long long nb = blocks_of(v.n);
     hipLaunchKernelGGL(scan_block_totals<10>, dim3((unsigned)nb), b, 0, st, v, (const double*)r.nax, (const double*)r.nay, (const double*)r.naz, r.bs, r.wavesums);
-    hipLaunchKernelGGL((scan_of_totals<10, false>), dim3(1), dim3(SOT), 0, st, r.bs, nb, sums10);
+    hipLaunchKernelGGL((scan_of_totals<10, false>), dim3(10), dim3(SOT), 0, st, r.bs, nb, sums10);
     return hipGetLastError();
 }
 
@@ -699,7 +699,7 @@ hipError_t launch_range_gr_forces(const View& v, const DevOp& op, double G, bool
                                   (const double*)r.wavesums, (const double*)r.scratch, r.ajx, r.ajy, r.ajz, r.wx, r.wy, r.wz, r.wsum, r.wwave, status, before10, first, m0);
     else hipLaunchKernelGGL((scan_main<SCAN_GR, false>), g, b, 0, st, v, op, G, (const double*)r.nax, (const double*)r.nay, (const double*)r.naz, (const double*)r.bs,
                             (const double*)r.wavesums, (const double*)r.scratch, r.ajx, r.ajy, r.ajz, r.wx, r.wy, r.wz, r.wsum, r.wwave, status, before10, first, m0);
-    hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(1), dim3(SOT), 0, st, r.wsum, nb, push3);
+    hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(3), dim3(SOT), 0, st, r.wsum, nb, push3);
     return hipGetLastError();
 }
 
@@ -732,9 +732,9 @@ hipError_t launch_gr_hamiltonian(const View& v, double G, double c, double* ws, 
     hipLaunchKernelGGL(massive_compact, g, b, 0, st, v, fl, cx, cy, cz, cgm, cidx, G);
     hipLaunchKernelGGL(newton_pot_from_compact, g, b, 0, st, v, cx, cy, cz, cgm, cidx, count, pot);
     hipLaunchKernelGGL(scan_block_totals<7>, gs, b, 0, st, v, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, bs, (double*)nullptr);
-    hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(1), dim3(SOT), 0, st, bs, nbs, totals);
+    hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(7), dim3(SOT), 0, st, bs, nbs, totals);
     hipLaunchKernelGGL(gr_hamiltonian_main, gs, b, 0, st, v, G, c * c, pot, bs, totals, part);
-    hipLaunchKernelGGL((scan_of_totals<3, false>), dim3(1), dim3(SOT), 0, st, part, nbs, out);
+    hipLaunchKernelGGL((scan_of_totals<3, false>), dim3(3), dim3(SOT), 0, st, part, nbs, out);
     return hipGetLastError();
 }
 

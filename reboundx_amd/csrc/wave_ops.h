@@ -45,6 +45,11 @@ __device__ __forceinline__ double wave_incl_scan_rev(double v, int lane) {
     return v;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global load
+// and store the wavefront has in flight, which turns a loop with requests issued ahead into a chain
+// of memory round trips; use this one when the barrier protects LDS contents alone.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Sum over the wavefront (the same value in every lane).
 __device__ __forceinline__ double wave_total(double v, int lane) { return lane_value(wave_incl_scan(v, lane), 63); }
 

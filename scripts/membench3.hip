@@ -2,6 +2,7 @@
 // arithmetic between the loads and the stores (development aid).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 typedef double d2 __attribute__((ext_vector_type(2)));
 struct Cols { const double* in[7]; double* a[3]; long long n; };
@@ -63,8 +64,8 @@ float timeit(F f, int reps) {
     return ms / reps * 1e3f;
 }
 
-int main() {
-    const long long n = 10000000;
+int main(int argc, char** argv) {
+    const long long n = argc > 1 ? (long long)atof(argv[1]) : 10000000;  // optional argument: number of particles
     Cols c; c.n = n;
     for (int q = 0; q < 7; q++) { double* p; CK(hipMalloc(&p, n * 8)); CK(hipMemset(p, 0, n * 8)); c.in[q] = p; }
     for (int q = 0; q < 3; q++) { CK(hipMalloc(&c.a[q], n * 8)); CK(hipMemset(c.a[q], 0, n * 8)); }
