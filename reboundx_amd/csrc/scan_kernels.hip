@@ -101,17 +101,30 @@ __global__ __launch_bounds__(SB) void scan_block_totals(View v, const double* na
     __shared__ double lds[SW][C];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long seg = segment_start(wave);
-    double acc[C];
+    double acc[C], cur[C], nxt[C];
 #pragma unroll
     for (int c = 0; c < C; c++) acc[c] = 0.;
-    for (int t = 0; t < ST; t++) {
-        const long long i = seg + t * 64 + lane;
-        if (i < v.n) {
-            double q[C];
-            weighted_state<C>(v, nax, nay, naz, i, q);
+    // Loads carry no branch (rows behind the end read the last body and are masked afterwards) and
+    // the next tile is requested before the current one is added up: a tile's loads then leave
+    // together instead of one by one, each waited for.
+    const long long last = v.n - 1;
+    auto request = [&](int t, double (&raw)[C]) {
+        const long long i = seg + t * 64 + lane, ic = i < v.n ? i : last;
+        raw[0] = ldnt(v.m, ic);
+        raw[1] = ldnt(v.x, ic); raw[2] = ldnt(v.y, ic); raw[3] = ldnt(v.z, ic);
+        raw[4] = ldnt(v.vx, ic); raw[5] = ldnt(v.vy, ic); raw[6] = ldnt(v.vz, ic);
+        if constexpr (C == 10) { raw[7] = ldnt(nax, ic); raw[8] = ldnt(nay, ic); raw[9] = ldnt(naz, ic); }
+    };
+    request(0, cur);
 #pragma unroll
-            for (int c = 0; c < C; c++) acc[c] += q[c];
-        }
+    for (int t = 0; t < ST; t++) {
+        if (t + 1 < ST) request(t + 1, nxt);
+        const double m = seg + t * 64 + lane < v.n ? cur[0] : 0.;
+        acc[0] += m;
+#pragma unroll
+        for (int c = 1; c < C; c++) acc[c] += m * cur[c];
+#pragma unroll
+        for (int c = 0; c < C; c++) cur[c] = nxt[c];
     }
 #pragma unroll
     for (int c = 0; c < C; c++) acc[c] = wave_total(acc[c], lane);
