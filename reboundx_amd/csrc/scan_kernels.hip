@@ -209,12 +209,18 @@ struct ScanRaw {
     }
 };
 
+// reaction of a body's force on the bodies before it, rounded the same way wherever it is formed
+__device__ __forceinline__ double reaction(double f, double a) {
+#pragma clang fp contract(off)
+    return f * a;
+}
+
 // pass 3: per-body force in its own frame (aJ) and its weighted reaction (w); totals of w per
 // wavefront segment (wwave) and per workgroup (wsums)
 template <int KIND, bool EXACT>
 __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, const double* nax, const double* nay, const double* naz,
                                                 const double* blocksums, const double* wavesums, const double* totals,
-                                                double* ajx, double* ajy, double* ajz, double* wx, double* wy, double* wz,
+                                                double* ajx, double* ajy, double* ajz, double* wf,
                                                 double* wsums, double* wwave, unsigned* status, const double* pre, long long first_acting, const double* m0) {
     constexpr int C = (KIND == SCAN_GR) ? 10 : 7;
     __shared__ double lds3[SW][3];
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, cons
         for (int c = 0; c < C; c++) { own[c] = q[c]; if (KIND != SCAN_MOF_BARY) q[c] = wave_incl_scan(q[c], lane); }
         if (live) {
             V3 a = {0., 0., 0.};
-            double w[3] = {0., 0., 0.};
+            double f = 0.;      // share of the body's force that falls back on the bodies before it
             double S[C];        // exclusive prefix (bodies before i), or the grand total for barycentric
 #pragma unroll
             for (int c = 0; c < C; c++) S[c] = (KIND == SCAN_MOF_BARY) ? totals[c] : base[c] + (q[c] - own[c]);
@@ -268,8 +274,7 @@ __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, cons
                     const int it = EXACT ? gr_term_exact(j, mu, op.c, op.iarg, a)
                                          : gr_term_fast(j, fast_rsqrt(j.x * j.x + j.y * j.y + j.z * j.z), mu, op.d, op.iarg, a);
                     if (it == 10) atomicOr(status, WARN_GR_ITER);
-                    const double f = mi / (eta + mi);
-                    w[0] = f * a.x; w[1] = f * a.y; w[2] = f * a.z;
+                    f = mi / (eta + mi);
                 }
             } else {
                 const bool acts = (KIND == SCAN_MOF_BARY) || i >= first_acting;
@@ -278,13 +283,14 @@ __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, cons
                     const double inv = eta > 0. ? 1. / eta : 1.;
                     ref.x = S[1] * inv; ref.y = S[2] * inv; ref.z = S[3] * inv; ref.vx = S[4] * inv; ref.vy = S[5] * inv; ref.vz = S[6] * inv; ref.m = eta;
                     if (EXACT) mof_exact(p, ref, a); else mof_fast(p, ref, a);
-                    const double f = (KIND == SCAN_MOF_BARY) ? mi / eta : mi / (eta + mi);
-                    w[0] = f * a.x; w[1] = f * a.y; w[2] = f * a.z;
+                    f = (KIND == SCAN_MOF_BARY) ? mi / eta : mi / (eta + mi);
                 }
             }
+            // the reaction itself (f times the force) is not stored: the last pass forms it again
+            // from these four numbers, with the same rounding
             __builtin_nontemporal_store(a.x, ajx + i); __builtin_nontemporal_store(a.y, ajy + i); __builtin_nontemporal_store(a.z, ajz + i);
-            __builtin_nontemporal_store(w[0], wx + i); __builtin_nontemporal_store(w[1], wy + i); __builtin_nontemporal_store(w[2], wz + i);
-            wacc[0] += w[0]; wacc[1] += w[1]; wacc[2] += w[2];
+            if (KIND != SCAN_MOF_BARY) __builtin_nontemporal_store(f, wf + i);
+            wacc[0] += reaction(f, a.x); wacc[1] += reaction(f, a.y); wacc[2] += reaction(f, a.z);
         }
         if (KIND != SCAN_MOF_BARY) {
 #pragma unroll
@@ -309,10 +315,11 @@ __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, cons
     }
 }
 
-// pass 5: a_i += aJ_i - (sum of w over bodies k >= i)   [barycentric: over all bodies]
+// pass 5: a_i += aJ_i - (sum of the reactions of bodies k >= i)   [barycentric: of all bodies]
+// A tile's loads carry no branch (rows behind the end read the last body and are masked) and the
+// next tile is requested before the current one is worked on.
 template <bool TOTAL>
-__global__ __launch_bounds__(SB) void scan_apply(View v, const double* ajx, const double* ajy, const double* ajz,
-                                                 const double* wx, const double* wy, const double* wz,
+__global__ __launch_bounds__(SB) void scan_apply(View v, const double* ajx, const double* ajy, const double* ajz, const double* wf,
                                                  const double* wsums_excl, const double* wwave, const double* wtotals, const double* suf) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long seg = segment_start(wave);
@@ -325,26 +332,39 @@ __global__ __launch_bounds__(SB) void scan_apply(View v, const double* ajx, cons
             if (suf != nullptr) base[k] += suf[k];          // bodies that follow this view
         }
     }
-#pragma unroll 4
+    double tot[3] = {0., 0., 0.};
+    if (TOTAL) { tot[0] = wtotals[0]; tot[1] = wtotals[1]; tot[2] = wtotals[2]; }
+    const long long last = v.n - 1;
+    double cur[7], nxt[7];
+    auto request = [&](int t, double (&r)[7]) {
+        const long long i = seg + t * 64 + lane, ic = i < v.n ? i : last;
+        r[0] = ldnt(ajx, ic); r[1] = ldnt(ajy, ic); r[2] = ldnt(ajz, ic);
+        r[3] = v.ax[ic]; r[4] = v.ay[ic]; r[5] = v.az[ic];
+        r[6] = TOTAL ? 0. : ldnt(wf, ic);
+    };
+    request(ST - 1, cur);
+#pragma unroll
     for (int t = ST - 1; t >= 0; t--) {
+        if (t > 0) request(t - 1, nxt);
         const long long i = seg + t * 64 + lane;
         const bool live = i < v.n;
         double w[3] = {0., 0., 0.};
         if (!TOTAL) {
-            if (live) { w[0] = ldnt(wx, i); w[1] = ldnt(wy, i); w[2] = ldnt(wz, i); }
 #pragma unroll
-            for (int k = 0; k < 3; k++) w[k] = wave_incl_scan_rev(w[k], lane);
+            for (int k = 0; k < 3; k++) w[k] = wave_incl_scan_rev(live ? reaction(cur[6], cur[k]) : 0., lane);
         }
         if (live) {
             double s0, s1, s2;
-            if (TOTAL) { s0 = wtotals[0]; s1 = wtotals[1]; s2 = wtotals[2]; }
+            if (TOTAL) { s0 = tot[0]; s1 = tot[1]; s2 = tot[2]; }
             else { s0 = w[0] + base[0]; s1 = w[1] + base[1]; s2 = w[2] + base[2]; }
-            v.ax[i] += ldnt(ajx, i) - s0; v.ay[i] += ldnt(ajy, i) - s1; v.az[i] += ldnt(ajz, i) - s2;
+            v.ax[i] = cur[3] + (cur[0] - s0); v.ay[i] = cur[4] + (cur[1] - s1); v.az[i] = cur[5] + (cur[2] - s2);
         }
         if (!TOTAL) {
 #pragma unroll
             for (int k = 0; k < 3; k++) base[k] += lane_value(w[k], 0);
         }
+#pragma unroll
+        for (int k = 0; k < 7; k++) cur[k] = nxt[k];
     }
 }
 
@@ -543,9 +563,9 @@ __global__ __launch_bounds__(SB) void gr_hamiltonian_main(View v, double G, doub
 size_t scan_workspace_doubles(long long n) {
     const long long nb = (n + SB - 1) / SB;
     const long long nbs = (n + SCHUNK - 1) / SCHUNK;
-    // 9 body columns (newton, aJ, w) + compact list (4 doubles + 1 index) + workgroup sums (10 + 3 + 1) + totals
+    // 7 body columns (newton 3, aJ 3, reaction share 1) + compact list (4 doubles + 1 index) + workgroup sums (10 + 3 + 1) + totals
     // + wavefront sums of the weighted-sum passes
-    return (size_t)(9 * n + 5 * n + 14 * nb + 64 + 13 * SW * nbs);
+    return (size_t)(7 * n + 5 * n + 14 * nb + 64 + 13 * SW * nbs);
 }
 
 hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, double* ws, unsigned* status, hipStream_t st) {
@@ -554,8 +574,8 @@ hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, 
     const long long nb = (n + SB - 1) / SB;
     double* nax = ws; double* nay = nax + n; double* naz = nay + n;
     double* ajx = naz + n; double* ajy = ajx + n; double* ajz = ajy + n;
-    double* wx = ajz + n; double* wy = wx + n; double* wz = wy + n;
-    double* cx = wz + n; double* cy = cx + n; double* cz = cy + n; double* cgm = cz + n;
+    double* wf = ajz + n;
+    double* cx = wf + n; double* cy = cx + n; double* cz = cy + n; double* cgm = cz + n;
     long long* cidx = reinterpret_cast<long long*>(cgm + n);
     double* bs = reinterpret_cast<double*>(cidx + n);      // nb * 10
     double* wsum = bs + 10 * nb;                            // nb * 3
@@ -577,22 +597,22 @@ hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, 
         else hipLaunchKernelGGL(newton_from_compact<false>, g, b, 0, st, v, cx, cy, cz, cgm, cidx, count, nax, nay, naz);
         hipLaunchKernelGGL(scan_block_totals<10>, gs, b, 0, st, v, nax, nay, naz, bs, wavesums);
         hipLaunchKernelGGL((scan_of_totals<10, false>), dim3(10), dim3(SOT), 0, st, bs, nbs, totals);
-        if (exact) hipLaunchKernelGGL((scan_main<SCAN_GR, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wx, wy, wz, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
-        else hipLaunchKernelGGL((scan_main<SCAN_GR, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wx, wy, wz, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
+        if (exact) hipLaunchKernelGGL((scan_main<SCAN_GR, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wf, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
+        else hipLaunchKernelGGL((scan_main<SCAN_GR, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wf, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
     } else {
         hipLaunchKernelGGL(scan_block_totals<7>, gs, b, 0, st, v, nax, nay, naz, bs, wavesums);
         hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(7), dim3(SOT), 0, st, bs, nbs, totals);
         if (kind == SCAN_MOF_JACOBI) {
-            if (exact) hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wx, wy, wz, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
-            else hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wx, wy, wz, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
+            if (exact) hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wf, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
+            else hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wf, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
         } else {
-            if (exact) hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wx, wy, wz, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
-            else hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wx, wy, wz, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
+            if (exact) hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wf, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
+            else hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wf, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
         }
     }
     hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(3), dim3(SOT), 0, st, wsum, nbs, wtot);
-    if (kind == SCAN_MOF_BARY) hipLaunchKernelGGL(scan_apply<true>, gs, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, wsum, wwave, wtot, (const double*)nullptr);
-    else hipLaunchKernelGGL(scan_apply<false>, gs, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, wsum, wwave, wtot, (const double*)nullptr);
+    if (kind == SCAN_MOF_BARY) hipLaunchKernelGGL(scan_apply<true>, gs, b, 0, st, v, ajx, ajy, ajz, wf, wsum, wwave, wtot, (const double*)nullptr);
+    else hipLaunchKernelGGL(scan_apply<false>, gs, b, 0, st, v, ajx, ajy, ajz, wf, wsum, wwave, wtot, (const double*)nullptr);
     return hipGetLastError();
 }
 
@@ -606,7 +626,7 @@ namespace rebxamd {
 static inline long long blocks_of(long long n) { return (n + SCHUNK - 1) / SCHUNK; }
 // (gr: 9 columns; per weighted-sum workgroup 10 + 3 sums and SW times as many wavefront sums; one flag total per
 // compaction workgroup)
-size_t scan_range_doubles(long long n) { return (size_t)(9 * n + 13 * (1 + SW) * blocks_of(n) + (n + SB - 1) / SB + 32); }
+size_t scan_range_doubles(long long n) { return (size_t)(7 * n + 13 * (1 + SW) * blocks_of(n) + (n + SB - 1) / SB + 32); }
 
 // sums7 <- (m, m x, m y, m z, m vx, m vy, m vz) summed over the range
 hipError_t launch_range_sums(const View& v, double* ws, double* sums7, hipStream_t st) {
@@ -625,8 +645,8 @@ hipError_t launch_range_mof_forces(const View& v, const DevOp& op, double G, boo
                                    double* ws, double* push3, hipStream_t st) {
     if (v.n <= 0) return hipMemsetAsync(push3, 0, 3 * sizeof(double), st);
     const long long n = v.n, nb = blocks_of(n);
-    double* ajx = ws; double* ajy = ajx + n; double* ajz = ajy + n; double* wx = ajz + n; double* wy = wx + n; double* wz = wy + n;
-    double* bs = wz + n;                    // nb * 7
+    double* ajx = ws; double* ajy = ajx + n; double* ajz = ajy + n; double* wf = ajz + n;
+    double* bs = wf + n;                    // nb * 7
     double* wsum = bs + 7 * nb;             // nb * 3
     double* scratch = wsum + 3 * nb;        // 16
     double* wavesums = scratch + 16;        // nb * SW * 7
@@ -636,10 +656,10 @@ hipError_t launch_range_mof_forces(const View& v, const DevOp& op, double G, boo
     hipLaunchKernelGGL(scan_block_totals<7>, g, b, 0, st, v, none, none, none, bs, wavesums);
     hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(7), dim3(SOT), 0, st, bs, nb, scratch);
     if (barycentric)
-        hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), g, b, 0, st, v, op, G, none, none, none, (const double*)bs, (const double*)wavesums, before7, ajx, ajy, ajz, wx, wy, wz, wsum,
+        hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), g, b, 0, st, v, op, G, none, none, none, (const double*)bs, (const double*)wavesums, before7, ajx, ajy, ajz, wf, wsum,
                            wwave, (unsigned*)nullptr, none, 0LL, v.m);
     else
-        hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), g, b, 0, st, v, op, G, none, none, none, (const double*)bs, (const double*)wavesums, (const double*)scratch, ajx, ajy, ajz, wx, wy, wz, wsum,
+        hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), g, b, 0, st, v, op, G, none, none, none, (const double*)bs, (const double*)wavesums, (const double*)scratch, ajx, ajy, ajz, wf, wsum,
                            wwave, (unsigned*)nullptr, before7, starts_at_origin ? 1LL : 0LL, v.m);
     hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(3), dim3(SOT), 0, st, wsum, nb, push3);
     return hipGetLastError();
@@ -650,24 +670,24 @@ hipError_t launch_range_mof_forces(const View& v, const DevOp& op, double G, boo
 hipError_t launch_range_mof_apply(const View& v, bool barycentric, const double* after3, double* ws, hipStream_t st) {
     if (v.n <= 0) return hipSuccess;
     const long long n = v.n, nb = blocks_of(n);
-    double* ajx = ws; double* ajy = ajx + n; double* ajz = ajy + n; double* wx = ajz + n; double* wy = wx + n; double* wz = wy + n;
-    double* wsum = wz + n + 7 * nb;
+    double* ajx = ws; double* ajy = ajx + n; double* ajz = ajy + n; double* wf = ajz + n;
+    double* wsum = wf + n + 7 * nb;
     double* wwave = wsum + 3 * nb + 16 + 7 * SW * nb;
     const dim3 g((unsigned)nb), b(SB);
-    if (barycentric) hipLaunchKernelGGL(scan_apply<true>, g, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, (const double*)wsum, (const double*)wwave, after3, (const double*)nullptr);
-    else hipLaunchKernelGGL(scan_apply<false>, g, b, 0, st, v, ajx, ajy, ajz, wx, wy, wz, (const double*)wsum, (const double*)wwave, (const double*)nullptr, after3);
+    if (barycentric) hipLaunchKernelGGL(scan_apply<true>, g, b, 0, st, v, ajx, ajy, ajz, wf, (const double*)wsum, (const double*)wwave, after3, (const double*)nullptr);
+    else hipLaunchKernelGGL(scan_apply<false>, g, b, 0, st, v, ajx, ajy, ajz, wf, (const double*)wsum, (const double*)wwave, (const double*)nullptr, after3);
     return hipGetLastError();
 }
 
 // ---- pieces of gr for particle shards.  Range workspace: Newtonian acc (3 columns), own
 // post-Newtonian acc (3), weighted reactions (3), workgroup sums (10 + 3 per workgroup), flag totals.
-struct GrRange { double *nax, *nay, *naz, *ajx, *ajy, *ajz, *wx, *wy, *wz, *bs, *wsum, *fl, *scratch, *wavesums, *wwave; };
+struct GrRange { double *nax, *nay, *naz, *ajx, *ajy, *ajz, *wf, *bs, *wsum, *fl, *scratch, *wavesums, *wwave; };
 static GrRange gr_range(double* ws, long long n) {
     GrRange r;
     const long long nb = blocks_of(n);
     r.nax = ws; r.nay = r.nax + n; r.naz = r.nay + n; r.ajx = r.naz + n; r.ajy = r.ajx + n; r.ajz = r.ajy + n;
-    r.wx = r.ajz + n; r.wy = r.wx + n; r.wz = r.wy + n;
-    r.bs = r.wz + n; r.wsum = r.bs + 10 * nb; r.fl = r.wsum + 3 * nb; r.scratch = r.fl + (n + SB - 1) / SB;
+    r.wf = r.ajz + n;
+    r.bs = r.wf + n; r.wsum = r.bs + 10 * nb; r.fl = r.wsum + 3 * nb; r.scratch = r.fl + (n + SB - 1) / SB;
     r.wavesums = r.scratch + 32; r.wwave = r.wavesums + 10 * SW * nb;
     return r;
 }
@@ -709,9 +729,9 @@ hipError_t launch_range_gr_forces(const View& v, const DevOp& op, double G, bool
     const dim3 g((unsigned)nb), b(SB);
     const long long first = starts_at_origin ? 1LL : 0LL;
     if (exact) hipLaunchKernelGGL((scan_main<SCAN_GR, true>), g, b, 0, st, v, op, G, (const double*)r.nax, (const double*)r.nay, (const double*)r.naz, (const double*)r.bs,
-                                  (const double*)r.wavesums, (const double*)r.scratch, r.ajx, r.ajy, r.ajz, r.wx, r.wy, r.wz, r.wsum, r.wwave, status, before10, first, m0);
+                                  (const double*)r.wavesums, (const double*)r.scratch, r.ajx, r.ajy, r.ajz, r.wf, r.wsum, r.wwave, status, before10, first, m0);
     else hipLaunchKernelGGL((scan_main<SCAN_GR, false>), g, b, 0, st, v, op, G, (const double*)r.nax, (const double*)r.nay, (const double*)r.naz, (const double*)r.bs,
-                            (const double*)r.wavesums, (const double*)r.scratch, r.ajx, r.ajy, r.ajz, r.wx, r.wy, r.wz, r.wsum, r.wwave, status, before10, first, m0);
+                            (const double*)r.wavesums, (const double*)r.scratch, r.ajx, r.ajy, r.ajz, r.wf, r.wsum, r.wwave, status, before10, first, m0);
     hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(3), dim3(SOT), 0, st, r.wsum, nb, push3);
     return hipGetLastError();
 }
@@ -721,7 +741,7 @@ hipError_t launch_range_gr_apply(const View& v, const double* after3, double* ws
     if (v.n <= 0) return hipSuccess;
     const GrRange r = gr_range(ws, v.n);
     hipLaunchKernelGGL(scan_apply<false>, dim3((unsigned)blocks_of(v.n)), dim3(SB), 0, st, v, (const double*)r.ajx, (const double*)r.ajy, (const double*)r.ajz,
-                       (const double*)r.wx, (const double*)r.wy, (const double*)r.wz, (const double*)r.wsum, (const double*)r.wwave, (const double*)nullptr, after3);
+                       (const double*)r.wf, (const double*)r.wsum, (const double*)r.wwave, (const double*)nullptr, after3);
     return hipGetLastError();
 }
 
@@ -731,7 +751,7 @@ hipError_t launch_gr_hamiltonian(const View& v, double G, double c, double* ws, 
     if (n <= 0) return hipSuccess;
     const long long nb = (n + SB - 1) / SB;
     double* pot = ws;
-    double* cx = ws + 9 * n; double* cy = cx + n; double* cz = cy + n; double* cgm = cz + n;
+    double* cx = ws + 7 * n; double* cy = cx + n; double* cz = cy + n; double* cgm = cz + n;
     long long* cidx = reinterpret_cast<long long*>(cgm + n);
     double* bs = reinterpret_cast<double*>(cidx + n);
     double* part = bs + 10 * nb;                            // nb * 3
