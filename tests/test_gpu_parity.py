@@ -478,6 +478,51 @@ def test_ten_million_particle_disk_matches_checker_on_a_sample(ctx, mode):
     assert rel_err(got, ref).max() <= TOL
 
 
+@pytest.mark.parametrize("mode", [FAST, EXACT])
+def test_prefix_sum_paths_over_several_rounds_of_the_totals_scan(ctx, mode):
+    """2.4 million bodies, six planets at random slots among massless dust.  The scan of the
+    per-workgroup totals (one row per 2048 bodies, 512 rows per round) runs two whole rounds and
+    a partial one, the scan of the massive-body flags (one row per 256 bodies) eighteen; every
+    planet's mass has to reach all bodies behind it across those rounds, and its reaction all
+    bodies in front.  The checker's cost stays O(n x massive) on this layout."""
+    n = 2_400_001
+    cols, pp, _ = synthetic.disk(n, 6)
+    cols, pp = scatter_planets(cols, pp)
+    cols = zero_acc(cols)
+    for force in (SCAN_FORCES[0], SCAN_FORCES[2], SCAN_FORCES[3]):
+        scan_check(ctx, cols, pp, [force], mode)
+
+
+def test_ten_million_massive_bodies_keep_the_total_momentum(ctx):
+    """Full size, every body massive (the checker would need O(n^2) here).  Size-independent
+    property: the reactions of these forces cancel the momentum they hand out -- with the
+    inclusive Jacobi reaction m_i a_i - m_i/(M_<i + m_i) a_i (M_<i + m_i) = 0, likewise about the
+    barycentre, and gr's Jacobi-to-inertial transform leaves the centre of mass alone -- so
+    sum_i m_i da_i vanishes to rounding (bar: 1e-10 of sum_i m_i |da_i|, i.e. rounding of 1e7
+    terms and of the prefix sums behind them).  Plus: two launches give the same bits."""
+    import torch
+    from reboundx_amd.device import DeviceParticles, apply_forces
+    n = 10_000_000
+    cols, pp, _ = synthetic.disk(n, 4, dust_mass=1e-12)
+    host = dict(zero_acc(cols))
+    for k in ("tau_a", "tau_e", "tau_inc"):
+        host[k] = pp[k]
+    m = torch.from_numpy(cols["m"]).to("cuda:0")
+    for force in (("modify_orbits_forces", {}), ("modify_orbits_forces", {"coordinates": 1}), ("gr", {"c": C})):
+        outs = []
+        for _ in range(2):
+            dp = DeviceParticles.from_host(host, n_head=n, tail_massless=False)
+            apply_forces(ctx, dp, [force], {}, FAST)
+            outs.append(torch.stack([dp.cols[k] for k in ("ax", "ay", "az")]).clone())
+            del dp
+        assert torch.equal(outs[0], outs[1]), force
+        a = outs[0]
+        assert torch.isfinite(a).all() and (a != 0).any(), force
+        net = (a * m).sum(dim=1).abs()
+        handed = (a.abs() * m).sum(dim=1)
+        assert (net <= 1e-10 * handed.max()).all(), (force, net.tolist(), handed.tolist())
+
+
 def test_gr_full_sharded_driver_on_the_hip_engine(ctx):
     """The multi-GPU driver (reboundx_amd/dist.py) with no process group: all rows on this GPU,
     through the same engine calls a rank makes for its shard."""
