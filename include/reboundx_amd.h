@@ -501,8 +501,14 @@ int rebxamd_fixed_stacks(rebxamd_ctx* ctx, int on);
  * -- every stage evaluated in registers, velocities and first-stage accelerations written; with
  * the implicit-midpoint scheme -- one pass per round (mean velocity, forces, new estimate, partial
  * sums of the convergence test).
+ * The switch also covers rebxamd_apply in default arithmetic on layouts with massive bodies
+ * anywhere: when a stack holds gr or Jacobi/barycentric modify_orbits_forces (evaluated with
+ * prefix sums) beside streaming forces that push on their sources, the pass of the streaming
+ * forces also applies the last of those two forces, so the accelerations are read and written
+ * once for both.
  * on = 0 makes this context run force passes and elementwise passes separately (default: 1).
- * Both compute the same expressions. */
+ * Both compute the same expressions (the order of the additions into a_i differs at rounding
+ * level in the rebxamd_apply case). */
 int rebxamd_carried_steps(rebxamd_ctx* ctx, int on);
 int rebxamd_timing_read(rebxamd_ctx* ctx, double* total_ms, int* launches);
 

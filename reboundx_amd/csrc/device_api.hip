@@ -299,7 +299,9 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
     const bool sparse = target_lo < 0 && (u->tail_massless != 0 || K == v.n) && K >= 1 && K <= REBXAMD_MAX_HEAD && max_src < K;
 
     const bool wh = step && step->epi == EPI_WH;
-    if (step && !(sparse && (wh ? K == 1 : v.n > K))) return STEP_NOT_CARRIED;
+    const bool applies = step && step->epi == EPI_APPLY;      // the pass also applies a prefix-sum force (any-mass-layout pass only)
+    if (step && !applies && !(sparse && (wh ? K == 1 : v.n > K))) return STEP_NOT_CARRIED;
+    if (applies && (sparse || prog.gr_op >= 0 || prog.mofcom_op >= 0 || target_lo >= 0 || pushes_only)) return STEP_NOT_CARRIED;
     HeadConsts* const hc = ctx->hc + ctx->hc_stage;
     if (sparse) {
         if (step && !wh) {
@@ -331,17 +333,27 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
             // pass over the particles less when a prefix-sum op sits in the middle of the stack; the
             // order in which the terms reach a_i changes, which the rounding-level bar of this mode covers)
             rebxamd_op rest[REBXAMD_MAX_OPS];
-            int nrest = 0;
-            for (int k = lo; k < hi; k++)
-                if (k - lo != prog.gr_op && k - lo != prog.mofcom_op) rest[nrest++] = ops[k];
-            if (nrest > 0) {
+            int nrest = 0, nreact = 0, last_scan = -1;
+            for (int k = lo; k < hi; k++) {
+                if (k - lo != prog.gr_op && k - lo != prog.mofcom_op) { nreact += has_backreaction(ops[k]) ? 1 : 0; rest[nrest++] = ops[k]; }
+                else last_scan = k;
+            }
+            // When the streaming pass is the any-mass-layout one with aligned columns, it also applies
+            // the last prefix-sum force: the accelerations make one round trip instead of two.
+            const bool rides = ctx->carried_steps && nrest > 0 && nreact > 0 && vec2 && stream_bodies_per_block() == scan_segment_bodies();
+            StepArgs sa = {0., 0., nullptr, EPI_APPLY, 0., 0., 0., {nullptr, nullptr, nullptr}, nullptr, nullptr, 0., {}};
+            if (nrest > 0 && !rides) {
                 const int rc = run_streaming(ctx, u, rest, 0, nrest, mode, st);
                 if (rc != REBXAMD_OK) return rc;
             }
             for (int k = lo; k < hi; k++) {
                 if (k - lo != prog.gr_op && k - lo != prog.mofcom_op) continue;
                 TimedLaunch tl(ctx, st);
-                HIP_TRY(launch_scan_op(v, prog.ops[k - lo], prog.G, exact, ctx->scan, ctx->status, st));
+                HIP_TRY(launch_scan_op(v, prog.ops[k - lo], prog.G, exact, ctx->scan, ctx->status, st, (rides && k == last_scan) ? &sa.tail : nullptr));
+            }
+            if (rides) {
+                const int rc = run_streaming(ctx, u, rest, 0, nrest, mode, st, -1, nullptr, false, &sa);
+                if (rc != REBXAMD_OK) return rc == STEP_NOT_CARRIED ? fail(ctx, REBXAMD_ERR_UNSUPPORTED, "streaming pass refused to apply the prefix-sum force") : rc;
             }
             return REBXAMD_OK;
         }
@@ -383,7 +395,7 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
     HIP_TRY(launch_stage(v, prog, hc, st));
     {
         TimedLaunch tl(ctx, st);
-        HIP_TRY(launch_stream(v, prog, first, hc, ctx->partials, &nblocks, nslots > 0, exact, vec2, ctx->fixed_stacks, ctx->status, st));
+        HIP_TRY(launch_stream(v, prog, first, hc, ctx->partials, &nblocks, nslots > 0, exact, vec2, ctx->fixed_stacks, ctx->status, st, applies ? step : nullptr));
     }
     if (nslots > 0 || sums_out) HIP_TRY(launch_finalize(v, prog, ctx->partials, nblocks, ctx->chunk_sums, sums_out, st));
     return REBXAMD_OK;

@@ -237,6 +237,12 @@ __device__ __forceinline__ void mof_exact(const Part& p, const Src& ref, V3& a) 
         a.z += prefac * dz + 2. * dvz / tau_inc;
     }
 }
+// Reaction of a body's force (one component) on the bodies before it in a prefix-sum force, given
+// the share f of the force that falls back on them; rounded the same way wherever it is formed.
+__device__ __forceinline__ double reaction(double f, double a) {
+#pragma clang fp contract(off)
+    return f * a;
+}
 // a / b from y = fast_rcp(b): the quotient estimate is corrected with its exact residual, which
 // leaves it within an ulp of the IEEE quotient (nearly always equal to it) at a third of the cost
 // of the hardware division sequence; y is shared by the quotients over the same b.

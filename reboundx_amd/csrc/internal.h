@@ -76,9 +76,20 @@ struct HeadConsts {
 //             of the final velocities (aux), the new estimate orig + c0*a replaces the old one, and
 //             the squared change and squared size (compare(), :47-62) are left as one pair of partial
 //             sums per workgroup in `partials`.  Velocity and acceleration columns are not written.
-enum { EPI_NONE = 0, EPI_WH = 1, EPI_EULER = 2, EPI_RK2 = 3, EPI_RK4 = 4, EPI_IM = 5 };
+//   EPI_APPLY (any-mass-layout pass, default arithmetic) the last pass of a prefix-sum force rides along:
+//             a_i also receives aJ_i minus the reactions of the bodies k >= i (scan_kernels.hip, pass 5),
+//             so the accelerations make one round trip for the streaming forces and that force together
+enum { EPI_NONE = 0, EPI_WH = 1, EPI_EULER = 2, EPI_RK2 = 3, EPI_RK4 = 4, EPI_IM = 5, EPI_APPLY = 6 };
+// What the per-body pass of a prefix-sum force leaves for the pass that applies it: the force in the body's
+// own frame (aj), the share of it that falls back on the bodies before (share), the reactions summed over
+// the workgroups behind each workgroup of that pass (behind_blocks, 3 per workgroup) and per wavefront
+// segment (wave_totals, 3 per segment, waves_per_block segments of segment_bodies bodies per workgroup);
+// all != nullptr (barycentric coordinates): every body receives the same total instead.
+struct ScanTail { const double* aj[3]; const double* share; const double* behind_blocks; const double* wave_totals; const double* all;
+                  int waves_per_block, segment_bodies; };
 struct StepArgs { double h, dtk; const double* star; int epi; double c0, c1, c2; double* aux[3]; double* partials;
-                  const double* star0; double h0; };   // EPI_WH: a leading Kepler drift over h0 about the record star0 (nullptr: none)
+                  const double* star0; double h0;      // EPI_WH: a leading Kepler drift over h0 about the record star0 (nullptr: none)
+                  ScanTail tail; };                    // EPI_APPLY
 
 enum { WARN_GR_ITER = 1u, WARN_GRFULL_SWEEPS = 2u, WARN_IM_ITER = 4u };
 
@@ -111,7 +122,10 @@ hipError_t launch_range_mof_forces(const View& v, const DevOp& op, double G, boo
                                    double* ws, double* push3, hipStream_t st);
 hipError_t launch_range_mof_apply(const View& v, bool barycentric, const double* after3, double* ws, hipStream_t st);
 hipError_t launch_gr_hamiltonian(const View& v, double G, double c, double* ws, double* out, hipStream_t st);
-hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, double* ws, unsigned* status, hipStream_t st);
+// tail != nullptr: the pass that applies the force is left to the caller (an EPI_APPLY streaming pass) and described there
+hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, double* ws, unsigned* status, hipStream_t st, ScanTail* tail = nullptr);
+int stream_bodies_per_block();     // bodies one workgroup of the streaming pass covers
+int scan_segment_bodies();         // bodies one wavefront of the prefix-sum passes covers
 
 // velocity/position updates of the force integrators and steppers (step_kernels.hip)
 hipError_t launch_lincomb(double* const out[3], const double* const v[3], const double* const a[3], double coef, long long n, bool exact, hipStream_t st);

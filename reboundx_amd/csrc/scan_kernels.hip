@@ -209,12 +209,6 @@ struct ScanRaw {
     }
 };
 
-// reaction of a body's force on the bodies before it, rounded the same way wherever it is formed
-__device__ __forceinline__ double reaction(double f, double a) {
-#pragma clang fp contract(off)
-    return f * a;
-}
-
 // pass 3: per-body force in its own frame (aJ) and its weighted reaction (w); totals of w per
 // wavefront segment (wwave) and per workgroup (wsums)
 template <int KIND, bool EXACT>
@@ -560,6 +554,7 @@ __global__ __launch_bounds__(SB) void gr_hamiltonian_main(View v, double G, doub
 }
 
 // ------------------------------------------------------------------ host driver
+int scan_segment_bodies() { return 64 * ST; }
 size_t scan_workspace_doubles(long long n) {
     const long long nb = (n + SB - 1) / SB;
     const long long nbs = (n + SCHUNK - 1) / SCHUNK;
@@ -568,7 +563,7 @@ size_t scan_workspace_doubles(long long n) {
     return (size_t)(7 * n + 5 * n + 14 * nb + 64 + 13 * SW * nbs);
 }
 
-hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, double* ws, unsigned* status, hipStream_t st) {
+hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, double* ws, unsigned* status, hipStream_t st, ScanTail* tail) {
     const long long n = v.n;
     if (n <= 0) return hipSuccess;
     const long long nb = (n + SB - 1) / SB;
@@ -611,6 +606,11 @@ hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, 
         }
     }
     hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(3), dim3(SOT), 0, st, wsum, nbs, wtot);
+    if (tail != nullptr) {
+        // the caller's streaming pass applies the force
+        *tail = ScanTail{{ajx, ajy, ajz}, wf, wsum, wwave, kind == SCAN_MOF_BARY ? wtot : nullptr, SW, 64 * ST};
+        return hipGetLastError();
+    }
     if (kind == SCAN_MOF_BARY) hipLaunchKernelGGL(scan_apply<true>, gs, b, 0, st, v, ajx, ajy, ajz, wf, wsum, wwave, wtot, (const double*)nullptr);
     else hipLaunchKernelGGL(scan_apply<false>, gs, b, 0, st, v, ajx, ajy, ajz, wf, wsum, wwave, wtot, (const double*)nullptr);
     return hipGetLastError();

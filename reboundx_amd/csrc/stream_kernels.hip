@@ -628,8 +628,9 @@ __device__ __forceinline__ void integrate_tail(const Program& prog, const HeadCo
 template <bool EXACT, bool BACKREACT, bool VEC2, int COLS, Sig SIG = 0ull, int EPI = EPI_NONE>
 __global__ __launch_bounds__(BLOCK, (!EXACT && !BACKREACT && COLS != COL_ALL) ? 4 : 3) void stream_kernel(View v, Program prog, long long lo, long long base,
                                                        const HeadConsts* __restrict__ tab, double* partials, unsigned* status, StepArgs step) {
-    static_assert(EPI == EPI_NONE || (!BACKREACT && (COLS & COL_VEL)), "a stepping pass streams massless bodies and needs their velocities");
-    constexpr bool STEP = EPI != EPI_NONE;        // forces start from zero
+    static_assert(EPI == EPI_NONE || (EPI == EPI_APPLY ? BACKREACT && VEC2 && !EXACT : !BACKREACT && (COLS & COL_VEL)),
+                  "a stepping pass streams massless bodies and needs their velocities; a pass that applies a prefix-sum force runs on any mass layout");
+    constexpr bool STEP = EPI != EPI_NONE && EPI != EPI_APPLY;        // forces start from zero
     const int tid = threadIdx.x;
     const long long i0 = base + 2 * ((long long)blockIdx.x * BLOCK + tid);
     const bool in0 = i0 < v.n, in1 = i0 + 1 < v.n;
@@ -809,6 +810,52 @@ __global__ __launch_bounds__(BLOCK, (!EXACT && !BACKREACT && COLS != COL_ALL) ? 
         }
         return;
     }
+    if (EPI == EPI_APPLY) {
+        // The workgroup's 2*BLOCK bodies are one wavefront segment of the per-body pass (the
+        // launcher checks the sizes): the reactions behind the segment come from that pass's
+        // tables, those inside it from a suffix sum over the workgroup.
+        __shared__ double later[WAVES][3];
+        const ScanTail& T = step.tail;
+        const int wave = tid >> 6, lane = tid & 63;
+        double aj[2][3], f[2] = {0., 0.};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            aj[0][c] = aj[1][c] = 0.;
+            if (full) ldpair(T.aj[c], i0, aj[0][c], aj[1][c]);
+            else { if (act0) aj[0][c] = ldone(T.aj[c], i0); if (act1) aj[1][c] = ldone(T.aj[c], i0 + 1); }
+        }
+        double s[2][3];
+        if (T.all != nullptr) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) s[0][c] = s[1][c] = T.all[c];
+        } else {
+            if (full) ldpair(T.share, i0, f[0], f[1]);
+            else { if (act0) f[0] = ldone(T.share, i0); if (act1) f[1] = ldone(T.share, i0 + 1); }
+            const long long sb = blockIdx.x / T.waves_per_block;
+            const int sw = blockIdx.x % T.waves_per_block;
+            double w[2][3], excl[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                w[0][c] = act0 ? reaction(f[0], aj[0][c]) : 0.;
+                w[1][c] = act1 ? reaction(f[1], aj[1][c]) : 0.;
+                const double pair = w[0][c] + w[1][c];
+                const double incl = wave_incl_scan_rev(pair, lane);
+                excl[c] = incl - pair;                       // the lanes behind this one
+                if (lane == 0) later[wave][c] = incl;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                double behind = T.behind_blocks[sb * 3 + c];
+                for (int q = T.waves_per_block - 1; q > sw; q--) behind += T.wave_totals[(sb * T.waves_per_block + q) * 3 + c];
+                for (int q = WAVES - 1; q > wave; q--) behind += later[q][c];
+                s[1][c] = w[1][c] + (excl[c] + behind);
+                s[0][c] = w[0][c] + s[1][c];
+            }
+        }
+        acc[0].x += aj[0][0] - s[0][0]; acc[0].y += aj[0][1] - s[0][1]; acc[0].z += aj[0][2] - s[0][2];
+        acc[1].x += aj[1][0] - s[1][0]; acc[1].y += aj[1][1] - s[1][1]; acc[1].z += aj[1][2] - s[1][2];
+    }
     if (full) {
         d2v ax, ay, az;
         ax.x = acc[0].x; ax.y = acc[1].x; ay.x = acc[0].y; ay.y = acc[1].y; az.x = acc[0].z; az.y = acc[1].z;
@@ -922,6 +969,7 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(View v) {
 }
 
 // ------------------------------------------------------------------ launchers
+int stream_bodies_per_block() { return 2 * BLOCK; }
 int stream_block_count(long long lo, long long n, bool) {
     const long long base = lo & ~1ll;
     const long long pairs = (n - base + 1) / 2;
@@ -971,6 +1019,18 @@ static void launch_stream_cols(dim3 g, dim3 b, hipStream_t st, bool vec2, bool f
 #undef FIXED_EPI
 #undef EPILOGUE
         }
+        if constexpr (BACKREACT && !EXACT) {
+            // the pass also applies a prefix-sum force (launch_stream has checked the alignment)
+#define FIXED_APPLY(...) \
+    { constexpr Sig S_ = sig_of(__VA_ARGS__); \
+      if (sig == S_) { hipLaunchKernelGGL((stream_kernel<false, true, true, sig_cols(S_, false), S_, EPI_APPLY>), g, b, 0, st, v, prog, lo, base, hc, partials, status, sa); return; } }
+            FIXED_APPLY(REBXAMD_OP_TIDES, REBXAMD_OP_GR_POTENTIAL)
+            FIXED_APPLY(REBXAMD_OP_J2, REBXAMD_OP_J4)
+            FIXED_APPLY(REBXAMD_OP_GR_POTENTIAL)
+            FIXED_APPLY(REBXAMD_OP_TIDES)
+#undef FIXED_APPLY
+            hipLaunchKernelGGL((stream_kernel<false, true, true, COL_ALL, 0ull, EPI_APPLY>), g, b, 0, st, v, prog, lo, base, hc, partials, status, sa);
+        }
         return;
     }
 #define LAUNCH(V, C) hipLaunchKernelGGL((stream_kernel<EXACT, BACKREACT, V, C>), g, b, 0, st, v, prog, lo, base, hc, partials, status, sa)
@@ -1005,7 +1065,9 @@ static void launch_stream_cols(dim3 g, dim3 b, hipStream_t st, bool vec2, bool f
 
 hipError_t launch_stream(const View& v, const Program& prog, long long lo, const HeadConsts* hc, double* partials,
                          int* nblocks_out, bool backreact, bool exact, bool vec2, bool fixed, unsigned* status, hipStream_t st, const StepArgs* step) {
-    if (step && backreact) return hipErrorInvalidValue;
+    if (step && step->epi == EPI_APPLY) {
+        if (!backreact || exact || !vec2 || lo != 0 || step->tail.segment_bodies != 2 * BLOCK) return hipErrorInvalidValue;
+    } else if (step && backreact) return hipErrorInvalidValue;
     const long long base = lo & ~1ll;
     const int nb = stream_block_count(lo, v.n, vec2);
     if (nblocks_out) *nblocks_out = nb;

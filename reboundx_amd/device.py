@@ -164,7 +164,8 @@ class Context:
         self._check(lib.rebxamd_fixed_stacks(self._h, 1 if on else 0))
 
     def carried_steps(self, on=True):
-        """Whether wh_steps lets the force pass carry kick and drift (default) or runs them as a pass of their own."""
+        """Whether force passes carry the elementwise passes around them (kick and drift in wh_steps, velocity updates in
+        integrate_force, the last pass of a prefix-sum force in apply; default) or every pass runs on its own."""
         self._check(lib.rebxamd_carried_steps(self._h, 1 if on else 0))
 
     def timing_read(self):

@@ -260,6 +260,40 @@ def test_full_stack_with_planets_scattered(ctx, mode):
     scan_check(ctx, zero_acc(cols), pp, stack, mode)
 
 
+RIDING_STACKS = {
+    "tides+jacobi+gr_potential": [("tides_precession", {}), ("modify_orbits_forces", {}), ("gr_potential", {"c": C})],
+    "harmonics+barycentric": [("gravitational_harmonics", {}), ("modify_orbits_forces", {"coordinates": 1})],
+    "gr+gr_potential": [("gr", {"c": C}), ("gr_potential", {"c": C})],
+    "tides+gr": [("tides_precession", {}), ("gr", {"c": 300.0, "max_iterations": 4})],
+    "gr+harmonics+jacobi+radiation+tides": [("gr", {"c": C}), ("gravitational_harmonics", {}), ("modify_orbits_forces", {}),
+                                            ("radiation_forces", {"c": C}), ("tides_precession", {})],
+}
+
+
+@pytest.mark.parametrize("fixed", [True, False])
+@pytest.mark.parametrize("stack", sorted(RIDING_STACKS))
+@pytest.mark.parametrize("n", [700, 20_001])
+def test_streaming_pass_that_also_applies_a_prefix_sum_force(ctx, n, stack, fixed):
+    """Default arithmetic, massive bodies anywhere: the pass of the streaming forces also adds the
+    last prefix-sum force (its force per body minus the reactions of the bodies behind), so the
+    accelerations are read and written once for both.  Checked against the checker, and against
+    the same stack with the force applied by a pass of its own."""
+    cols, pp, _ = synthetic.disk(n, 3, dust_mass=1e-11)
+    cols = zero_acc(cols)
+    synthetic.add_newtonian(cols, n_head=4)
+    forces = RIDING_STACKS[stack]
+    ctx.fixed_stacks(fixed)
+    try:
+        riding, _ = scan_check(ctx, cols, pp, forces, FAST)
+        ctx.carried_steps(False)
+        apart, _ = scan_check(ctx, cols, pp, forces, FAST)
+    finally:
+        ctx.carried_steps(True)
+        ctx.fixed_stacks(True)
+    scale = np.abs(apart).max(axis=0)
+    assert (np.abs(riding - apart) <= 1e-13 * np.where(scale == 0., 1., scale)).all()
+
+
 # parameters of the reference's own tests (reboundx/test/test_machine_independent.py:39-42,135-136,
 # 159-160,183-184,207-209) on the reference's own three-body system (:25-31)
 TWOPLANETS_PP = {
