@@ -939,7 +939,8 @@ extern "C" int rebxamd_potentials(rebxamd_ctx* ctx, const rebxamd_view* view, co
         DevOp& d = prog.ops[k];
         d.kind = o.kind; d.src = o.src; d.iarg = o.iarg; d.slot = -1; d.a = o.a; d.b = o.b; d.c = 0.; d.d = 0.;
         switch (o.kind) {
-        case REBXAMD_OP_J2: case REBXAMD_OP_J4: case REBXAMD_OP_CENTRAL: case REBXAMD_OP_TIDES: break;
+        case REBXAMD_OP_J2: case REBXAMD_OP_J4: case REBXAMD_OP_CENTRAL: break;
+        case REBXAMD_OP_TIDES: prog.need_tides = 1; break;
         case REBXAMD_OP_GR_POTENTIAL: d.src = 0; d.c = o.a * o.a; break;
         default: return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_potentials: this op has no potential (J2, J4, central_force, tides_precession, gr_potential do)");
         }

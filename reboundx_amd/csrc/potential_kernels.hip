@@ -7,20 +7,24 @@
 // kernel adds the workgroup sums in a fixed order.  The reference adds the terms sequentially;
 // the results agree to rounding of a sum of that many terms.
 #include "internal.h"
+#include "wave_ops.h"
 #include <float.h>
 
 namespace rebxamd {
 
 static constexpr int PB = 256;
 
-__device__ __forceinline__ double potential_term(const DevOp& op, const View& v, long long i, double G) {
+// what one thread holds of its particle (parameter columns: NaN = not set)
+struct PotBody { double x, y, z, m, Rt, k1; };
+
+__device__ __forceinline__ double potential_term(const DevOp& op, const View& v, long long i, const PotBody& b, double G) {
 #pragma clang fp contract(off)
     const int s = op.src;
     if (i == s) return 0.;
     if (op.kind == REBXAMD_OP_GR_POTENTIAL && i < 1) return 0.;
-    const double dx = v.x[i] - v.x[s], dy = v.y[i] - v.y[s], dz = v.z[i] - v.z[s];
+    const double dx = b.x - v.x[s], dy = b.y - v.y[s], dz = b.z - v.z[s];
     const double r2 = dx * dx + dy * dy + dz * dz;
-    const double mi = v.m[i], ms = v.m[s];
+    const double mi = b.m, ms = v.m[s];
     switch (op.kind) {
     case REBXAMD_OP_J2: {
         const double r = sqrt(r2);
@@ -49,8 +53,8 @@ __device__ __forceinline__ double potential_term(const DevOp& op, const View& v,
         const double fac0 = k10 * R0 * R0 * R0 * R0 * R0;
         double fac = 0.;
         fac += fac0 * mratio;
-        const double Rp = (v.Rt && v.Rt[i] == v.Rt[i]) ? v.Rt[i] : 0.;
-        const double k1p = (v.k1 && v.k1[i] == v.k1[i]) ? v.k1[i] : 0.;
+        const double Rp = b.Rt == b.Rt ? b.Rt : 0.;
+        const double k1p = b.k1 == b.k1 ? b.k1 : 0.;
         fac += k1p * Rp * Rp * Rp * Rp * Rp / mratio;
         return -3. / 6. * G * (ms + mi) * mi / (r2 * r2 * r2) * fac;
     }
@@ -65,21 +69,28 @@ __device__ __forceinline__ double potential_term(const DevOp& op, const View& v,
 }
 
 __global__ __launch_bounds__(PB) void potential_kernel(View v, Program prog, double* partials) {
-    __shared__ double red[PB / 64];
+    __shared__ double red[REBXAMD_MAX_OPS][PB / 64];
     const long long i = (long long)blockIdx.x * PB + threadIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool in = i < v.n;
+    // the particle is read once for all ops (read-once columns: nontemporal)
+    const double nan = __builtin_nan("");
+    PotBody b = {0., 0., 0., 0., nan, nan};
+    if (in) {
+        b.x = __builtin_nontemporal_load(v.x + i); b.y = __builtin_nontemporal_load(v.y + i); b.z = __builtin_nontemporal_load(v.z + i);
+        b.m = __builtin_nontemporal_load(v.m + i);
+        if (prog.need_tides && v.Rt) b.Rt = __builtin_nontemporal_load(v.Rt + i);
+        if (prog.need_tides && v.k1) b.k1 = __builtin_nontemporal_load(v.k1 + i);
+    }
     for (int k = 0; k < prog.nops; k++) {
-        double t = i < v.n ? potential_term(prog.ops[k], v, i, prog.G) : 0.;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-        __syncthreads();
-        if (lane == 0) red[wave] = t;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double s = 0.;
-            for (int w = 0; w < PB / 64; w++) s += red[w];
-            partials[(long long)k * gridDim.x + blockIdx.x] = s;
-        }
+        const double t = wave_total(in ? potential_term(prog.ops[k], v, i, b, prog.G) : 0., lane);
+        if (lane == 0) red[k][wave] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < prog.nops) {
+        double s = 0.;
+        for (int w = 0; w < PB / 64; w++) s += red[threadIdx.x][w];
+        partials[(long long)threadIdx.x * gridDim.x + blockIdx.x] = s;
     }
 }
 
