@@ -14,15 +14,18 @@ static constexpr int TB = 256;
 
 struct Cols3 { double *x, *y, *z; };
 struct CCols3 { const double *x, *y, *z; };
+// columns a pass reads once and nobody reads again soon: nontemporal, so that they do not push the
+// columns being updated out of the caches
+__device__ __forceinline__ double once(const double* col, long long i) { return __builtin_nontemporal_load(col + i); }
 
 // out = v + coef * a   (out may alias v: kick, drift, euler)
 template <bool EXACT>
 __global__ __launch_bounds__(TB) void lincomb_kernel(Cols3 out, CCols3 v, CCols3 a, double coef, long long n) {
     const long long i = (long long)blockIdx.x * TB + threadIdx.x;
     if (i >= n) return;
-    out.x[i] = axpy1<EXACT>(v.x[i], coef, a.x[i]);
-    out.y[i] = axpy1<EXACT>(v.y[i], coef, a.y[i]);
-    out.z[i] = axpy1<EXACT>(v.z[i], coef, a.z[i]);
+    out.x[i] = axpy1<EXACT>(v.x[i], coef, once(a.x, i));
+    out.y[i] = axpy1<EXACT>(v.y[i], coef, once(a.y, i));
+    out.z[i] = axpy1<EXACT>(v.z[i], coef, once(a.z, i));
 }
 
 // integrator_rk2.c:61-66:  v += b1*a1 + b2*a2
@@ -30,9 +33,9 @@ template <bool EXACT>
 __global__ __launch_bounds__(TB) void rk2_final_kernel(Cols3 v, CCols3 a1, CCols3 a2, double b1, double b2, long long n) {
     const long long i = (long long)blockIdx.x * TB + threadIdx.x;
     if (i >= n) return;
-    v.x[i] = rk2_combine<EXACT>(v.x[i], b1, a1.x[i], b2, a2.x[i]);
-    v.y[i] = rk2_combine<EXACT>(v.y[i], b1, a1.y[i], b2, a2.y[i]);
-    v.z[i] = rk2_combine<EXACT>(v.z[i], b1, a1.z[i], b2, a2.z[i]);
+    v.x[i] = rk2_combine<EXACT>(v.x[i], b1, once(a1.x, i), b2, once(a2.x, i));
+    v.y[i] = rk2_combine<EXACT>(v.y[i], b1, once(a1.y, i), b2, once(a2.y, i));
+    v.z[i] = rk2_combine<EXACT>(v.z[i], b1, once(a1.z, i), b2, once(a2.z, i));
 }
 
 // integrator_rk4.c:74-82:  stage velocity for k4 = v + dt*k3;  k3 += k2;  k2's accelerations reset
@@ -44,7 +47,7 @@ __global__ __launch_bounds__(TB) void rk4_mid_kernel(Cols3 sv, CCols3 v, Cols3 k
     sv.x[i] = axpy1<EXACT>(v.x[i], dt, k3x);
     sv.y[i] = axpy1<EXACT>(v.y[i], dt, k3y);
     sv.z[i] = axpy1<EXACT>(v.z[i], dt, k3z);
-    k3a.x[i] = k3x + k2a.x[i]; k3a.y[i] = k3y + k2a.y[i]; k3a.z[i] = k3z + k2a.z[i];
+    k3a.x[i] = k3x + once(k2a.x, i); k3a.y[i] = k3y + once(k2a.y, i); k3a.z[i] = k3z + once(k2a.z, i);
     k2a.x[i] = 0.; k2a.y[i] = 0.; k2a.z[i] = 0.;
 }
 
@@ -53,9 +56,9 @@ template <bool EXACT>
 __global__ __launch_bounds__(TB) void rk4_final_kernel(Cols3 v, CCols3 a1, CCols3 a4, CCols3 k23, double dt6, long long n) {
     const long long i = (long long)blockIdx.x * TB + threadIdx.x;
     if (i >= n) return;
-    v.x[i] = rk4_combine<EXACT>(v.x[i], dt6, a1.x[i], a4.x[i], k23.x[i]);
-    v.y[i] = rk4_combine<EXACT>(v.y[i], dt6, a1.y[i], a4.y[i], k23.y[i]);
-    v.z[i] = rk4_combine<EXACT>(v.z[i], dt6, a1.z[i], a4.z[i], k23.z[i]);
+    v.x[i] = rk4_combine<EXACT>(v.x[i], dt6, once(a1.x, i), once(a4.x, i), once(k23.x, i));
+    v.y[i] = rk4_combine<EXACT>(v.y[i], dt6, once(a1.y, i), once(a4.y, i), once(k23.y, i));
+    v.z[i] = rk4_combine<EXACT>(v.z[i], dt6, once(a1.z, i), once(a4.z, i), once(k23.z, i));
 }
 
 // integrator_implicit_midpoint.c:101-114: new estimate of the final velocities from the
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(TB) void im_update_kernel(Cols3 fin, CCols3 orig, C
     const long long i = (long long)blockIdx.x * TB + threadIdx.x;
     double d2 = 0., t2 = 0.;
     if (i < n) {
-        const double ox = orig.x[i], oy = orig.y[i], oz = orig.z[i];
+        const double ox = once(orig.x, i), oy = once(orig.y, i), oz = once(orig.z, i);
         const double fx = axpy1<EXACT>(ox, dt, avga.x[i]);
         const double fy = axpy1<EXACT>(oy, dt, avga.y[i]);
         const double fz = axpy1<EXACT>(oz, dt, avga.z[i]);
