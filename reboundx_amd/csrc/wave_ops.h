@@ -5,13 +5,14 @@ namespace rebxamd {
 
 // Wavefront scans.  Within each row of 16 lanes: four data-parallel-primitive shifts (row_shr /
 // row_shl by 1, 2, 4, 8; lanes the shift leaves empty read zero), which run at VALU rate instead
-// of going through the LDS crossbar; across the four rows: the row totals are read with
-// v_readlane and added to the rows behind (in front, for the suffix scan).
-template <int CTRL>
+// of going through the LDS crossbar; across the four rows: row broadcasts (row_bcast:15, row_bcast:31)
+// for the prefix scan, v_readlane of the row totals for the suffix scan (no broadcast runs towards
+// lower rows).
+template <int CTRL, int ROWS = 0xf>
 __device__ __forceinline__ double dpp_shift(double v) {
     const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, ROWS, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, ROWS, 0xf, true);
     return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
 }
 __device__ __forceinline__ double lane_value(double v, int lane) {
@@ -25,11 +26,11 @@ __device__ __forceinline__ double wave_incl_scan(double v, int lane) {
     v += dpp_shift<0x112>(v);       // row_shr:2
     v += dpp_shift<0x114>(v);       // row_shr:4
     v += dpp_shift<0x118>(v);       // row_shr:8
-    const int row = lane >> 4;
-    const double t0 = lane_value(v, 15), t2 = lane_value(v, 47);
-    v += (row == 1) ? t0 : ((row == 3) ? t2 : 0.);
-    const double t01 = lane_value(v, 31);
-    v += (row >= 2) ? t01 : 0.;
+    // across the rows, forwards: the last lane of a row broadcast to the row behind it (rows 1 and
+    // 3 take the totals of rows 0 and 2), then lane 31 to rows 2 and 3; rows outside the mask read zero
+    (void)lane;
+    v += dpp_shift<0x142, 0xa>(v);  // row_bcast:15 row_mask:0xa
+    v += dpp_shift<0x143, 0xc>(v);  // row_bcast:31 row_mask:0xc
     return v;
 }
 __device__ __forceinline__ double wave_incl_scan_rev(double v, int lane) {
