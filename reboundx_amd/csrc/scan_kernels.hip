@@ -161,10 +161,12 @@ __global__ __launch_bounds__(SOT) void scan_of_totals(double* table, long long n
     const int c = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const long long nfull = nb / SOT;
     const bool tail = nfull * SOT < nb;
-    // address of this thread's row in round s (the last row of the scan when there is none)
+    // address of this thread's row in round s; where that round has no row for it: its row in the
+    // round before, which no other thread touches (the value read there is not used)
     auto at = [&](long long s) -> double* {
         long long r = s * SOT + tid;
-        if (r > nb - 1) r = nb - 1;
+        if (r > nb - 1) r -= SOT;
+        if (r < 0) r = 0;
         return table + (REVERSE ? nb - 1 - r : r) * C + c;
     };
     double carry = 0., ahead = 0.;
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(SOT) void scan_of_totals(double* table, long long n
         const bool live = decltype(whole)::value || s * SOT + tid < nb;
         const double v = live ? ahead : 0.;
         double* const mine = at(s);
-        ahead = *at(s + 1);
+        if (decltype(whole)::value) ahead = *at(s + 1);     // (a partial round is the last one)
         const double incl = wave_incl_scan(v, lane);
         double* const wt = wtot[s & 1];                 // two copies: one barrier per round
         if (lane == 63) wt[wave] = incl;
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(SOT) void scan_of_totals(double* table, long long n
         if (live) *mine = carry + before + (incl - v);
         carry += all;
     };
-    if (nb > 0) ahead = *at(0);
+    if (tid < nb) ahead = *at(0);
     if (nfull > 0) round(0, std::true_type());
 #pragma unroll 1
     for (long long s = 1; s < nfull; s++) round(s, std::true_type());
