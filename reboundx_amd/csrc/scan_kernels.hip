@@ -335,7 +335,8 @@ __global__ __launch_bounds__(SB) void scan_apply(View v, const double* ajx, cons
     auto request = [&](int t, double (&r)[7]) {
         const long long i = seg + t * 64 + lane, ic = i < v.n ? i : last;
         r[0] = ldnt(ajx, ic); r[1] = ldnt(ajy, ic); r[2] = ldnt(ajz, ic);
-        r[3] = v.ax[ic]; r[4] = v.ay[ic]; r[5] = v.az[ic];
+        // (rows behind the end never read the columns this pass writes)
+        r[3] = *(i < v.n ? v.ax + i : ajx + last); r[4] = *(i < v.n ? v.ay + i : ajy + last); r[5] = *(i < v.n ? v.az + i : ajz + last);
         r[6] = TOTAL ? 0. : ldnt(wf, ic);
     };
     request(ST - 1, cur);
