@@ -23,7 +23,7 @@ struct rebxamd_ctx {
     size_t gf_cap = 0;
     unsigned* gf_flag = nullptr;
     double* chunk_sums = nullptr;       // second-stage scratch of the back-reaction reduction
-    double* star = nullptr;             // 2 x 16 doubles: records of body 0 around Wisdom-Holman drifts
+    double* star = nullptr;             // 3 x 16 doubles: records of body 0 around Wisdom-Holman drifts (two alternate between steps, one for the leading half drift)
     double* integ = nullptr;            // stage columns of the force integrators
     size_t integ_cap = 0;
     double* shard = nullptr;            // per-range forces and reactions of the sharded Jacobi/barycentric modify_orbits_forces
@@ -84,7 +84,7 @@ extern "C" int rebxamd_create(int device, rebxamd_ctx** out) {
         hipMalloc((void**)&ctx->status, sizeof(unsigned)) != hipSuccess ||
         hipMalloc((void**)&ctx->ll, sizeof(long long)) != hipSuccess ||
         hipMalloc((void**)&ctx->gf_flag, sizeof(unsigned)) != hipSuccess ||
-        hipMalloc((void**)&ctx->star, 32 * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&ctx->star, 48 * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&ctx->chunk_sums, sizeof(double) * REBXAMD_MAX_OPS * 64 * 3) != hipSuccess ||
         hipMemset(ctx->hc, 0, 4 * sizeof(HeadConsts)) != hipSuccess ||
         hipMemset(ctx->status, 0, sizeof(unsigned)) != hipSuccess) {
@@ -312,7 +312,9 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
             return REBXAMD_OK;
         }
         // in a Wisdom-Holman run the head pass (one body) also records and drifts that body
-        HIP_TRY(launch_head(v, prog, hc, ctx->status, exact, st, wh ? ctx->star : nullptr, wh ? step->h : 0.));
+        // (unless the previous step's pass has already filled this step's tables)
+        if (!(wh && step->head_ready))
+            HIP_TRY(launch_head(v, prog, hc, ctx->status, exact, st, wh ? const_cast<double*>(step->star) : nullptr, wh ? step->h : 0.));
         if (v.n > K) {
             TimedLaunch tl(ctx, st);
             HIP_TRY(launch_stream(v, prog, K, hc, nullptr, nullptr, false, exact, vec2, ctx->fixed_stacks, ctx->status, st, step));
@@ -730,11 +732,22 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
     rc = rebxamd_reset_accelerations(ctx, view, stream);
     if (rc != REBXAMD_OK) return rc;
     if (carried) {
-        double* const star0 = ctx->star + 16;
+        double* const star0 = ctx->star + 32;
         HIP_TRY(launch_wh_star(x, v, view->m, view->G, 0.5 * dt, star0, st));       // body 0 to mid-step; the others follow inside the pass
+        // With a one-body head pass (no barycentric op) the pass of step k also runs the head pass of
+        // step k + 1 in one extra workgroup, into the other copy of the tables and of body 0's record:
+        // one launch per step after the first.
+        bool chain = view->vx != nullptr;
+        for (int k = 0; k < nops; k++)
+            if (ops[k].kind == REBXAMD_OP_MOF && ops[k].iarg == REBX_COORDINATES_BARYCENTRIC) chain = false;
+        struct StageReset { rebxamd_ctx* c; ~StageReset() { c->hc_stage = 0; } } stage_reset{ctx};
         for (int64_t k = 0; k < nsteps; k++) {
             const double h = k + 1 < nsteps ? dt : 0.5 * dt;
-            const StepArgs sa = {h, dt, ctx->star, EPI_WH, 0., 0., 0., {nullptr, nullptr, nullptr}, nullptr, k == 0 ? star0 : nullptr, 0.5 * dt};
+            const int cur = chain ? (int)(k & 1) : 0, nxt = cur ^ 1;
+            ctx->hc_stage = cur;
+            StepArgs sa = {h, dt, ctx->star + 16 * cur, EPI_WH, 0., 0., 0., {nullptr, nullptr, nullptr}, nullptr, k == 0 ? star0 : nullptr, 0.5 * dt, {}};
+            if (chain && k + 1 < nsteps) { sa.next_hc = ctx->hc + nxt; sa.next_star = ctx->star + 16 * nxt; sa.next_h = k + 2 < nsteps ? dt : 0.5 * dt; }
+            sa.head_ready = (chain && k > 0) ? 1 : 0;
             rc = run_streaming(ctx, view, ops, 0, nops, mode, st, -1, nullptr, false, &sa);
             if (rc == STEP_NOT_CARRIED) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_steps: the force stack cannot ride in one pass over this layout");
             if (rc != REBXAMD_OK) return rc;

@@ -89,7 +89,11 @@ struct ScanTail { const double* aj[3]; const double* share; const double* behind
                   int waves_per_block, segment_bodies; };
 struct StepArgs { double h, dtk; const double* star; int epi; double c0, c1, c2; double* aux[3]; double* partials;
                   const double* star0; double h0;      // EPI_WH: a leading Kepler drift over h0 about the record star0 (nullptr: none)
-                  ScanTail tail; };                    // EPI_APPLY
+                  ScanTail tail;                       // EPI_APPLY
+                  // EPI_WH, one-body head: one extra workgroup of the pass fills the tables and the record of body 0
+                  // for the NEXT step (next_hc, next_star; drift of body 0 over next_h), so that step needs no head
+                  // pass of its own (head_ready: this step's tables were filled that way)
+                  HeadConsts* next_hc; double* next_star; double next_h; int head_ready; };
 
 enum { WARN_GR_ITER = 1u, WARN_GRFULL_SWEEPS = 2u, WARN_IM_ITER = 4u };
 

@@ -367,8 +367,7 @@ __global__ __launch_bounds__(64) void head_kernel(View v, Program prog, HeadCons
 // Jacobi frame is empty), so the pass only fills the tables -- with the arithmetic of head_kernel
 // for K = 1, rounding included -- and, in a Wisdom-Holman run, records and drifts the body.  A
 // fraction of head_kernel's latency: no loops over ops with barriers, no LDS.
-__global__ __launch_bounds__(64) void head_one_kernel(View v, Program prog, HeadConsts* hc, double* star, double h) {
-    const int t = threadIdx.x;
+__device__ __forceinline__ void head_one_body(const View& v, const Program& prog, HeadConsts* hc, double* star, double h, const int t) {
     Src S;
     load_src(v, 0, S);                                  // every lane reads the same body
     if (t < prog.nops) {
@@ -407,6 +406,9 @@ __global__ __launch_bounds__(64) void head_one_kernel(View v, Program prog, Head
         const_cast<double*>(v.x)[0] = nx; const_cast<double*>(v.y)[0] = ny; const_cast<double*>(v.z)[0] = nz;
         star[6] = nx; star[7] = ny; star[8] = nz;
     }
+}
+__global__ __launch_bounds__(64) void head_one_kernel(View v, Program prog, HeadConsts* hc, double* star, double h) {
+    head_one_body(v, prog, hc, star, h, threadIdx.x);
 }
 
 // ------------------------------------------------------------------ streaming kernel
@@ -632,7 +634,16 @@ __global__ __launch_bounds__(BLOCK, (!EXACT && !BACKREACT && COLS != COL_ALL) ? 
                   "a stepping pass streams massless bodies and needs their velocities; a pass that applies a prefix-sum force runs on any mass layout");
     constexpr bool STEP = EPI != EPI_NONE && EPI != EPI_APPLY;        // forces start from zero
     const int tid = threadIdx.x;
-    const long long i0 = base + 2 * ((long long)blockIdx.x * BLOCK + tid);
+    const bool chained = EPI == EPI_WH && step.next_hc != nullptr;
+    if (chained && blockIdx.x == 0) {
+        // the extra workgroup of a Wisdom-Holman pass: the head pass of the next step (it reads and
+        // writes body 0 and the other copy of the tables, which no workgroup of this pass touches).
+        // It is the first workgroup, so that its latency hides behind the others.
+        if (tid < 64) head_one_body(v, prog, step.next_hc, step.next_star, step.next_h, tid);
+        return;
+    }
+    const unsigned blk = blockIdx.x - (chained ? 1u : 0u);
+    const long long i0 = base + 2 * ((long long)blk * BLOCK + tid);
     const bool in0 = i0 < v.n, in1 = i0 + 1 < v.n;
     const bool act0 = in0 && i0 >= lo, act1 = in1 && i0 + 1 >= lo;
     const bool full = VEC2 && act0 && act1;      // the common case: both particles, 16-byte accesses
@@ -1072,7 +1083,7 @@ hipError_t launch_stream(const View& v, const Program& prog, long long lo, const
     const int nb = stream_block_count(lo, v.n, vec2);
     if (nblocks_out) *nblocks_out = nb;
     if (nb <= 0) return hipSuccess;
-    const dim3 g(nb), b(BLOCK);
+    const dim3 g(nb + ((step && step->epi == EPI_WH && step->next_hc != nullptr) ? 1 : 0)), b(BLOCK);
     const int cols = (prog.need_vel ? COL_VEL : 0) | (prog.need_beta ? COL_BETA : 0) | (prog.need_tides ? COL_TIDES : 0) | (prog.need_tau ? COL_TAU : 0);
     if (exact) {
         if (backreact) launch_stream_cols<true, true>(g, b, st, vec2, fixed, cols, v, prog, lo, base, hc, partials, status, step);
