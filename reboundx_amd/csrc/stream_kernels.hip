@@ -628,7 +628,7 @@ __device__ __forceinline__ void integrate_tail(const Program& prog, const HeadCo
 // pass carries a whole velocity update of a force integrator; velocities and the first-stage
 // accelerations are written.
 template <bool EXACT, bool BACKREACT, bool VEC2, int COLS, Sig SIG = 0ull, int EPI = EPI_NONE>
-__global__ __launch_bounds__(BLOCK, (!EXACT && !BACKREACT && COLS != COL_ALL) ? 4 : 3) void stream_kernel(View v, Program prog, long long lo, long long base,
+__global__ __launch_bounds__(BLOCK, (BACKREACT && SIG == 0ull) ? 2 : (!EXACT && !BACKREACT && COLS != COL_ALL) ? 4 : 3) void stream_kernel(View v, Program prog, long long lo, long long base,
                                                        const HeadConsts* __restrict__ tab, double* partials, unsigned* status, StepArgs step) {
     static_assert(EPI == EPI_NONE || (EPI == EPI_APPLY ? BACKREACT && VEC2 && !EXACT : !BACKREACT && (COLS & COL_VEL)),
                   "a stepping pass streams massless bodies and needs their velocities; a pass that applies a prefix-sum force runs on any mass layout");
