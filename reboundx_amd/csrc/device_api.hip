@@ -23,6 +23,7 @@ struct rebxamd_ctx {
     size_t gf_cap = 0;
     unsigned* gf_flag = nullptr;
     double* chunk_sums = nullptr;       // second-stage scratch of the back-reaction reduction
+    void* hpin = nullptr;               // 512 B of pinned host memory: small results come back through it (no staging copy inside the runtime)
     double* star = nullptr;             // 3 x 16 doubles: records of body 0 around Wisdom-Holman drifts (two alternate between steps, one for the leading half drift)
     double* integ = nullptr;            // stage columns of the force integrators
     size_t integ_cap = 0;
@@ -72,6 +73,16 @@ static int fail(rebxamd_ctx* ctx, int code, const char* what, hipError_t e = hip
         if (_e != hipSuccess) return fail(ctx, REBXAMD_ERR_HIP, #call, _e);  \
     } while (0)
 
+// A small result (at most 512 bytes) from device memory to `dst`, waiting for the stream: through
+// the context's pinned buffer, so that the copy is one DMA and not a staged one inside the runtime.
+static int read_back(rebxamd_ctx* ctx, void* dst, const void* src_dev, size_t bytes, hipStream_t st) {
+    if (bytes > 512) return fail(ctx, REBXAMD_ERR_ARG, "read_back: result larger than the pinned buffer");
+    HIP_TRY(hipMemcpyAsync(ctx->hpin, src_dev, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    memcpy(dst, ctx->hpin, bytes);
+    return REBXAMD_OK;
+}
+
 extern "C" int rebxamd_create(int device, rebxamd_ctx** out) {
     if (!out) return REBXAMD_ERR_ARG;
     *out = nullptr;
@@ -85,6 +96,7 @@ extern "C" int rebxamd_create(int device, rebxamd_ctx** out) {
         hipMalloc((void**)&ctx->ll, sizeof(long long)) != hipSuccess ||
         hipMalloc((void**)&ctx->gf_flag, sizeof(unsigned)) != hipSuccess ||
         hipMalloc((void**)&ctx->star, 48 * sizeof(double)) != hipSuccess ||
+        hipHostMalloc(&ctx->hpin, 512, hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void**)&ctx->chunk_sums, sizeof(double) * REBXAMD_MAX_OPS * 64 * 3) != hipSuccess ||
         hipMemset(ctx->hc, 0, 4 * sizeof(HeadConsts)) != hipSuccess ||
         hipMemset(ctx->status, 0, sizeof(unsigned)) != hipSuccess) {
@@ -106,6 +118,7 @@ extern "C" void rebxamd_destroy(rebxamd_ctx* ctx) {
     if (ctx->gf) (void)hipFree(ctx->gf);
     if (ctx->gf_flag) (void)hipFree(ctx->gf_flag);
     if (ctx->star) (void)hipFree(ctx->star);
+    if (ctx->hpin) (void)hipHostFree(ctx->hpin);
     if (ctx->chunk_sums) (void)hipFree(ctx->chunk_sums);
     if (ctx->scan) (void)hipFree(ctx->scan);
     if (ctx->shard) (void)hipFree(ctx->shard);
@@ -188,8 +201,7 @@ extern "C" int rebxamd_classify(rebxamd_ctx* ctx, const double* m, int64_t n, in
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(launch_last_massive(m, n, ctx->ll, st));
     long long h = 0;
-    HIP_TRY(hipMemcpyAsync(&h, ctx->ll, sizeof(h), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    { const int rb = read_back(ctx, &h, ctx->ll, sizeof(h), st); if (rb != REBXAMD_OK) return rb; }
     *n_head = h < 1 ? 1 : h;
     return REBXAMD_OK;
 }
@@ -566,14 +578,12 @@ extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* vie
                 HIP_TRY(launch_im_update(fin, cv3, hv, ha, dt, K, partials, nullptr, exact, st));
                 HIP_TRY(launch_im_sum(partials, nb + 1, sums, st));
                 double h[2] = {0., 0.};
-                HIP_TRY(hipMemcpyAsync(h, sums, sizeof(h), hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
+                { const int rb = read_back(ctx, h, sums, sizeof(h), st); if (rb != REBXAMD_OK) return rb; }
                 if (h[0] / h[1] < 2.220446049250313e-16 * 2.220446049250313e-16) break;   // compare(), :57
             }
             if (it == 10) {
                 unsigned cur = 0;
-                HIP_TRY(hipMemcpyAsync(&cur, ctx->status, sizeof(cur), hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
+                { const int rb = read_back(ctx, &cur, ctx->status, sizeof(cur), st); if (rb != REBXAMD_OK) return rb; }
                 cur |= WARN_IM_ITER;
                 HIP_TRY(hipMemcpyAsync(ctx->status, &cur, sizeof(cur), hipMemcpyHostToDevice, st));
                 HIP_TRY(hipStreamSynchronize(st));
@@ -672,14 +682,12 @@ extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* vie
         if (rc != REBXAMD_OK) return rc;
         HIP_TRY(launch_im_update(kb, cv, sv, ka, dt, n, partials, sums, exact, st));
         double h[2] = {0., 0.};
-        HIP_TRY(hipMemcpyAsync(h, sums, sizeof(h), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        { const int rb = read_back(ctx, h, sums, sizeof(h), st); if (rb != REBXAMD_OK) return rb; }
         if (h[0] / h[1] < 2.220446049250313e-16 * 2.220446049250313e-16) break;   // compare(), :57
     }
     if (it == 10) {
         unsigned cur = 0;
-        HIP_TRY(hipMemcpyAsync(&cur, ctx->status, sizeof(cur), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        { const int rb = read_back(ctx, &cur, ctx->status, sizeof(cur), st); if (rb != REBXAMD_OK) return rb; }
         cur |= WARN_IM_ITER;
         HIP_TRY(hipMemcpyAsync(ctx->status, &cur, sizeof(cur), hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -966,8 +974,7 @@ extern "C" int rebxamd_potentials(rebxamd_ctx* ctx, const rebxamd_view* view, co
     if (rc != REBXAMD_OK) return rc;
     double* dout = ctx->partials + (size_t)nops * (size_t)nb;
     HIP_TRY(launch_potentials(v, prog, ctx->partials, dout, st));
-    HIP_TRY(hipMemcpyAsync(out, dout, (size_t)nops * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    { const int rb = read_back(ctx, out, dout, (size_t)nops * sizeof(double), st); if (rb != REBXAMD_OK) return rb; }
     return REBXAMD_OK;
 }
 
@@ -985,8 +992,7 @@ extern "C" int rebxamd_gr_hamiltonian(rebxamd_ctx* ctx, const rebxamd_view* view
     double* dout = ctx->scan + scan_workspace_doubles(v.n);
     HIP_TRY(launch_gr_hamiltonian(v, view->G, c, ctx->scan, dout, st));
     double h[3] = {0., 0., 0.};
-    HIP_TRY(hipMemcpyAsync(h, dout, sizeof(h), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    { const int rb = read_back(ctx, h, dout, sizeof(h), st); if (rb != REBXAMD_OK) return rb; }
     *H = h[0] + h[1] + h[2] / (c * c);              // T + V_newt + V_PN (gr.c:239-245)
     return REBXAMD_OK;
 }
@@ -1005,8 +1011,7 @@ extern "C" int rebxamd_gr_full_hamiltonian(rebxamd_ctx* ctx, const rebxamd_view*
     double* dout = nullptr;
     HIP_TRY(launch_grfull_hamiltonian(v, view->G, c, ctx->gf, &dout, st));
     double h[3] = {0., 0., 0.};
-    HIP_TRY(hipMemcpyAsync(h, dout, sizeof(h), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    { const int rb = read_back(ctx, h, dout, sizeof(h), st); if (rb != REBXAMD_OK) return rb; }
     *H = h[0] + h[1] + h[2];
     return REBXAMD_OK;
 }
@@ -1122,15 +1127,13 @@ extern "C" int rebxamd_grfull(rebxamd_ctx* ctx, const rebxamd_view* u, double c,
         HIP_TRY(hipMemsetAsync(ctx->gf_flag, 0, sizeof(unsigned), st));
         rc = rebxamd_grfull_sweep(ctx, u, c, 0, n, anx, any_, anz, aox, aoy, aoz, acx, acy, acz, nwx, nwy, nwz, ctx->gf_flag, mode, stream);
         if (rc != REBXAMD_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(&flag, ctx->gf_flag, sizeof(flag), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        { const int rb = read_back(ctx, &flag, ctx->gf_flag, sizeof(flag), st); if (rb != REBXAMD_OK) return rb; }
         std::swap(aox, nwx); std::swap(aoy, nwy); std::swap(aoz, nwz);   // a_old now holds the newest iterate
         if (!flag) { k++; break; }
     }
     if (flag) {                         // all ten sweeps ran without meeting the stopping rule
         unsigned bit = WARN_GRFULL_SWEEPS, cur = 0;
-        HIP_TRY(hipMemcpyAsync(&cur, ctx->status, sizeof(cur), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        { const int rb = read_back(ctx, &cur, ctx->status, sizeof(cur), st); if (rb != REBXAMD_OK) return rb; }
         cur |= bit;
         HIP_TRY(hipMemcpyAsync(ctx->status, &cur, sizeof(cur), hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
