@@ -552,7 +552,10 @@ extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* vie
             rc = ensure(ctx, &ctx->integ, &ctx->integ_cap, (3 * stride + 6 * hs + 2 * (size_t)(nb + 1) + 2) * sizeof(double), st);
             if (rc != REBXAMD_OK) return rc;
             double* w = ctx->integ;
-            double* const fin[3] = {w, w + stride, w + 2 * stride};                  // estimate of the final velocities, every body
+            // The velocity columns themselves hold the estimate of the final velocities (it starts as the
+            // velocities at the start of the step and ends as the result: no copy back); the velocities at
+            // the start of the step are kept in the workspace and read from there.
+            double* const orig[3] = {w, w + stride, w + 2 * stride};
             double* const hv[3] = {w + 3 * stride, w + 3 * stride + hs, w + 3 * stride + 2 * hs};          // prefix: averaged velocities
             double* const ha[3] = {w + 3 * stride + 3 * hs, w + 3 * stride + 4 * hs, w + 3 * stride + 5 * hs};   // prefix: accelerations there
             double* partials = w + 3 * stride + 6 * hs;                              // pair 0: the prefix; pairs 1..nb: the pass behind it
@@ -560,22 +563,25 @@ extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* vie
             const double* const cv3[3] = {view->vx, view->vy, view->vz};
             double* const v3[3] = {const_cast<double*>(view->vx), const_cast<double*>(view->vy), const_cast<double*>(view->vz)};
             for (int k = 0; k < 3; k++) {
-                HIP_TRY(hipMemcpyAsync(fin[k], cv3[k], (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(orig[k], cv3[k], (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
                 HIP_TRY(hipMemcpyAsync(hv[k], cv3[k], (size_t)K * sizeof(double), hipMemcpyDeviceToDevice, st));
             }
+            const double* const corig[3] = {orig[0], orig[1], orig[2]};
+            rebxamd_view start = *view;                 // the bodies with their velocities at the start of the step
+            start.vx = orig[0]; start.vy = orig[1]; start.vz = orig[2];
             HIP_TRY(hipMemsetAsync(ha[0], 0, 3 * hs * sizeof(double), st));
             rebxamd_view head = *view;
             head.n = K; head.n_head = K;
             head.vx = hv[0]; head.vy = hv[1]; head.vz = hv[2]; head.ax = ha[0]; head.ay = ha[1]; head.az = ha[2];
-            StepArgs sa = {0., 0., nullptr, EPI_IM, dt, 0., 0., {fin[0], fin[1], fin[2]}, partials + 2, nullptr, 0.};
+            StepArgs sa = {0., 0., nullptr, EPI_IM, dt, 0., 0., {v3[0], v3[1], v3[2]}, partials + 2, nullptr, 0.};
             int it = 0;
             for (it = 0; it < 10; it++) {
                 ctx->hc_stage = 0;
                 rc = rebxamd_apply(ctx, &head, ops, nops, mode, stream);                 // prefix forces + head table at the averaged state
                 if (rc != REBXAMD_OK) return rc;
-                rc = run_streaming(ctx, view, ops, 0, nops, mode, st, -1, nullptr, false, &sa);
+                rc = run_streaming(ctx, &start, ops, 0, nops, mode, st, -1, nullptr, false, &sa);
                 if (rc != REBXAMD_OK) return rc == STEP_NOT_CARRIED ? fail(ctx, REBXAMD_ERR_ARG, "rebxamd_integrate_force: layout changed between passes") : rc;
-                HIP_TRY(launch_im_update(fin, cv3, hv, ha, dt, K, partials, nullptr, exact, st));
+                HIP_TRY(launch_im_update(v3, corig, hv, ha, dt, K, partials, nullptr, exact, st));
                 HIP_TRY(launch_im_sum(partials, nb + 1, sums, st));
                 double h[2] = {0., 0.};
                 { const int rb = read_back(ctx, h, sums, sizeof(h), st); if (rb != REBXAMD_OK) return rb; }
@@ -588,7 +594,6 @@ extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* vie
                 HIP_TRY(hipMemcpyAsync(ctx->status, &cur, sizeof(cur), hipMemcpyHostToDevice, st));
                 HIP_TRY(hipStreamSynchronize(st));
             }
-            for (int k = 0; k < 3; k++) HIP_TRY(hipMemcpyAsync(v3[k], fin[k], (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
             if (iterations) *iterations = it;
             return REBXAMD_OK;
         }
