@@ -218,10 +218,11 @@ extern "C" int rebxamd_fetch_warnings(rebxamd_ctx* ctx, uint32_t* bits, void* st
     if (!ctx || !bits) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_fetch_warnings: bad argument");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(ctx->device));
-    unsigned h = 0;
-    HIP_TRY(hipMemcpyAsync(&h, ctx->status, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(ctx->hpin, ctx->status, sizeof(unsigned), hipMemcpyDeviceToHost, st));      // (pinned: one DMA)
     HIP_TRY(hipMemsetAsync(ctx->status, 0, sizeof(unsigned), st));
     HIP_TRY(hipStreamSynchronize(st));
+    unsigned h = 0;
+    memcpy(&h, ctx->hpin, sizeof(h));
     *bits = h;
     return REBXAMD_OK;
 }
