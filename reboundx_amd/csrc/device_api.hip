@@ -550,7 +550,7 @@ extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* vie
             const int nb = stream_block_count(K, n, true);
             const size_t stride = ((size_t)n + 1) & ~(size_t)1;
             const size_t hs = ((size_t)K + 1) & ~(size_t)1;
-            rc = ensure(ctx, &ctx->integ, &ctx->integ_cap, (3 * stride + 6 * hs + 2 * (size_t)(nb + 1) + 2) * sizeof(double), st);
+            rc = ensure(ctx, &ctx->integ, &ctx->integ_cap, (3 * stride + 6 * hs + 2 * (size_t)(nb + 1) + 2 + 1) * sizeof(double), st);
             if (rc != REBXAMD_OK) return rc;
             double* w = ctx->integ;
             // The velocity columns themselves hold the estimate of the final velocities (it starts as the
@@ -561,6 +561,7 @@ extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* vie
             double* const ha[3] = {w + 3 * stride + 3 * hs, w + 3 * stride + 4 * hs, w + 3 * stride + 5 * hs};   // prefix: accelerations there
             double* partials = w + 3 * stride + 6 * hs;                              // pair 0: the prefix; pairs 1..nb: the pass behind it
             double* sums = partials + 2 * (size_t)(nb + 1);
+            unsigned* stop = reinterpret_cast<unsigned*>(sums + 2);                // [0] converged, [1] rounds counted
             const double* const cv3[3] = {view->vx, view->vy, view->vz};
             double* const v3[3] = {const_cast<double*>(view->vx), const_cast<double*>(view->vy), const_cast<double*>(view->vz)};
             for (int k = 0; k < 3; k++) {
@@ -574,19 +575,27 @@ extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* vie
             rebxamd_view head = *view;
             head.n = K; head.n_head = K;
             head.vx = hv[0]; head.vy = hv[1]; head.vz = hv[2]; head.ax = ha[0]; head.ay = ha[1]; head.az = ha[2];
-            StepArgs sa = {0., 0., nullptr, EPI_IM, dt, 0., 0., {v3[0], v3[1], v3[2]}, partials + 2, nullptr, 0.};
-            int it = 0;
-            for (it = 0; it < 10; it++) {
-                ctx->hc_stage = 0;
-                rc = rebxamd_apply(ctx, &head, ops, nops, mode, stream);                 // prefix forces + head table at the averaged state
-                if (rc != REBXAMD_OK) return rc;
-                rc = run_streaming(ctx, &start, ops, 0, nops, mode, st, -1, nullptr, false, &sa);
-                if (rc != REBXAMD_OK) return rc == STEP_NOT_CARRIED ? fail(ctx, REBXAMD_ERR_ARG, "rebxamd_integrate_force: layout changed between passes") : rc;
-                HIP_TRY(launch_im_update(v3, corig, hv, ha, dt, K, partials, nullptr, exact, st));
-                HIP_TRY(launch_im_sum(partials, nb + 1, sums, st));
-                double h[2] = {0., 0.};
-                { const int rb = read_back(ctx, h, sums, sizeof(h), st); if (rb != REBXAMD_OK) return rb; }
-                if (h[0] / h[1] < 2.220446049250313e-16 * 2.220446049250313e-16) break;   // compare(), :57
+            StepArgs sa = {0., 0., nullptr, EPI_IM, dt, 0., 0., {v3[0], v3[1], v3[2]}, partials + 2, nullptr, 0., {}};
+            sa.stop = stop;
+            HIP_TRY(hipMemsetAsync(stop, 0, 2 * sizeof(unsigned), st));
+            // Rounds are queued ahead of the host: the sums are tested on the device, and once the test is
+            // met the kernels of the rounds still in the queue return at once.  The host looks after four
+            // rounds (most steps need three), then after every second one, up to the reference's ten.
+            int it = 10, queued = 0;
+            while (queued < 10) {
+                const int batch = queued == 0 ? 4 : 2;
+                for (int b = 0; b < batch && queued < 10; b++, queued++) {
+                    ctx->hc_stage = 0;
+                    rc = rebxamd_apply(ctx, &head, ops, nops, mode, stream);                 // prefix forces + head table at the averaged state
+                    if (rc != REBXAMD_OK) return rc;
+                    rc = run_streaming(ctx, &start, ops, 0, nops, mode, st, -1, nullptr, false, &sa);
+                    if (rc != REBXAMD_OK) return rc == STEP_NOT_CARRIED ? fail(ctx, REBXAMD_ERR_ARG, "rebxamd_integrate_force: layout changed between passes") : rc;
+                    HIP_TRY(launch_im_update(v3, corig, hv, ha, dt, K, partials, nullptr, exact, st, stop));
+                    HIP_TRY(launch_im_sum(partials, nb + 1, sums, st, stop));
+                }
+                unsigned h[2] = {0u, 0u};
+                { const int rb = read_back(ctx, h, stop, sizeof(h), st); if (rb != REBXAMD_OK) return rb; }
+                if (h[0] != 0u) { it = (int)h[1] - 1; break; }            // the index of the round that met the test (compare(), :57)
             }
             if (it == 10) {
                 unsigned cur = 0;

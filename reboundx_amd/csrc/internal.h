@@ -93,7 +93,8 @@ struct StepArgs { double h, dtk; const double* star; int epi; double c0, c1, c2;
                   // EPI_WH, one-body head: one extra workgroup of the pass fills the tables and the record of body 0
                   // for the NEXT step (next_hc, next_star; drift of body 0 over next_h), so that step needs no head
                   // pass of its own (head_ready: this step's tables were filled that way)
-                  HeadConsts* next_hc; double* next_star; double next_h; int head_ready; };
+                  HeadConsts* next_hc; double* next_star; double next_h; int head_ready;
+                  const unsigned* stop; };             // EPI_IM with rounds queued ahead of the host: the pass returns at once when *stop is set
 
 enum { WARN_GR_ITER = 1u, WARN_GRFULL_SWEEPS = 2u, WARN_IM_ITER = 4u };
 
@@ -142,8 +143,9 @@ hipError_t launch_wh_drift(double* const x[3], double* const v[3], double* const
                            double* star, bool exact, hipStream_t st);
 long long im_partial_count(long long n);
 hipError_t launch_im_update(double* const fin[3], const double* const orig[3], double* const avgv[3], double* const avga[3], double dt,
-                            long long n, double* partials, double* sums, bool exact, hipStream_t st);
-hipError_t launch_im_sum(const double* partials, long long nb, double* sums, hipStream_t st);
+                            long long n, double* partials, double* sums, bool exact, hipStream_t st, const unsigned* stop = nullptr);
+// stop (two words, device): [0] set once the round's test is met, [1] rounds counted; kernels given the word return at once when [0] is set
+hipError_t launch_im_sum(const double* partials, long long nb, double* sums, hipStream_t st, unsigned* stop = nullptr);
 
 // operators modify_mass and modify_orbits_direct (operator_kernels.hip)
 long long operator_partial_doubles(long long n);

@@ -65,8 +65,10 @@ __global__ __launch_bounds__(TB) void rk4_final_kernel(Cols3 v, CCols3 a1, CCols
 // accelerations at the averaged state; squared change and squared size (compare(), :47-62) as
 // per-workgroup partial sums; then the averaged state for the next round (avg_particles, :32-45).
 template <bool EXACT>
-__global__ __launch_bounds__(TB) void im_update_kernel(Cols3 fin, CCols3 orig, Cols3 avgv, Cols3 avga, double dt, long long n, double* partials) {
+__global__ __launch_bounds__(TB) void im_update_kernel(Cols3 fin, CCols3 orig, Cols3 avgv, Cols3 avga, double dt, long long n, double* partials,
+                                                       const unsigned* stop) {
     __shared__ double red[2][TB / 64];
+    if (stop != nullptr && *stop != 0u) return;        // rounds queued past convergence do nothing
     const long long i = (long long)blockIdx.x * TB + threadIdx.x;
     double d2 = 0., t2 = 0.;
     if (i < n) {
@@ -94,9 +96,13 @@ __global__ __launch_bounds__(TB) void im_update_kernel(Cols3 fin, CCols3 orig, C
     }
 }
 
-// fixed-order sum of the per-workgroup pairs -> out[0], out[1]
-__global__ __launch_bounds__(1024) void im_sum_kernel(const double* partials, long long nb, double* out) {
+// fixed-order sum of the per-workgroup pairs -> out[0], out[1].  With a stop word (rounds queued
+// ahead of the host): the round is counted in stop[1] and the reference's test (squared change over
+// squared size below machine epsilon squared, integrator_implicit_midpoint.c:47-62) sets stop[0],
+// after which the kernels of the rounds still in the queue return at once.
+__global__ __launch_bounds__(1024) void im_sum_kernel(const double* partials, long long nb, double* out, unsigned* stop) {
     __shared__ double red[2][16];
+    if (stop != nullptr && stop[0] != 0u) return;
     double a = 0., b = 0.;
     for (long long k = threadIdx.x; k < nb; k += 1024) { a += partials[2 * k]; b += partials[2 * k + 1]; }
 #pragma unroll
@@ -108,6 +114,10 @@ __global__ __launch_bounds__(1024) void im_sum_kernel(const double* partials, lo
         double s = 0., t = 0.;
         for (int w = 0; w < 16; w++) { s += red[0][w]; t += red[1][w]; }
         out[0] = s; out[1] = t;
+        if (stop != nullptr) {
+            stop[1] += 1u;
+            if (s / t < 2.220446049250313e-16 * 2.220446049250313e-16) stop[0] = 1u;
+        }
     }
 }
 
@@ -191,19 +201,19 @@ hipError_t launch_rk4_final(double* const v[3], const double* const a1[3], const
 long long im_partial_count(long long n) { return (n + TB - 1) / TB; }
 
 hipError_t launch_im_update(double* const fin[3], const double* const orig[3], double* const avgv[3], double* const avga[3], double dt,
-                            long long n, double* partials, double* sums, bool exact, hipStream_t st) {
+                            long long n, double* partials, double* sums, bool exact, hipStream_t st, const unsigned* stop) {
     if (n <= 0) return hipSuccess;
     const Cols3 f = {fin[0], fin[1], fin[2]}, av = {avgv[0], avgv[1], avgv[2]}, aa = {avga[0], avga[1], avga[2]};
     const CCols3 o = {orig[0], orig[1], orig[2]};
-    if (exact) hipLaunchKernelGGL(im_update_kernel<true>, grid_for(n), dim3(TB), 0, st, f, o, av, aa, dt, n, partials);
-    else hipLaunchKernelGGL(im_update_kernel<false>, grid_for(n), dim3(TB), 0, st, f, o, av, aa, dt, n, partials);
-    if (sums != nullptr) hipLaunchKernelGGL(im_sum_kernel, dim3(1), dim3(1024), 0, st, partials, im_partial_count(n), sums);
+    if (exact) hipLaunchKernelGGL(im_update_kernel<true>, grid_for(n), dim3(TB), 0, st, f, o, av, aa, dt, n, partials, stop);
+    else hipLaunchKernelGGL(im_update_kernel<false>, grid_for(n), dim3(TB), 0, st, f, o, av, aa, dt, n, partials, stop);
+    if (sums != nullptr) hipLaunchKernelGGL(im_sum_kernel, dim3(1), dim3(1024), 0, st, partials, im_partial_count(n), sums, (unsigned*)nullptr);
     return hipGetLastError();
 }
 
 // sums[0..1] <- fixed-order sums of nb (squared change, squared size) pairs
-hipError_t launch_im_sum(const double* partials, long long nb, double* sums, hipStream_t st) {
-    hipLaunchKernelGGL(im_sum_kernel, dim3(1), dim3(1024), 0, st, partials, nb, sums);
+hipError_t launch_im_sum(const double* partials, long long nb, double* sums, hipStream_t st, unsigned* stop) {
+    hipLaunchKernelGGL(im_sum_kernel, dim3(1), dim3(1024), 0, st, partials, nb, sums, stop);
     return hipGetLastError();
 }
 

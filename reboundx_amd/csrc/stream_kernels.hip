@@ -634,6 +634,7 @@ __global__ __launch_bounds__(BLOCK, (BACKREACT && SIG == 0ull) ? 2 : (!EXACT && 
                   "a stepping pass streams massless bodies and needs their velocities; a pass that applies a prefix-sum force runs on any mass layout");
     constexpr bool STEP = EPI != EPI_NONE && EPI != EPI_APPLY;        // forces start from zero
     const int tid = threadIdx.x;
+    if (EPI == EPI_IM && step.stop != nullptr && *step.stop != 0u) return;      // a round queued past convergence
     const bool chained = EPI == EPI_WH && step.next_hc != nullptr;
     if (chained && blockIdx.x == 0) {
         // the extra workgroup of a Wisdom-Holman pass: the head pass of the next step (it reads and
