@@ -116,6 +116,32 @@ def test_update_carried_by_one_pass_equals_separate_passes(ctx, n, planets, forc
         assert (np.abs(a1 - a2) / np.where(big == 0., 1., big)[None, :]).max() <= TOL
 
 
+@pytest.mark.parametrize("dt", [1e-6, 0.01, 0.5, 2.0])
+def test_implicit_midpoint_rounds_queued_ahead_of_the_host(ctx, dt):
+    """The carried implicit-midpoint update tests convergence on the device and queues rounds ahead
+    of the host (four, then two at a time): whether the test is met inside the first batch (the
+    rounds behind it must then leave everything alone), at its end, or in a later batch, the
+    number of rounds and the velocities are those of the separate passes, bit for bit in
+    reference-order arithmetic, and the count is the checker's (these steps leave the loop at
+    index 2, 3, 5 and 6)."""
+    n = 3001
+    cols, pp, _ = synthetic.disk(n, 2)
+    ops = build_ops(C5_STACK, pp)
+    out, rounds = [], []
+    for carried in (True, False):
+        dp = device_state(cols, pp)
+        try:
+            ctx.carried_steps(carried)
+            rounds.append(ctx.integrate_force(dp.view(), ops, "implicit_midpoint", dt, EXACT))
+        finally:
+            ctx.carried_steps(True)
+        out.append(vel(dp))
+    assert rounds[0] == rounds[1]
+    assert np.array_equal(out[0], out[1])
+    ref = oracle.Sim(cols)
+    assert oracle.integrate_force(ref, "implicit_midpoint", dt, C5_STACK, pp) == rounds[0]
+
+
 @pytest.mark.parametrize("integrator", ["rk4", "implicit_midpoint"])
 def test_every_particle_massive_uses_reductions(ctx, integrator):
     n = 20011
