@@ -533,10 +533,10 @@ extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* vie
         const int src = (ops[k].kind == REBXAMD_OP_GR || ops[k].kind == REBXAMD_OP_GR_POTENTIAL) ? 0 : ops[k].src;
         if (!com && (src < 0 || src >= K)) carried = false;
     }
-    if (!carried || integrator == REBXAMD_INTEGRATOR_IMPLICIT_MIDPOINT) {
+    if (!carried) {
         // integrate_force.c:46 -- the simulation's accelerations are cleared first, whatever the scheme
         // (the carried pass of an explicit scheme overwrites those of the massless bodies, and the prefix
-        // clears its own; the implicit scheme leaves them cleared)
+        // clears its own; the carried implicit scheme clears them in its first pass and leaves them cleared)
         rc = rebxamd_reset_accelerations(ctx, view, stream);
         if (rc != REBXAMD_OK || n == 0) return rc;
     }
@@ -564,10 +564,10 @@ extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* vie
             unsigned* stop = reinterpret_cast<unsigned*>(sums + 2);                // [0] converged, [1] rounds counted
             const double* const cv3[3] = {view->vx, view->vy, view->vz};
             double* const v3[3] = {const_cast<double*>(view->vx), const_cast<double*>(view->vy), const_cast<double*>(view->vz)};
-            for (int k = 0; k < 3; k++) {
-                HIP_TRY(hipMemcpyAsync(orig[k], cv3[k], (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
-                HIP_TRY(hipMemcpyAsync(hv[k], cv3[k], (size_t)K * sizeof(double), hipMemcpyDeviceToDevice, st));
-            }
+            if (!view->ax || !view->ay || !view->az) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_integrate_force: acceleration columns missing");
+            double* const a3[3] = {view->ax, view->ay, view->az};
+            HIP_TRY(launch_im_begin(orig, cv3, a3, n, st));          // keeps the starting velocities, clears the accelerations
+            for (int k = 0; k < 3; k++) HIP_TRY(hipMemcpyAsync(hv[k], cv3[k], (size_t)K * sizeof(double), hipMemcpyDeviceToDevice, st));
             const double* const corig[3] = {orig[0], orig[1], orig[2]};
             rebxamd_view start = *view;                 // the bodies with their velocities at the start of the step
             start.vx = orig[0]; start.vy = orig[1]; start.vz = orig[2];

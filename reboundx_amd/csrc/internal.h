@@ -146,6 +146,7 @@ hipError_t launch_im_update(double* const fin[3], const double* const orig[3], d
                             long long n, double* partials, double* sums, bool exact, hipStream_t st, const unsigned* stop = nullptr);
 // stop (two words, device): [0] set once the round's test is met, [1] rounds counted; kernels given the word return at once when [0] is set
 hipError_t launch_im_sum(const double* partials, long long nb, double* sums, hipStream_t st, unsigned* stop = nullptr);
+hipError_t launch_im_begin(double* const keep[3], const double* const v[3], double* const a[3], long long n, hipStream_t st);
 
 // operators modify_mass and modify_orbits_direct (operator_kernels.hip)
 long long operator_partial_doubles(long long n);

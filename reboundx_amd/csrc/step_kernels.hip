@@ -96,6 +96,15 @@ __global__ __launch_bounds__(TB) void im_update_kernel(Cols3 fin, CCols3 orig, C
     }
 }
 
+// Start of a carried implicit-midpoint update in one pass: the velocities at the start of the step
+// are kept aside and the accelerations cleared (integrate_force.c:46).
+__global__ __launch_bounds__(TB) void im_begin_kernel(Cols3 keep, CCols3 v, Cols3 a, long long n) {
+    const long long i = (long long)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    __builtin_nontemporal_store(v.x[i], keep.x + i); __builtin_nontemporal_store(v.y[i], keep.y + i); __builtin_nontemporal_store(v.z[i], keep.z + i);
+    __builtin_nontemporal_store(0., a.x + i); __builtin_nontemporal_store(0., a.y + i); __builtin_nontemporal_store(0., a.z + i);
+}
+
 // fixed-order sum of the per-workgroup pairs -> out[0], out[1].  With a stop word (rounds queued
 // ahead of the host): the round is counted in stop[1] and the reference's test (squared change over
 // squared size below machine epsilon squared, integrator_implicit_midpoint.c:47-62) sets stop[0],
@@ -212,6 +221,13 @@ hipError_t launch_im_update(double* const fin[3], const double* const orig[3], d
 }
 
 // sums[0..1] <- fixed-order sums of nb (squared change, squared size) pairs
+hipError_t launch_im_begin(double* const keep[3], const double* const v[3], double* const a[3], long long n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const Cols3 k = {keep[0], keep[1], keep[2]}, acc = {a[0], a[1], a[2]};
+    const CCols3 cv = {v[0], v[1], v[2]};
+    hipLaunchKernelGGL(im_begin_kernel, grid_for(n), dim3(TB), 0, st, k, cv, acc, n);
+    return hipGetLastError();
+}
 hipError_t launch_im_sum(const double* partials, long long nb, double* sums, hipStream_t st, unsigned* stop) {
     hipLaunchKernelGGL(im_sum_kernel, dim3(1), dim3(1024), 0, st, partials, nb, sums, stop);
     return hipGetLastError();
