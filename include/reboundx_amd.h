@@ -340,6 +340,26 @@ int rebxamd_classify(rebxamd_ctx* ctx, const double* m, int64_t n, int64_t* n_he
  * on `stream`. */
 int rebxamd_apply(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, int mode, void* stream);
 
+/* rebxamd_apply for callers that cannot allocate device memory (no counterpart in the reference;
+ * for code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc).
+ * Same kernels and results as rebxamd_apply, but no context: the small tables, the warning word and
+ * the partial sums of the pushes on source particles live in a fixed 4 MiB array inside the
+ * library's code object (one copy per GPU, held until the process ends), and the call makes no
+ * hipMalloc/hipFree.  Works on the current device, which must be the one that holds the columns of
+ * `view`.  The address of the array is looked up on the first call on each device
+ * (hipGetSymbolAddress), so make that first call outside graph capture.
+ * Limits (REBXAMD_ERR_UNSUPPORTED with a message in errbuf beyond them): nops <= REBXAMD_MAX_OPS; no
+ * gr_full; gr and Jacobi/barycentric modify_orbits_forces only when the massive bodies are a prefix
+ * of at most REBXAMD_MAX_HEAD particles (view->n_head, view->tail_massless); on layouts that need
+ * parallel sums of the pushes (massive bodies beyond such a prefix), (number of ops that push on a
+ * source) x ceil(n / 512) x 24 bytes must fit in the array less 80 KiB (3 such ops: n <= 2.9e7).
+ * warnings_dev: device word in which kernels raise the rebxamd_fetch_warnings bits (the caller
+ * clears it), or NULL (bits are dropped).  errbuf (may be NULL) receives a message on failure.
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two
+ * host threads) race. */
+int rebxamd_apply_static(const rebxamd_view* view, const rebxamd_op* ops, int nops, int mode, uint32_t* warnings_dev, void* stream,
+                         char* errbuf, int errbuf_len);
+
 /* Particle-sharded runs (no counterpart in the reference).  `view` holds [the replicated head |
  * this device's slice of the particles] and the slice may contain massive particles.
  * rebxamd_apply_targets applies `ops` (no gr, no gr_full, modify_orbits_forces in PARTICLE

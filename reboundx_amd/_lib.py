@@ -47,6 +47,7 @@ _sig = {
     "rebxamd_last_error": (c_char_p, [c_void_p]),
     "rebxamd_classify": (c_int, [c_void_p, c_void_p, c_int64, POINTER(c_int64), c_void_p]),
     "rebxamd_apply": (c_int, [c_void_p, POINTER(View), POINTER(Op), c_int, c_int, c_void_p]),
+    "rebxamd_apply_static": (c_int, [POINTER(View), POINTER(Op), c_int, c_int, c_void_p, c_void_p, c_char_p, c_int]),
     "rebxamd_apply_targets": (c_int, [c_void_p, POINTER(View), POINTER(Op), c_int, c_int, c_int64, c_void_p, c_void_p]),
     "rebxamd_add_pushes": (c_int, [c_void_p, POINTER(View), POINTER(Op), c_int, c_void_p, c_void_p]),
     "rebxamd_shard_sums": (c_int, [c_void_p, POINTER(View), c_int64, c_int64, c_void_p, c_void_p]),

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -35,6 +36,7 @@ struct rebxamd_ctx {
     bool timing = false;
     bool carried_steps = true;  // Wisdom-Holman runs: kick and drift ride in the force pass when the layout allows
     bool fixed_stacks = true;   // stacks with a kernel instance of their own use it
+    bool fixed_scratch = false; // the buffers above are slices of a fixed array: never grown, never freed
     std::vector<hipEvent_t> ev;         // pairs: start, stop
     size_t ev_used = 0;
 };
@@ -184,6 +186,7 @@ static bool all_aligned(const View& v) {
 
 static int ensure(rebxamd_ctx* ctx, double** buf, size_t* cap, size_t bytes, hipStream_t st) {
     if (bytes <= *cap) return REBXAMD_OK;
+    if (ctx->fixed_scratch) return fail(ctx, REBXAMD_ERR_UNSUPPORTED, "the request needs more workspace than the fixed scratch array of this entry point holds");
     if (*buf) {
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipFree(*buf));
@@ -416,17 +419,13 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
     return REBXAMD_OK;
 }
 
-extern "C" int rebxamd_apply(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, int mode, void* stream) {
-    if (!ctx) return REBXAMD_ERR_ARG;
-    if (!view || nops < 0 || (nops > 0 && !ops) || view->n < 0 || view->n_head < 0) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_apply: bad argument");
-    if (mode != REBXAMD_MODE_FAST && mode != REBXAMD_MODE_EXACT) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_apply: bad mode");
-    hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipSetDevice(ctx->device));
+// rebxamd_apply without the argument checks: ops[0, nops) split into streaming runs and gr_full evaluations
+static int apply_ops(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, int mode, hipStream_t st) {
     int lo = 0;
     while (lo < nops) {
         if (ops[lo].kind == REBXAMD_OP_GR_FULL) {
             int sweeps = 0;
-            const int rc = rebxamd_grfull(ctx, view, ops[lo].a, ops[lo].iarg, mode, &sweeps, stream);
+            const int rc = rebxamd_grfull(ctx, view, ops[lo].a, ops[lo].iarg, mode, &sweeps, (void*)st);
             if (rc != REBXAMD_OK) return rc;
             lo++;
             continue;
@@ -442,6 +441,107 @@ extern "C" int rebxamd_apply(rebxamd_ctx* ctx, const rebxamd_view* view, const r
         lo = hi;
     }
     return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_apply(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, int mode, void* stream) {
+    if (!ctx) return REBXAMD_ERR_ARG;
+    if (!view || nops < 0 || (nops > 0 && !ops) || view->n < 0 || view->n_head < 0) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_apply: bad argument");
+    if (mode != REBXAMD_MODE_FAST && mode != REBXAMD_MODE_EXACT) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_apply: bad mode");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return apply_ops(ctx, view, ops, nops, mode, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ rebxamd_apply for callers that cannot allocate
+//
+// Same kernels as rebxamd_apply; the small tables, the warning word and the partial sums of the
+// pushes on source particles live in `scratch`, a fixed array of this library's code object, instead
+// of buffers of a context.  Each GPU holds its own copy of the array at its own address: the address
+// is looked up once per device (hipGetSymbolAddress, with that device current) and only that pointer
+// is handed to kernels and memsets -- the array's name is a host-side stand-in, not a device address.
+static constexpr size_t STATIC_SCRATCH_BYTES = 4u << 20;
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+
+static constexpr size_t round256(size_t b) { return (b + 255) & ~(size_t)255; }
+static constexpr size_t SS_TABLES = 0;                                                   // 4 x HeadConsts
+static constexpr size_t SS_STATUS = SS_TABLES + round256(4 * sizeof(HeadConsts));       // warning word
+static constexpr size_t SS_CHUNKS = SS_STATUS + 256;                                     // second-stage sums of the pushes
+static constexpr size_t SS_PARTIALS = SS_CHUNKS + round256(sizeof(double) * REBXAMD_MAX_OPS * 64 * 3);
+static_assert(SS_PARTIALS + (1u << 20) <= STATIC_SCRATCH_BYTES, "the fixed scratch array is too small for its tables");
+
+static constexpr int STATIC_MAX_DEVICES = 64;
+struct StaticSlot { bool ready = false; rebxamd_ctx ctx; };
+static StaticSlot g_static[STATIC_MAX_DEVICES];
+static std::mutex g_static_mutex;
+
+static void copy_msg(char* dst, int len, const char* msg) {
+    if (!dst || len <= 0) return;
+    snprintf(dst, (size_t)len, "%s", msg);
+}
+
+extern "C" int rebxamd_apply_static(const rebxamd_view* view, const rebxamd_op* ops, int nops, int mode, uint32_t* warnings_dev, void* stream,
+                                    char* errbuf, int errbuf_len) {
+    copy_msg(errbuf, errbuf_len, "");
+    if (!view || nops < 0 || nops > REBXAMD_MAX_OPS || (nops > 0 && !ops) || view->n < 0 || view->n_head < 0 ||
+        (mode != REBXAMD_MODE_FAST && mode != REBXAMD_MODE_EXACT)) {
+        copy_msg(errbuf, errbuf_len, "rebxamd_apply_static: bad argument (at most REBXAMD_MAX_OPS ops)");
+        return REBXAMD_ERR_ARG;
+    }
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= STATIC_MAX_DEVICES) {
+        copy_msg(errbuf, errbuf_len, "rebxamd_apply_static: no current device");
+        return REBXAMD_ERR_HIP;
+    }
+    StaticSlot& slot = g_static[dev];
+    {
+        std::lock_guard<std::mutex> lock(g_static_mutex);
+        if (!slot.ready) {
+            // set-up, once per device, with that device current
+            unsigned char* ptr = nullptr;
+            const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || ptr == nullptr) {
+                copy_msg(errbuf, errbuf_len, "rebxamd_apply_static: hipGetSymbolAddress(scratch) failed");
+                return REBXAMD_ERR_HIP;
+            }
+            rebxamd_ctx& c = slot.ctx;
+            c.device = dev;
+            c.fixed_scratch = true;
+            c.hc = reinterpret_cast<HeadConsts*>(ptr + SS_TABLES);
+            c.status = reinterpret_cast<unsigned*>(ptr + SS_STATUS);
+            c.chunk_sums = reinterpret_cast<double*>(ptr + SS_CHUNKS);
+            c.partials = reinterpret_cast<double*>(ptr + SS_PARTIALS);
+            c.partials_cap = STATIC_SCRATCH_BYTES - SS_PARTIALS;
+            slot.ready = true;
+        }
+    }
+    rebxamd_ctx* const ctx = &slot.ctx;
+    hipStream_t st = (hipStream_t)stream;
+    // Refused up front: the forces whose workspace grows with the number of particles.
+    const long long K = view->n_head < view->n ? view->n_head : view->n;
+    const bool short_head = (view->tail_massless != 0 || K == view->n) && K >= 1 && K <= REBXAMD_MAX_HEAD;
+    for (int k = 0; k < nops; k++) {
+        const bool com = ops[k].kind == REBXAMD_OP_MOF && ops[k].iarg != REBX_COORDINATES_PARTICLE;
+        if (ops[k].kind == REBXAMD_OP_GR_FULL || ((ops[k].kind == REBXAMD_OP_GR || com) && !short_head)) {
+            copy_msg(errbuf, errbuf_len, "rebxamd_apply_static: gr_full, and gr or Jacobi/barycentric modify_orbits_forces with massive bodies beyond a "
+                                         "64-body prefix, need workspace in proportion to the particles; use rebxamd_apply");
+            return REBXAMD_ERR_UNSUPPORTED;
+        }
+    }
+    unsigned* const own_status = ctx->status;
+    if (warnings_dev) ctx->status = warnings_dev;           // kernels raise their warning bits in the caller's word
+    else if (hipMemsetAsync(own_status, 0, sizeof(unsigned), st) != hipSuccess) {
+        copy_msg(errbuf, errbuf_len, "rebxamd_apply_static: hipMemsetAsync failed");
+        return REBXAMD_ERR_HIP;
+    }
+    ctx->hc_stage = 0;
+    const int rc = apply_ops(ctx, view, ops, nops, mode, st);
+    ctx->status = own_status;
+    if (rc != REBXAMD_OK) {
+        std::string msg = "rebxamd_apply_static: " + ctx->err;
+        if (rc == REBXAMD_ERR_UNSUPPORTED && ctx->err.find("fixed scratch") != std::string::npos)
+            msg += " (limit: pushing ops x ceil(n / 512) x 24 bytes <= " + std::to_string(STATIC_SCRATCH_BYTES - SS_PARTIALS) + ")";
+        copy_msg(errbuf, errbuf_len, msg.c_str());
+    }
+    return rc;
 }
 
 extern "C" int rebxamd_apply_targets(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, int mode,
