@@ -75,6 +75,14 @@ int orc_tides_precession(const orc_sim* s, const double* R_tides, const double* 
  * PARTICLE coordinates are requested and no particle carries `primary` */
 int orc_modify_orbits_forces(const orc_sim* s, int coordinates, const double* tau_a, const double* tau_e,
                              const double* tau_inc, const uint8_t* primary);
+/* The same two forces evaluated in IEEE binary128 (rebx_oracle_hp.c): what gr (src/gr.c:73-171) and
+ * modify_orbits_forces in Jacobi or barycentric coordinates (src/modify_orbits_forces.c:77-118,
+ * src/rebxtools.c:45-126) ADD to every body's acceleration, as pairs of doubles: out[0..2] = leading
+ * parts of x, y, z, out[3..5] = remainders (value = hi + lo), each an array of N.  A yardstick for the
+ * rounding error of the fp64 evaluations (sequential here, parallel sums on the device). */
+int orc_hp_gr(const orc_sim* s, double c, int max_iterations, double* const out[6]);
+int orc_hp_modify_orbits_forces(const orc_sim* s, int coordinates, const double* tau_a, const double* tau_e, const double* tau_inc,
+                                double* const out[6]);
 /* src/core.c:860-866 */
 void orc_reset_accelerations(const orc_sim* s);
 

@@ -1,5 +1,8 @@
 """Shared helpers for the GPU parity tests: run the same stack of forces through the CPU
 checker and through librebxamd (device-resident C ABI) and compare accelerations."""
+import json
+import os
+
 import numpy as np
 
 import oracle
@@ -24,6 +27,36 @@ def rel_err(got, ref, scale_rows=None):
     den = np.maximum(np.abs(ref), FLOOR * big)
     den = np.where(den == 0.0, 1.0, den)
     return (np.abs(got - ref) / den).max(axis=0)
+
+
+def unfloored_rel_err(got, ref):
+    """|got - ref| / |ref| per component with NO floor (components whose reference value is exactly
+    zero are left out); per-particle maximum.  Reported beside rel_err: a component that nearly
+    cancels shows here with the full size of the rounding of its terms."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        e = np.where(ref != 0.0, np.abs(got - ref) / np.abs(ref), 0.0)
+    return e.max(axis=0)
+
+
+def err_vs_exact(got, hi, lo):
+    """|got - (hi + lo)| per component, for a binary128 value carried as a pair of doubles."""
+    return np.abs((np.asarray(got, dtype=np.float64) - hi) - lo)
+
+
+_REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.jsonl")
+
+
+def record(label, **numbers):
+    """Appends one line to gpurun_out/parity_report.jsonl (floored and un-floored error figures of a
+    parity case, for the record; never fails a test)."""
+    try:
+        os.makedirs(os.path.dirname(_REPORT), exist_ok=True)
+        with open(_REPORT, "a") as f:
+            f.write(json.dumps({"case": label, **{k: float(v) for k, v in numbers.items()}}) + "\n")
+    except OSError:
+        pass
 
 
 def ulp_diff(a, b):

@@ -105,6 +105,35 @@ def modify_orbits_forces(sim, coordinates=0, tau_a=None, tau_e=None, tau_inc=Non
     return lib.orc_modify_orbits_forces(ctypes.byref(sim.s), c_int(coordinates), _d(a), _d(b), _d(c), _d(f))
 
 
+def _hp(fn, sim, *args):
+    """Calls one of the binary128 evaluations; returns (hi, lo), each (3, N) float64, value = hi + lo."""
+    hi, lo = np.zeros((3, sim.N)), np.zeros((3, sim.N))
+    ptrs = (c_void_p * 6)(*[hi[k].ctypes.data for k in range(3)], *[lo[k].ctypes.data for k in range(3)])
+    rc = fn(ctypes.byref(sim.s), *args, ptrs)
+    assert rc == 0
+    return hi, lo
+
+
+def hp_gr(sim, c, max_iterations=10):
+    """What gr adds to the accelerations, evaluated in binary128 (oracle/rebx_oracle_hp.c)."""
+    return _hp(lib.orc_hp_gr, sim, c_double(c), c_int(max_iterations))
+
+
+def hp_modify_orbits_forces(sim, coordinates=0, tau_a=None, tau_e=None, tau_inc=None):
+    a, b, c = _col(tau_a, sim.N), _col(tau_e, sim.N), _col(tau_inc, sim.N)
+    return _hp(lib.orc_hp_modify_orbits_forces, sim, c_int(coordinates), _d(a), _d(b), _d(c))
+
+
+def hp_force(sim, force, pp):
+    """(hi, lo) of one prefix-sum force given as (name, effect parameters)."""
+    name, ep = force
+    if name == "gr":
+        return hp_gr(sim, ep["c"], ep.get("max_iterations", 10))
+    if name == "modify_orbits_forces" and ep.get("coordinates", 0) in (0, 1):
+        return hp_modify_orbits_forces(sim, ep.get("coordinates", 0), pp.get("tau_a"), pp.get("tau_e"), pp.get("tau_inc"))
+    raise ValueError("no binary128 evaluation of %s" % (force,))
+
+
 def newtonian_gravity(sim):
     lib.orc_newtonian_gravity(ctypes.byref(sim.s))
 

@@ -308,6 +308,61 @@ def test_sequential_interior_mass_drift():
     assert drift[-1] > 3 * drift[n // 10]      # grows with the index
 
 
+def _zero_acc(cols):
+    c = dict(cols)
+    for k in ("ax", "ay", "az"):
+        c[k] = np.zeros_like(cols["x"])
+    return c
+
+
+HP_FORCES = [("gr", {"c": synthetic.C_DEFAULT}), ("modify_orbits_forces", {}), ("modify_orbits_forces", {"coordinates": 1})]
+
+
+@pytest.mark.parametrize("force", HP_FORCES, ids=lambda f: f[0] + str(f[1].get("coordinates", "")))
+def test_binary128_evaluation_agrees_with_the_checker_on_short_sums_and_keeps_momentum(force):
+    """oracle/rebx_oracle_hp.c states gr and Jacobi/barycentric modify_orbits_forces in closed form
+    (interior sums, suffix sums) in binary128.  On the reference's own three-body test system, where
+    the sequential sums are three terms long, it must agree with the fp64 checker to rounding; and the
+    reactions must cancel the momentum handed out to ~1e-30 (they cancel identically in exact arithmetic)."""
+    cols = _zero_acc(synthetic.twoplanets())
+    pp = {"tau_a": np.array([np.nan, -1e4, np.nan]), "tau_e": np.array([np.nan, -1e3, -1e3]), "tau_inc": np.array([np.nan, np.nan, -1e3])}
+    hi, lo = oracle.hp_force(oracle.Sim(cols), force, pp)
+    s = oracle.Sim(cols)
+    oracle.apply_forces(s, [force], pp)
+    seq = np.array(s.acc)
+    scale = np.abs(hi).max(axis=0)
+    assert (np.abs((seq - hi) - lo) <= 2e-15 * scale[None, :]).all()
+    cols, pp, _ = synthetic.disk(500, 3, dust_mass=1e-7)
+    hi, lo = oracle.hp_force(oracle.Sim(_zero_acc(cols)), force, pp)
+    m = cols["m"].astype(np.longdouble)
+    net = np.abs(((hi.astype(np.longdouble) + lo.astype(np.longdouble)) * m).sum(axis=1))
+    handed = (np.abs(hi) * cols["m"]).sum(axis=1)
+    assert (net <= 1e-17 * handed.max()).all()        # long double sums of hi + lo: ~1e-19 per term
+
+
+def test_sequential_checker_drifts_from_the_binary128_value_with_the_number_of_bodies():
+    """The reference evaluates Jacobi modify_orbits_forces as sequential recurrences: the centre of mass
+    is down-dated one body at a time (src/rebxtools.c:77) and every reaction is subtracted from every
+    body before it one at a time (:96-106).  Both accumulate rounding with the number of bodies: the
+    distance of the fp64 checker (same order of operations) from the exact value of the same formulas,
+    relative to each body's largest component, grows from ~1e-14 at 257 bodies to ~5e-13 at 6000.  This
+    is the error a parallel evaluation of the same sums (the HIP library's prefix/suffix sums) cannot and
+    should not reproduce; tests/test_gpu_parity.py measures the device against the same exact value."""
+    worst = {}
+    for n in (257, 6000):
+        cols, pp, _ = synthetic.disk(n, 2, dust_mass=1e-9)
+        cols = _zero_acc(cols)
+        force = ("modify_orbits_forces", {})
+        hi, lo = oracle.hp_force(oracle.Sim(cols), force, pp)
+        s = oracle.Sim(cols)
+        oracle.apply_forces(s, [force], pp)
+        err = np.abs((np.array(s.acc) - hi) - lo)
+        worst[n] = (err / np.abs(hi).max(axis=0)[None, :]).max()
+    assert worst[257] < 1e-13
+    assert 1e-13 < worst[6000] < 1e-11
+    assert worst[6000] > 10 * worst[257]
+
+
 def test_gr_reproduces_second_notebook_pericentre_advance():
     kat = json.load(open(os.path.join(GOLDEN, "notebook_kats.json")))["gr_pomega_from_t0"]
     cols = _two_body(1.66013e-07, 0.387098, 0.205630)
