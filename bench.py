@@ -179,6 +179,95 @@ def c3_section(ctx, n, mode, device):
     return out
 
 
+def timed_evals(ctx, view, ops, mode, reps, warm=2):
+    """Seconds per rebxamd_apply (wall clock around `reps` queued evaluations) and the HIP-event time of its
+    streaming passes per evaluation."""
+    for _ in range(warm):
+        ctx.apply(view, ops, mode)
+    torch.cuda.synchronize()
+    ctx.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.apply(view, ops, mode)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    kernel_ms, _ = ctx.timing_read()
+    ctx.timing_enable(False)
+    return dt, kernel_ms / 1e3 / reps
+
+
+def ooc_section(ctx, n, mode, device):
+    """The headline stack on star + n massless grains with n large enough that nothing survives in the 256 MiB
+    last-level cache from one evaluation to the next (4e7 grains: 3.5 GB of columns): the same kernel as the
+    headline line, priced the same way (112 B per grain against 8 TB/s, HIP events on the launch stream)."""
+    cols = synthetic.disk_device(n + 1, device, dust_mass=0.0, newtonian=True)
+    keep = ("x", "y", "z", "vx", "vy", "vz", "m", "ax", "ay", "az", "beta")
+    dp = DeviceParticles({k: cols[k] for k in keep}, n_head=1, tail_massless=True)
+    del cols
+    ops = build_ops(STACK, synthetic.star_params())
+    dt, kernel_s = timed_evals(ctx, dp.view(), ops, mode, 10)
+    achieved = BYTES_PER_EVAL * n / kernel_s / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("out_of_cache", {}).get("hbm_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            traffic = None
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "particles": n, "kernel": "stream_kernel (tail pass)", "kernel_us": kernel_s * 1e6, "us_per_eval_wall": dt * 1e6,
+            "algorithmic_bytes_per_launch": BYTES_PER_EVAL * n,
+            "note": "same kernel and stack as the headline line; at 1e7 grains the three acceleration columns (240 MB) stay in the last-level cache between evaluations, here nothing does"}
+
+
+def c3_big_section(ctx, n_total, mode, dist, device, rank, world, red_dev):
+    """BASELINE configuration 3 at its full size: tides_precession + modify_orbits_forces + gr_potential on n_total
+    grains of 1e-15 solar masses (every body massive), generated on the device.  One GPU: the whole disk through
+    rebxamd_apply.  Several: the grains sharded by index over the ranks (every rank holds [star | its slice]); the
+    pushes on the star are summed with one all-reduce of 3 doubles per force, and in Jacobi coordinates the prefix
+    and suffix sums cross ranks through two all-gathers of 7 and 3 doubles (reboundx_amd.dist).  Strong scaling: the
+    total size is fixed; the time is the slowest rank's, collectives included."""
+    from reboundx_amd.dist import apply_forces_sharded, particle_shard
+    lo, hi = particle_shard(n_total, 1, world, rank)
+    cols = synthetic.disk_device(1 + (hi - lo), device, dust_mass=1e-15, seed=3 + rank)
+    keep = ("x", "y", "z", "vx", "vy", "vz", "m", "ax", "ay", "az", "R_tides", "k1", "tau_a", "tau_e", "tau_inc")
+    dp = DeviceParticles({k: cols[k] for k in keep}, n_head=1, tail_massless=False)
+    del cols
+    sp = synthetic.star_params()
+    out = {"n_total": n_total, "n_gpus": world, "bytes_per_eval": 144, "scaling": "strong",
+           "sharding": "one GPU, rebxamd_apply" if world == 1 else "grains by index over ranks; all-reduce of the pushes on the star, all-gathers of the prefix/suffix sums"}
+    reps = 5
+    for label, coords in (("particle", 2), ("jacobi", 0)):
+        stack = [("tides_precession", {}), ("modify_orbits_forces", {"coordinates": coords}), ("gr_potential", {"c": C})]
+        ops = build_ops(stack, sp)
+
+        def run():
+            if world == 1:
+                ctx.apply(dp.view(), ops, mode)
+            else:
+                apply_forces_sharded(ctx, dp, ops, mode)
+        for _ in range(2):
+            run()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            run()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = (time.perf_counter() - t0) / reps
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        peak = HBM_PEAK_GBS * world
+        out[label] = {"ms_per_eval": dt * 1e3, "evals_per_s": n_total / dt,
+                      "roofline": {"bound": "hbm", "achieved": 144 * n_total / dt / 1e9, "peak": peak, "unit": "GB/s", "frac": 144 * n_total / dt / 1e9 / peak}}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,6 +282,8 @@ def main():
     ap.add_argument("--c5-n", type=int, default=1_000_000, help="0 disables the device-resident stepping section")
     ap.add_argument("--c5-steps", type=int, default=10_000)
     ap.add_argument("--c3-n", type=int, default=10_000_000, help="0 disables the all-massive stack section")
+    ap.add_argument("--c3-big-n", type=int, default=100_000_000, help="total grains of the full-size all-massive stack, sharded over the ranks; 0 disables")
+    ap.add_argument("--ooc-n", type=int, default=40_000_000, help="grains of the out-of-cache run of the headline stack; 0 disables")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -296,7 +387,20 @@ def main():
             gr = grfull_section(ctx, args.grfull_n, mode, dist, "cuda:%d" % local_rank)     # collective: every rank takes part
         except Exception as e:  # noqa: BLE001 -- a failure of this secondary section must not lose the headline line
             gr = {"error": "%s: %s" % (type(e).__name__, e)}
+    big = None
+    if args.c3_big_n > 0:
+        try:
+            big = c3_big_section(ctx, args.c3_big_n, mode, dist, "cuda:%d" % local_rank, rank, world, red_dev)    # collective
+        except Exception as e:  # noqa: BLE001
+            big = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
+        if big is not None:
+            out["massive_stack_full_size"] = big
+        if args.ooc_n > 0:
+            try:
+                out["roofline_out_of_cache"] = ooc_section(ctx, args.ooc_n, mode, "cuda:%d" % local_rank)
+            except Exception as e:  # noqa: BLE001
+                out["roofline_out_of_cache"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if args.c5_n > 0:
             try:
                 out["resident_run"] = c5_section(ctx, args.c5_n, args.c5_steps, mode, "cuda:%d" % local_rank)

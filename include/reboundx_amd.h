@@ -558,9 +558,14 @@ int rebxamd_grfull_sweep(rebxamd_ctx* ctx, const rebxamd_view* view, double c, i
                          const double* acx, const double* acy, const double* acz,       /* a_const, rows in range valid */
                          double* outx, double* outy, double* outz,                      /* a_new, rows in range written */
                          uint32_t* dev_flag, int mode, void* stream);
+/* Lets a driver queue sweeps ahead of the host (no counterpart in the reference): while stop_dev != NULL,
+ * the kernels of every rebxamd_grfull_sweep call on this context return at once, writing nothing, when the
+ * device word *stop_dev is non-zero at the time they run.  NULL (default) switches this off. */
+int rebxamd_grfull_stop_word(rebxamd_ctx* ctx, const uint32_t* stop_dev);
 /* Whole evaluation on one device, including the reference's stopping rule; adds the result
- * to view->a{x,y,z}.  *sweeps receives the number of sweeps run.  Synchronises (it reads
- * the stopping flag after every sweep). */
+ * to view->a{x,y,z}.  The ten sweeps are queued at once and the stopping rule is evaluated on the device
+ * (sweeps past the one that meets it return at once).  *sweeps (may be NULL) receives the number of sweeps
+ * run: asking for it waits for the stream; with NULL the call is asynchronous. */
 int rebxamd_grfull(rebxamd_ctx* ctx, const rebxamd_view* view, double c, int gravity_ignore_10, int mode, int* sweeps, void* stream);
 
 #ifdef __cplusplus

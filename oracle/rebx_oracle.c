@@ -549,6 +549,8 @@ void orc_gr_full_pot(const orc_sim* s, double c, int row0, int row1, double* pot
     const int N = s->N;
     const double G = s->G, C2 = c * c;
     body* p = gather(s);
+    /* (rows are independent; threads only shorten the wait at large N -- each row's own sum keeps the reference's order) */
+#pragma omp parallel for schedule(static) if (row1 - row0 > 256)
     for (int i = row0; i < row1; i++) {
         double s2 = 0.;
         for (int k = 0; k < N; k++) {
@@ -567,6 +569,7 @@ void orc_gr_full_const(const orc_sim* s, double c, int row0, int row1, const dou
     const int N = s->N;
     const double G = s->G, C2 = c * c;
     body* p = gather(s);
+#pragma omp parallel for schedule(static) if (row1 - row0 > 256)
     for (int i = row0; i < row1; i++) {
         double cx = 0., cy = 0., cz = 0.;
         const double vi2 = p[i].vx * p[i].vx + p[i].vy * p[i].vy + p[i].vz * p[i].vz;
@@ -609,6 +612,7 @@ int orc_gr_full_sweep(const orc_sim* s, double c, int row0, int row1,
     const double G = s->G, C2 = c * c;
     body* p = gather(s);
     int unconverged = 0;
+#pragma omp parallel for schedule(static) reduction(|:unconverged) if (row1 - row0 > 256)
     for (int i = row0; i < row1; i++) {
         double nx = 0., ny = 0., nz = 0.;
         for (int j = 0; j < N; j++) {

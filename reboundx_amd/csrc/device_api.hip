@@ -22,7 +22,8 @@ struct rebxamd_ctx {
     size_t partials_cap = 0;
     double* gf = nullptr;               // gr_full workspace
     size_t gf_cap = 0;
-    unsigned* gf_flag = nullptr;
+    unsigned* gf_flag = nullptr;        // gr_full control words: stop, sweeps run, vote of the sweep just run (+ one spare)
+    const unsigned* gf_stop = nullptr;  // caller's stop word for rebxamd_grfull_sweep (rebxamd_grfull_stop_word)
     double* chunk_sums = nullptr;       // second-stage scratch of the back-reaction reduction
     void* hpin = nullptr;               // 512 B of pinned host memory: small results come back through it (no staging copy inside the runtime)
     double* star = nullptr;             // 3 x 16 doubles: records of body 0 around Wisdom-Holman drifts (two alternate between steps, one for the leading half drift)
@@ -96,7 +97,7 @@ extern "C" int rebxamd_create(int device, rebxamd_ctx** out) {
         hipMalloc((void**)&ctx->hc, 4 * sizeof(HeadConsts)) != hipSuccess ||
         hipMalloc((void**)&ctx->status, sizeof(unsigned)) != hipSuccess ||
         hipMalloc((void**)&ctx->ll, sizeof(long long)) != hipSuccess ||
-        hipMalloc((void**)&ctx->gf_flag, sizeof(unsigned)) != hipSuccess ||
+        hipMalloc((void**)&ctx->gf_flag, 4 * sizeof(unsigned)) != hipSuccess ||
         hipMalloc((void**)&ctx->star, 48 * sizeof(double)) != hipSuccess ||
         hipHostMalloc(&ctx->hpin, 512, hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void**)&ctx->chunk_sums, sizeof(double) * REBXAMD_MAX_OPS * 64 * 3) != hipSuccess ||
@@ -424,8 +425,7 @@ static int apply_ops(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_o
     int lo = 0;
     while (lo < nops) {
         if (ops[lo].kind == REBXAMD_OP_GR_FULL) {
-            int sweeps = 0;
-            const int rc = rebxamd_grfull(ctx, view, ops[lo].a, ops[lo].iarg, mode, &sweeps, (void*)st);
+            const int rc = rebxamd_grfull(ctx, view, ops[lo].a, ops[lo].iarg, mode, nullptr, (void*)st);
             if (rc != REBXAMD_OK) return rc;
             lo++;
             continue;
@@ -1190,7 +1190,13 @@ extern "C" int rebxamd_grfull_sweep(rebxamd_ctx* ctx, const rebxamd_view* u, dou
         if (rc != REBXAMD_OK) return rc;
     }
     HIP_TRY(launch_grfull_pass(2, make_view(u), u->G, c, row0, row1, nullptr, anx, any_, anz, aox, aoy, aoz, acx, acy, acz,
-                               outx, outy, outz, dev_flag, ctx->partials, exact, st));
+                               outx, outy, outz, dev_flag, ctx->partials, exact, st, ctx->gf_stop));
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_grfull_stop_word(rebxamd_ctx* ctx, const uint32_t* stop_dev) {
+    if (!ctx) return REBXAMD_ERR_ARG;
+    ctx->gf_stop = stop_dev;
     return REBXAMD_OK;
 }
 
@@ -1236,24 +1242,28 @@ extern "C" int rebxamd_grfull(rebxamd_ctx* ctx, const rebxamd_view* u, double c,
     if (rc != REBXAMD_OK) return rc;
     rc = rebxamd_grfull_const(ctx, u, c, 0, n, pot, acx, acy, acz, mode, stream);
     if (rc != REBXAMD_OK) return rc;
-    int k = 0;
-    unsigned flag = 0;
-    for (k = 0; k < 10; k++) {          // reference gr_full.c:173: the bound is the literal 10
-        HIP_TRY(hipMemsetAsync(ctx->gf_flag, 0, sizeof(unsigned), st));
-        rc = rebxamd_grfull_sweep(ctx, u, c, 0, n, anx, any_, anz, aox, aoy, aoz, acx, acy, acz, nwx, nwy, nwz, ctx->gf_flag, mode, stream);
-        if (rc != REBXAMD_OK) return rc;
-        { const int rb = read_back(ctx, &flag, ctx->gf_flag, sizeof(flag), st); if (rb != REBXAMD_OK) return rb; }
-        std::swap(aox, nwx); std::swap(aoy, nwy); std::swap(aoz, nwz);   // a_old now holds the newest iterate
-        if (!flag) { k++; break; }
+    // All ten sweeps (reference gr_full.c:173: the bound is the literal 10) are queued at once: the stopping rule is
+    // evaluated on the device, and the kernels of a sweep queued past the one that met it return at once.  Sweep k reads
+    // the iterate in buffer k & 1 and writes the other one.  The host waits only if the caller asks for the sweep count.
+    unsigned* const ctl = ctx->gf_flag;
+    HIP_TRY(hipMemsetAsync(ctl, 0, 4 * sizeof(unsigned), st));
+    double* const b0[3] = {aox, aoy, aoz};
+    double* const b1[3] = {nwx, nwy, nwz};
+    const unsigned* const caller_stop = ctx->gf_stop;
+    ctx->gf_stop = ctl;
+    for (int k = 0; k < 10 && rc == REBXAMD_OK; k++) {
+        double* const* src = (k & 1) ? b1 : b0;
+        double* const* dst = (k & 1) ? b0 : b1;
+        rc = rebxamd_grfull_sweep(ctx, u, c, 0, n, anx, any_, anz, src[0], src[1], src[2], acx, acy, acz, dst[0], dst[1], dst[2], ctl + 2, mode, stream);
+        if (rc == REBXAMD_OK && launch_grfull_vote(ctl, st) != hipSuccess) rc = fail(ctx, REBXAMD_ERR_HIP, "gr_full: vote kernel");
     }
-    if (flag) {                         // all ten sweeps ran without meeting the stopping rule
-        unsigned bit = WARN_GRFULL_SWEEPS, cur = 0;
-        { const int rb = read_back(ctx, &cur, ctx->status, sizeof(cur), st); if (rb != REBXAMD_OK) return rb; }
-        cur |= bit;
-        HIP_TRY(hipMemcpyAsync(ctx->status, &cur, sizeof(cur), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
+    ctx->gf_stop = caller_stop;
+    if (rc != REBXAMD_OK) return rc;
+    HIP_TRY(launch_grfull_finish_select(v, b0, b1, ctl, ctx->status, st));
+    if (sweeps) {
+        unsigned h[2] = {0u, 0u};
+        { const int rb = read_back(ctx, h, ctl, sizeof(h), st); if (rb != REBXAMD_OK) return rb; }
+        *sweeps = (int)h[1];
     }
-    if (sweeps) *sweeps = k;
-    HIP_TRY(launch_grfull_finish(v, aox, aoy, aoz, st));
     return REBXAMD_OK;
 }

@@ -33,6 +33,7 @@ struct GrFullArgs {
     const double *pot;                  // const pass
     const double *anx, *any_, *anz, *aox, *aoy, *aoz;   // sweep pass
     double* part;                       // [nchunks][nrows][ncomp]
+    const unsigned* stop;               // sweeps queued ahead of the host: the pass returns at once when *stop is set (nullptr: never)
 };
 
 // ------------------------------------------------------------------ fast passes
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(GB) void grfull_fast_kernel(GrFullArgs a) {
     __shared__ TileA ta[GB];
     __shared__ TileB tb[GB];
     const int tid = threadIdx.x;
+    if (PASS == PASS_SWEEP && a.stop != nullptr && *a.stop != 0u) return;       // a sweep queued past convergence
     const long long nrows = a.row1 - a.row0;
     const long long j0 = (long long)blockIdx.y * a.jchunk;
     long long j1 = j0 + a.jchunk; if (j1 > a.n) j1 = a.n;
@@ -185,7 +187,8 @@ template <int PASS>
 __global__ __launch_bounds__(256) void grfull_combine_kernel(const double* part, int nchunks, long long row0, long long row1,
                                                              const double* acx, const double* acy, const double* acz,
                                                              const double* aox, const double* aoy, const double* aoz,
-                                                             double* o0, double* o1, double* o2, unsigned* flag) {
+                                                             double* o0, double* o1, double* o2, unsigned* flag, const unsigned* stop) {
+    if (PASS == PASS_SWEEP && stop != nullptr && *stop != 0u) return;
     const long long nrows = row1 - row0;
     const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
     bool unconverged = false;
@@ -223,6 +226,7 @@ template <int PASS>
 __global__ __launch_bounds__(GB) void grfull_exact_kernel(GrFullArgs a, const double* acx, const double* acy, const double* acz,
                                                           double* o0, double* o1, double* o2, unsigned* flag) {
 #pragma clang fp contract(off)
+    if (PASS == PASS_SWEEP && a.stop != nullptr && *a.stop != 0u) return;
     const long long r = (long long)blockIdx.x * GB + threadIdx.x;
     const long long i = a.row0 + r;
     bool unconverged = false;
@@ -314,6 +318,27 @@ __global__ __launch_bounds__(256) void grfull_prepare_kernel(View v, double G, i
 }
 
 __global__ __launch_bounds__(256) void grfull_finish_kernel(View v, const double* ax, const double* ay, const double* az) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < v.n; i += (long long)gridDim.x * 256) {
+        v.ax[i] += ax[i]; v.ay[i] += ay[i]; v.az[i] += az[i];
+    }
+}
+
+// Sweeps queued ahead of the host (rebxamd_grfull): ctl[0] = stop (the stopping rule has been met), ctl[1] = sweeps
+// run, ctl[2] = the vote of the sweep that has just run (raised by any row that fails the rule).
+__global__ void grfull_vote_kernel(unsigned* ctl) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || ctl[0] != 0u) return;
+    ctl[1] += 1u;
+    if (ctl[2] == 0u) ctl[0] = 1u;
+    ctl[2] = 0u;
+}
+// v.a += the newest iterate: sweep k reads buffer k & 1 and writes the other one, so after ctl[1] sweeps it is
+// buffer ctl[1] & 1.  All ten sweeps run and the rule still not met: the reference's warning (gr_full.c:221-223).
+__global__ __launch_bounds__(256) void grfull_finish_select_kernel(View v, const double* b0x, const double* b0y, const double* b0z,
+                                                                   const double* b1x, const double* b1y, const double* b1z,
+                                                                   const unsigned* ctl, unsigned* status) {
+    const bool odd = (ctl[1] & 1u) != 0u;
+    const double* ax = odd ? b1x : b0x; const double* ay = odd ? b1y : b0y; const double* az = odd ? b1z : b0z;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && ctl[0] == 0u) atomicOr(status, WARN_GRFULL_SWEEPS);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < v.n; i += (long long)gridDim.x * 256) {
         v.ax[i] += ax[i]; v.ay[i] += ay[i]; v.az[i] += az[i];
     }
@@ -496,7 +521,7 @@ static GrFullArgs base_args(const View& v, double G, double c, long long row0, l
     a.n = v.n; a.row0 = row0; a.row1 = row1; a.jchunk = v.n;
     a.G = G; a.C2 = c * c; a.invC2 = 1. / (c * c);
     a.x = v.x; a.y = v.y; a.z = v.z; a.vx = v.vx; a.vy = v.vy; a.vz = v.vz; a.m = v.m;
-    a.pot = nullptr; a.anx = a.any_ = a.anz = a.aox = a.aoy = a.aoz = nullptr; a.part = nullptr;
+    a.pot = nullptr; a.anx = a.any_ = a.anz = a.aox = a.aoy = a.aoz = nullptr; a.part = nullptr; a.stop = nullptr;
     return a;
 }
 
@@ -504,10 +529,11 @@ hipError_t launch_grfull_pass(int pass, const View& v, double G, double c, long 
                               const double* anx, const double* any_, const double* anz,
                               const double* aox, const double* aoy, const double* aoz,
                               const double* acx, const double* acy, const double* acz,
-                              double* o0, double* o1, double* o2, unsigned* flag, double* part, bool exact, hipStream_t st) {
+                              double* o0, double* o1, double* o2, unsigned* flag, double* part, bool exact, hipStream_t st, const unsigned* stop) {
     const long long nrows = row1 - row0;
     if (nrows <= 0) return hipSuccess;
     GrFullArgs a = base_args(v, G, c, row0, row1);
+    a.stop = stop;
     a.pot = pot; a.anx = anx; a.any_ = any_; a.anz = anz; a.aox = aox; a.aoy = aoy; a.aoz = aoz;
     if (exact) {
         const dim3 g((unsigned)((nrows + GB - 1) / GB)), b(GB);
@@ -524,15 +550,15 @@ hipError_t launch_grfull_pass(int pass, const View& v, double G, double c, long 
     if (pass == PASS_POT) {
         if (two) hipLaunchKernelGGL((grfull_fast_kernel<PASS_POT, 2>), g, b, 0, st, a);
         else hipLaunchKernelGGL((grfull_fast_kernel<PASS_POT, 1>), g, b, 0, st, a);
-        hipLaunchKernelGGL(grfull_combine_kernel<PASS_POT>, g2, b2, 0, st, part, p.nchunks, row0, row1, acx, acy, acz, aox, aoy, aoz, o0, o1, o2, flag);
+        hipLaunchKernelGGL(grfull_combine_kernel<PASS_POT>, g2, b2, 0, st, part, p.nchunks, row0, row1, acx, acy, acz, aox, aoy, aoz, o0, o1, o2, flag, stop);
     } else if (pass == PASS_CONST) {
         if (two) hipLaunchKernelGGL((grfull_fast_kernel<PASS_CONST, 2>), g, b, 0, st, a);
         else hipLaunchKernelGGL((grfull_fast_kernel<PASS_CONST, 1>), g, b, 0, st, a);
-        hipLaunchKernelGGL(grfull_combine_kernel<PASS_CONST>, g2, b2, 0, st, part, p.nchunks, row0, row1, acx, acy, acz, aox, aoy, aoz, o0, o1, o2, flag);
+        hipLaunchKernelGGL(grfull_combine_kernel<PASS_CONST>, g2, b2, 0, st, part, p.nchunks, row0, row1, acx, acy, acz, aox, aoy, aoz, o0, o1, o2, flag, stop);
     } else {
         if (two) hipLaunchKernelGGL((grfull_fast_kernel<PASS_SWEEP, 2>), g, b, 0, st, a);
         else hipLaunchKernelGGL((grfull_fast_kernel<PASS_SWEEP, 1>), g, b, 0, st, a);
-        hipLaunchKernelGGL(grfull_combine_kernel<PASS_SWEEP>, g2, b2, 0, st, part, p.nchunks, row0, row1, acx, acy, acz, aox, aoy, aoz, o0, o1, o2, flag);
+        hipLaunchKernelGGL(grfull_combine_kernel<PASS_SWEEP>, g2, b2, 0, st, part, p.nchunks, row0, row1, acx, acy, acz, aox, aoy, aoz, o0, o1, o2, flag, stop);
     }
     return hipGetLastError();
 }
@@ -542,6 +568,18 @@ hipError_t launch_grfull_prepare(const View& v, double G, int gravity_ignore_10,
     if (v.n <= 0) return hipSuccess;
     long long nb = (v.n + 255) / 256; if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(grfull_prepare_kernel, dim3((unsigned)nb), dim3(256), 0, st, v, G, gravity_ignore_10, anx, any_, anz, a0x, a0y, a0z);
+    return hipGetLastError();
+}
+
+hipError_t launch_grfull_vote(unsigned* ctl, hipStream_t st) {
+    hipLaunchKernelGGL(grfull_vote_kernel, dim3(1), dim3(64), 0, st, ctl);
+    return hipGetLastError();
+}
+
+hipError_t launch_grfull_finish_select(const View& v, double* const b0[3], double* const b1[3], const unsigned* ctl, unsigned* status, hipStream_t st) {
+    if (v.n <= 0) return hipSuccess;
+    long long nb = (v.n + 255) / 256; if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(grfull_finish_select_kernel, dim3((unsigned)nb), dim3(256), 0, st, v, b0[0], b0[1], b0[2], b1[0], b1[1], b1[2], ctl, status);
     return hipGetLastError();
 }
 

@@ -165,7 +165,11 @@ hipError_t launch_grfull_pass(int pass, const View& v, double G, double c, long 
                               const double* anx, const double* any_, const double* anz,
                               const double* aox, const double* aoy, const double* aoz,
                               const double* acx, const double* acy, const double* acz,
-                              double* o0, double* o1, double* o2, unsigned* flag, double* part, bool exact, hipStream_t st);
+                              double* o0, double* o1, double* o2, unsigned* flag, double* part, bool exact, hipStream_t st,
+                              const unsigned* stop = nullptr);
+// sweeps queued ahead of the host: ctl = {stop, sweeps run, vote of the sweep just run}
+hipError_t launch_grfull_vote(unsigned* ctl, hipStream_t st);
+hipError_t launch_grfull_finish_select(const View& v, double* const b0[3], double* const b1[3], const unsigned* ctl, unsigned* status, hipStream_t st);
 size_t grfull_hamiltonian_doubles(long long n);
 hipError_t launch_grfull_hamiltonian(const View& v, double G, double c, double* ws, double** out, hipStream_t st);
 hipError_t launch_grfull_prepare(const View& v, double G, int gravity_ignore_10, double* anx, double* any_, double* anz,

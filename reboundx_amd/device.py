@@ -178,6 +178,10 @@ class Context:
         self._check(lib.rebxamd_grfull(self._h, ctypes.byref(view), c, gravity_ignore_10, mode, ctypes.byref(sweeps), self._stream()))
         return sweeps.value
 
+    def grfull_stop_word(self, word):
+        """word: int32 device tensor (kept alive by the caller) or None."""
+        self._check(lib.rebxamd_grfull_stop_word(self._h, ctypes.c_void_p(word.data_ptr()) if word is not None else None))
+
     def grfull_newton(self, view, gravity_ignore_10, an, a0):
         self._check(lib.rebxamd_grfull_newton(self._h, ctypes.byref(view), gravity_ignore_10, an[0].data_ptr(), an[1].data_ptr(), an[2].data_ptr(),
                                               a0[0].data_ptr(), a0[1].data_ptr(), a0[2].data_ptr(), self._stream()))

@@ -215,6 +215,10 @@ class HipGrFullEngine:
     def finish(self, a):
         self.ctx.grfull_finish(self.view, a)
 
+    def set_stop(self, word):
+        """word: int32 device tensor; while set, sweeps queued behind a non-zero word return at once."""
+        self.ctx.grfull_stop_word(word)
+
 
 def grfull_sharded(engine, c, gravity_ignore_10=0, group=None):
     """One gr_full evaluation (reference src/gr_full.c:61-231) with rows sharded over the
@@ -248,21 +252,58 @@ def grfull_sharded(engine, c, gravity_ignore_10=0, group=None):
     if use_dist:
         _all_gather_into(pot, pot[rank * per:(rank + 1) * per].clone(), group)
     engine.const(c, r0, r1, pot, ac)
-    sweeps = 0
-    for k in range(10):                             # reference loop bound (gr_full.c:173)
-        sweeps = k + 1
+    bufs = [ao3, out3]                              # sweep k reads the iterate in bufs[k % 2] and writes bufs[(k + 1) % 2]
+
+    def one_sweep(k):
+        """Queues sweep k and its exchange; returns the device tensor that is non-zero while any rank's rows fail
+        the stopping rule."""
+        src, dst = bufs[k % 2], bufs[(k + 1) % 2]
         flag.zero_()
-        engine.sweep(c, r0, r1, an, [ao3[0], ao3[1], ao3[2]], ac, [out3[0], out3[1], out3[2]], flag)
-        if use_dist:
-            send[:3 * per].view(3, per).copy_(out3.view(3, world, per)[:, rank, :])
-            send[3 * per:].copy_(flag)
-            _all_gather_into(recv_flat, send, group)
-            out3.view(3, world, per).copy_(recv[:, :3 * per].view(world, 3, per).permute(1, 0, 2))
-            unconverged = float(recv[:, 3 * per].max().item()) != 0.0
-        else:
-            unconverged = int(flag.item()) != 0
-        ao3, out3 = out3, ao3
-        if not unconverged:
-            break
-    engine.finish([ao3[0], ao3[1], ao3[2]])
+        engine.sweep(c, r0, r1, an, [src[0], src[1], src[2]], ac, [dst[0], dst[1], dst[2]], flag)
+        if not use_dist:
+            return flag
+        send[:3 * per].view(3, per).copy_(dst.view(3, world, per)[:, rank, :])
+        send[3 * per:].copy_(flag)
+        _all_gather_into(recv_flat, send, group)
+        dst.view(3, world, per).copy_(recv[:, :3 * per].view(world, 3, per).permute(1, 0, 2))
+        return recv[:, 3 * per].max()
+
+    sweeps, converged = 10, False
+    if hasattr(engine, "set_stop") and pot.is_cuda:
+        # Sweeps are queued one ahead of the host: the vote of sweep k is turned into a stop word on the device
+        # (the kernels of a sweep queued behind a set word return at once, writing nothing) and copied to pinned
+        # memory without waiting; the host looks at the vote of sweep k - 1 after it has queued sweep k.
+        stop = engine.flag()
+        votes = torch.ones(10, dtype=torch.int32).pin_memory()
+        events = []
+        engine.set_stop(stop)
+        try:
+            for k in range(10):                     # reference loop bound (gr_full.c:173)
+                vote = one_sweep(k)
+                unconv = (vote != 0).to(torch.int32).reshape(1)
+                torch.maximum(stop, 1 - unconv, out=stop)
+                votes[k:k + 1].copy_(unconv, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                events.append(ev)
+                if k >= 1:
+                    events[k - 1].synchronize()
+                    if int(votes[k - 1]) == 0:      # sweep k - 1 met the rule: k sweeps ran, sweep k was skipped on the device
+                        sweeps, converged = k, True
+                        break
+            if not converged:
+                events[-1].synchronize()
+                converged = int(votes[9]) == 0
+        finally:
+            engine.set_stop(None)
+    else:
+        for k in range(10):
+            if float(one_sweep(k)) == 0.0:
+                sweeps, converged = k + 1, True
+                break
+    if not converged:
+        import warnings
+        warnings.warn("10 loops in rebx_gr_full did not converge.")      # the reference's message (gr_full.c:221-223)
+    newest = bufs[sweeps % 2]
+    engine.finish([newest[0], newest[1], newest[2]])
     return sweeps

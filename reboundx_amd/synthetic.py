@@ -106,6 +106,65 @@ def disk(n, n_planets=0, seed=3, lo=0, hi=None, dust_mass=0.0, with_head=True):
     return cols, pp, idx
 
 
+def disk_device(n, device, dust_mass=0.0, seed=3, newtonian=False):
+    """The same kind of disk as :func:`disk` with no planets (star at index 0, dust on a in [1,1.2], e in
+    [0,0.1], inc in [0,0.1], the same parameter values), generated ON THE GPU with torch's generator, for
+    sizes at which building the columns on the host would dominate a run (1e8 bodies: 50 ms instead of 30 s).
+    Not the same random numbers as :func:`disk`: callers that need a host copy of some bodies copy those rows
+    back.  Returns a dict of float64 device columns: x y z vx vy vz m ax ay az beta R_tides k1 tau_a tau_e
+    tau_inc (NaN = not set).  newtonian: accelerations start as the star's Newtonian pull instead of zero."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    u = lambda: torch.rand(n, dtype=torch.float64, device=device, generator=g)
+    a = 1.0 + 0.2 * u()
+    e = 0.1 * u()
+    inc = 0.1 * u()
+    Om, om, f = 2 * np.pi * u(), 2 * np.pi * u(), 2 * np.pi * u()
+    mu = 1.0 + dust_mass
+    r = a * (1.0 - e * e) / (1.0 + e * torch.cos(f))
+    v0 = torch.sqrt(mu / (a * (1.0 - e * e)))
+    del a
+    cO, sO, co, so, ci, si, cf, sf = torch.cos(Om), torch.sin(Om), torch.cos(om), torch.sin(om), torch.cos(inc), torch.sin(inc), torch.cos(f), torch.sin(f)
+    del Om, om, inc, f
+    cols = {}
+    cols["x"] = r * (cO * (co * cf - so * sf) - sO * (so * cf + co * sf) * ci)
+    cols["y"] = r * (sO * (co * cf - so * sf) + cO * (so * cf + co * sf) * ci)
+    cols["z"] = r * (so * cf + co * sf) * si
+    cols["vx"] = v0 * ((e + cf) * (-ci * co * sO - cO * so) - sf * (co * cO - ci * so * sO))
+    cols["vy"] = v0 * ((e + cf) * (ci * co * cO - sO * so) - sf * (co * sO + ci * so * cO))
+    cols["vz"] = v0 * ((e + cf) * co * si - sf * si * so)
+    del r, v0, e, cO, sO, co, so, ci, si, cf, sf
+    cols["m"] = torch.full((n,), float(dust_mass), dtype=torch.float64, device=device)
+    for k in ("x", "y", "z", "vx", "vy", "vz"):
+        cols[k][0] = 0.0
+    cols["m"][0] = 1.0
+    for k in ("ax", "ay", "az"):
+        cols[k] = torch.zeros(n, dtype=torch.float64, device=device)
+    if newtonian:
+        r2 = cols["x"] ** 2 + cols["y"] ** 2 + cols["z"] ** 2
+        r2[0] = 1.0
+        w = -1.0 / (r2 * torch.sqrt(r2))
+        w[0] = 0.0
+        for k, s in (("ax", "x"), ("ay", "y"), ("az", "z")):
+            cols[k] = w * cols[s]
+        del r2, w
+    cols["beta"] = 0.01 + 0.49 * u()
+    for k, val, star in (("tau_a", -1.0e4, np.nan), ("tau_e", -1.0e3, np.nan), ("tau_inc", -1.0e3, np.nan), ("R_tides", 1.0e-5, 1.0e-3), ("k1", 0.3, 0.4)):
+        cols[k] = torch.full((n,), val, dtype=torch.float64, device=device)
+        cols[k][0] = star
+    cols["beta"][0] = np.nan
+    return cols
+
+
+def star_params():
+    """Per-particle parameters of the star of :func:`disk` / :func:`disk_device`, as length-1 host columns
+    (what :func:`reboundx_amd.program.build_ops` needs when every source is the star)."""
+    nan = np.array([np.nan])
+    return {"beta": nan.copy(), "tau_a": nan.copy(), "tau_e": nan.copy(), "tau_inc": nan.copy(), "R_tides": np.array([1.0e-3]), "k1": np.array([0.4]),
+            "J2": np.array([1.0e-3]), "J4": np.array([1.0e-3]), "R_eq": np.array([1.0e-3]), "primary": np.array([1], dtype=np.uint8)}
+
+
 def add_newtonian(cols, G=1.0, n_head=None):
     """Adds the Newtonian pull of the massive head bodies to the accelerations (what REBOUND's
     gravity routine leaves in particles[i].a before the additional-force hook runs)."""

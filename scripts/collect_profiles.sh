@@ -8,6 +8,6 @@ ROOT="$(pwd)"
 OUT="$ROOT/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_trace" -o bench -- python3 "$ROOT/bench.py" --no-cpu > "$OUT/prof_trace.log" 2>&1
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/prof_fetch" -o fetch -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu --grfull-n 0 --c5-n 0 --c3-n 0 > "$OUT/prof_fetch.log" 2>&1
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/prof_write" -o write -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu --grfull-n 0 --c5-n 0 --c3-n 0 > "$OUT/prof_write.log" 2>&1
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/prof_fetch" -o fetch -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu --grfull-n 0 --c5-n 0 --c3-n 0 --c3-big-n 0 --ooc-n 0 > "$OUT/prof_fetch.log" 2>&1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/prof_write" -o write -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu --grfull-n 0 --c5-n 0 --c3-n 0 --c3-big-n 0 --ooc-n 0 > "$OUT/prof_write.log" 2>&1
 find "$OUT"/prof_trace "$OUT"/prof_fetch "$OUT"/prof_write -name "*.csv" | head -20

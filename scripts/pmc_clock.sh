@@ -5,7 +5,7 @@ set -e
 ROOT="$(pwd)"
 OUT="$ROOT/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$OUT/prof_clock" -o clk -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu --c5-n 0 --c3-n 0 > "$OUT/prof_clock.log" 2>&1
+timeout -s KILL 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$OUT/prof_clock" -o clk -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu --c5-n 0 --c3-n 0 --c3-big-n 0 --ooc-n 0 > "$OUT/prof_clock.log" 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
@@ -20,7 +20,7 @@ for r in rows:
             acc[k[:60]]["dur_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 import json
 summary = {"source": "rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --kernel-trace on "
-                     "`bench.py --steps 3 --warmup 1 --no-cpu --c5-n 0 --c3-n 0`; clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel duration", "kernels": {}}
+                     "`bench.py --steps 3 --warmup 1 --no-cpu --c5-n 0 --c3-n 0 --c3-big-n 0 --ooc-n 0`; clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel duration", "kernels": {}}
 for k, d in acc.items():
     m = {c: sum(v) / len(v) for c, v in d.items()}
     summary["kernels"][k] = {"dispatches": len(d["SQ_WAVES"]), "duration_us": m.get("dur_ns", 0) / 1e3,

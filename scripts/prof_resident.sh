@@ -4,7 +4,7 @@ set -e
 ROOT="$(pwd)"
 OUT="$ROOT/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_resident" -o res -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu --grfull-n 0 --c3-n 0 --c5-steps 2000 > "$OUT/prof_resident.log" 2>&1
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_resident" -o res -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu --grfull-n 0 --c3-n 0 --c3-big-n 0 --ooc-n 0 --c5-steps 2000 > "$OUT/prof_resident.log" 2>&1
 tail -1 "$OUT/prof_resident.log" | cut -c1-300
 python3 - "$OUT" <<'PY'
 import csv, glob, sys

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_prints_one_json_line_with_the_contract_fields():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--n-per-gpu", "200000", "--cpu-reps", "1",
-                        "--grfull-n", "2048", "--c5-n", "50000", "--c5-steps", "20", "--c3-n", "100000"],
+                        "--grfull-n", "2048", "--c5-n", "50000", "--c5-steps", "20", "--c3-n", "100000", "--c3-big-n", "200000", "--ooc-n", "300000"],
                        capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -31,3 +31,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     cpu = out["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["unit"] == "evals/s" and cpu["sample"]
     assert out["resident_run"]["state_finite"] and out["gr_full"]["sweeps"] >= 1 and "jacobi" in out["massive_stack"]
+    ooc = out["roofline_out_of_cache"]
+    assert ooc["bound"] == "hbm" and ooc["particles"] == 300000 and abs(ooc["frac"] - ooc["achieved"] / ooc["peak"]) < 1e-12
+    full = out["massive_stack_full_size"]
+    assert full["n_total"] == 200000 and full["scaling"] == "strong" and full["particle"]["ms_per_eval"] > 0 and full["jacobi"]["ms_per_eval"] > 0
