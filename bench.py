@@ -129,11 +129,19 @@ def c5_section(ctx, n, steps, mode, device):
     dt = 2 * np.pi / 100.0
     ctx.wh_steps(view, ops, dt, 20, mode)
     torch.cuda.synchronize()
+    # one call and one wait per step, as a host-driven integrator would make them (arguments built once, the C entry
+    # point called directly: what a C caller pays, without this script's per-call argument marshalling)
+    import ctypes
+    from reboundx_amd._lib import Op, lib
+    arr = (Op * len(ops))(*ops)
+    vref, stream = ctypes.byref(view), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     t0 = time.perf_counter()
     for _ in range(steps):
-        ctx.wh_steps(view, ops, dt, 1, mode)
-        torch.cuda.synchronize()
+        rc = lib.rebxamd_wh_steps(ctx._h, vref, arr, len(ops), dt, 1, mode, stream)
+        torch.cuda.current_stream().synchronize()
     synced = (time.perf_counter() - t0) / steps
+    if rc != 0:
+        raise RuntimeError("rebxamd_wh_steps failed: %d" % rc)
     t0 = time.perf_counter()
     ctx.wh_steps(view, ops, dt, steps, mode)
     torch.cuda.synchronize()

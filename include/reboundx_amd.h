@@ -429,7 +429,8 @@ int rebxamd_reset_accelerations(rebxamd_ctx* ctx, const rebxamd_view* view, void
  * ops (the additional forces alone: the dominant mass is in the drift); v_i += dt*(a_i - a_0);
  * drift dt/2 }, with the two half drifts between consecutive steps merged into one Kepler drift of
  * dt (the state is synchronised when the call returns, not in between).  Positions and velocities
- * are updated in place and view->ax/ay/az are left cleared; asynchronous (G*m0 is formed on the device). */
+ * are updated in place.  The acceleration columns are scratch: on return body 0's is zero and the others'
+ * are either untouched (the forces never left registers) or zero.  Asynchronous (G*m0 is formed on the device). */
 int rebxamd_wh_drift(rebxamd_ctx* ctx, const rebxamd_view* view, double dt, int mode, void* stream);
 int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, double dt, int64_t nsteps,
                      int mode, void* stream);

@@ -331,7 +331,8 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
         // in a Wisdom-Holman run the head pass (one body) also records and drifts that body
         // (unless the previous step's pass has already filled this step's tables)
         if (!(wh && step->head_ready))
-            HIP_TRY(launch_head(v, prog, hc, ctx->status, exact, st, wh ? const_cast<double*>(step->star) : nullptr, wh ? step->h : 0.));
+            HIP_TRY(launch_head(v, prog, hc, ctx->status, exact, st, wh ? const_cast<double*>(step->star) : nullptr, wh ? step->h : 0.,
+                                (wh && step->lead_in_head) ? const_cast<double*>(step->star0) : nullptr, wh ? step->h0 : 0.));
         if (v.n > K) {
             TimedLaunch tl(ctx, st);
             HIP_TRY(launch_stream(v, prog, K, hc, nullptr, nullptr, false, exact, vec2, ctx->fixed_stacks, ctx->status, st, step));
@@ -852,17 +853,22 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
         const int src = (ops[k].kind == REBXAMD_OP_GR || ops[k].kind == REBXAMD_OP_GR_POTENTIAL) ? 0 : ops[k].src;
         if (!com && src != 0) carried = false;
     }
-    rc = rebxamd_reset_accelerations(ctx, view, stream);
-    if (rc != REBXAMD_OK) return rc;
     if (carried) {
-        double* const star0 = ctx->star + 32;
-        HIP_TRY(launch_wh_star(x, v, view->m, view->G, 0.5 * dt, star0, st));       // body 0 to mid-step; the others follow inside the pass
+        // (the acceleration columns are neither read nor written on this path: body 0's starts from zero inside the head
+        // pass, the others' never leave registers)
+        double* const star0 = ctx->star + 32;      // record of body 0 for the leading half drift, filled by the first head pass
         // With a one-body head pass (no barycentric op) the pass of step k also runs the head pass of
         // step k + 1 in one extra workgroup, into the other copy of the tables and of body 0's record:
         // one launch per step after the first.
         bool chain = view->vx != nullptr;
         for (int k = 0; k < nops; k++)
             if (ops[k].kind == REBXAMD_OP_MOF && ops[k].iarg == REBX_COORDINATES_BARYCENTRIC) chain = false;
+        if (!chain) {
+            // the general head pass reads body 0's acceleration column and has no room for the leading drift
+            rc = rebxamd_reset_accelerations(ctx, view, stream);
+            if (rc != REBXAMD_OK) return rc;
+            HIP_TRY(launch_wh_star(x, v, view->m, view->G, 0.5 * dt, star0, st));   // body 0 to mid-step; the others follow inside the pass
+        }
         struct StageReset { rebxamd_ctx* c; ~StageReset() { c->hc_stage = 0; } } stage_reset{ctx};
         for (int64_t k = 0; k < nsteps; k++) {
             const double h = k + 1 < nsteps ? dt : 0.5 * dt;
@@ -871,12 +877,15 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
             StepArgs sa = {h, dt, ctx->star + 16 * cur, EPI_WH, 0., 0., 0., {nullptr, nullptr, nullptr}, nullptr, k == 0 ? star0 : nullptr, 0.5 * dt, {}};
             if (chain && k + 1 < nsteps) { sa.next_hc = ctx->hc + nxt; sa.next_star = ctx->star + 16 * nxt; sa.next_h = k + 2 < nsteps ? dt : 0.5 * dt; }
             sa.head_ready = (chain && k > 0) ? 1 : 0;
+            sa.lead_in_head = (chain && k == 0) ? 1 : 0;
             rc = run_streaming(ctx, view, ops, 0, nops, mode, st, -1, nullptr, false, &sa);
             if (rc == STEP_NOT_CARRIED) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_steps: the force stack cannot ride in one pass over this layout");
             if (rc != REBXAMD_OK) return rc;
         }
         return REBXAMD_OK;
     }
+    rc = rebxamd_reset_accelerations(ctx, view, stream);
+    if (rc != REBXAMD_OK) return rc;
     HIP_TRY(launch_wh_drift(x, v, nullptr, view->m, view->G, 0.5 * dt, 0., view->n, ctx->star, exact, st));
     for (int64_t k = 0; k < nsteps; k++) {
         const double h = k + 1 < nsteps ? dt : 0.5 * dt;

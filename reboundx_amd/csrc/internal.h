@@ -94,14 +94,16 @@ struct StepArgs { double h, dtk; const double* star; int epi; double c0, c1, c2;
                   // for the NEXT step (next_hc, next_star; drift of body 0 over next_h), so that step needs no head
                   // pass of its own (head_ready: this step's tables were filled that way)
                   HeadConsts* next_hc; double* next_star; double next_h; int head_ready;
-                  const unsigned* stop; };             // EPI_IM with rounds queued ahead of the host: the pass returns at once when *stop is set
+                  const unsigned* stop;                // EPI_IM with rounds queued ahead of the host: the pass returns at once when *stop is set
+                  int lead_in_head; };                 // EPI_WH: this step's head pass also records star0 and drifts body 0 over h0 (no pass of its own)
 
 enum { WARN_GR_ITER = 1u, WARN_GRFULL_SWEEPS = 2u, WARN_IM_ITER = 4u };
 
 // launchers implemented in stream_kernels.hip
 // star != nullptr: a one-body head is recorded in `star`, its acceleration cleared, and drifted over h (Wisdom-Holman runs)
+// lead != nullptr (one-body head only): body 0 is first recorded in `lead` and drifted over h_lead (the leading half drift of a run)
 hipError_t launch_head(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, bool exact, hipStream_t st,
-                       double* star = nullptr, double h = 0.);
+                       double* star = nullptr, double h = 0., double* lead = nullptr, double h_lead = 0.);
 hipError_t launch_stream(const View& v, const Program& prog, long long lo, const HeadConsts* hc, double* partials,
                          int* nblocks_out, bool backreact, bool exact, bool vec2, bool fixed, unsigned* status, hipStream_t st,
                          const StepArgs* step = nullptr);

@@ -367,9 +367,21 @@ __global__ __launch_bounds__(64) void head_kernel(View v, Program prog, HeadCons
 // Jacobi frame is empty), so the pass only fills the tables -- with the arithmetic of head_kernel
 // for K = 1, rounding included -- and, in a Wisdom-Holman run, records and drifts the body.  A
 // fraction of head_kernel's latency: no loops over ops with barriers, no LDS.
-__device__ __forceinline__ void head_one_body(const View& v, const Program& prog, HeadConsts* hc, double* star, double h, const int t) {
+// lead != nullptr (first step of a Wisdom-Holman run): body 0 is first recorded in `lead` and drifted over h_lead
+// -- the record the tail pass needs for its leading half drift -- and the tables are then filled for the drifted body.
+__device__ __forceinline__ void head_one_body(const View& v, const Program& prog, HeadConsts* hc, double* star, double h, const int t,
+                                              double* lead = nullptr, double h_lead = 0.) {
     Src S;
     load_src(v, 0, S);                                  // every lane reads the same body
+    if (lead != nullptr) {
+#pragma clang fp contract(off)
+        const double nx = S.x + h_lead * S.vx, ny = S.y + h_lead * S.vy, nz = S.z + h_lead * S.vz;
+        if (t == 0) {
+            lead[0] = S.x; lead[1] = S.y; lead[2] = S.z; lead[3] = S.vx; lead[4] = S.vy; lead[5] = S.vz;
+            lead[6] = nx; lead[7] = ny; lead[8] = nz; lead[12] = prog.G * S.m;
+        }
+        S.x = nx; S.y = ny; S.z = nz;                   // (carried in registers: the columns are written once, below)
+    }
     if (t < prog.nops) {
         int s = prog.ops[t].src;
         if (prog.ops[t].kind == REBXAMD_OP_GR) s = 0;
@@ -379,6 +391,9 @@ __device__ __forceinline__ void head_one_body(const View& v, const Program& prog
     if (S.m != 0.) { hc->head[0][0] = S.x; hc->head[0][1] = S.y; hc->head[0][2] = S.z; hc->head[0][3] = S.m; }
     hc->nheadm = S.m != 0. ? 1 : 0;
     hc->head0 = S.m != 0. ? 0 : -1;
+    // In a stepping run the acceleration of body 0 starts from zero whatever the column holds (the columns of
+    // the bodies behind it are neither read nor written there).
+    double a0x = star != nullptr ? 0. : v.ax[0], a0y = star != nullptr ? 0. : v.ay[0], a0z = star != nullptr ? 0. : v.az[0];
     if (prog.gr_op >= 0) {
 #pragma clang fp contract(off)
         const double eta = S.m, ei = 1. / eta;
@@ -388,7 +403,8 @@ __device__ __forceinline__ void head_one_body(const View& v, const Program& prog
         hc->gr_mu = prog.G * S.m;
         // what the back-transformation of an empty Jacobi chain leaves on the body: zero (NaN for a massless one)
         const double na0 = ((0. * eta) * ei);
-        v.ax[0] += na0; v.ay[0] += na0; v.az[0] += na0;
+        a0x += na0; a0y += na0; a0z += na0;
+        if (star == nullptr) { v.ax[0] = a0x; v.ay[0] = a0y; v.az[0] = a0z; }
     }
     if (prog.mofcom_op >= 0) {
         Com c = {0., 0., 0., 0., 0., 0., 0.};
@@ -400,15 +416,15 @@ __device__ __forceinline__ void head_one_body(const View& v, const Program& prog
     if (star != nullptr) {
 #pragma clang fp contract(off)
         star[0] = S.x; star[1] = S.y; star[2] = S.z; star[3] = S.vx; star[4] = S.vy; star[5] = S.vz;
-        star[9] = v.ax[0]; star[10] = v.ay[0]; star[11] = v.az[0]; star[12] = prog.G * S.m;
+        star[9] = a0x; star[10] = a0y; star[11] = a0z; star[12] = prog.G * S.m;
         v.ax[0] = 0.; v.ay[0] = 0.; v.az[0] = 0.;
         const double nx = S.x + h * S.vx, ny = S.y + h * S.vy, nz = S.z + h * S.vz;
         const_cast<double*>(v.x)[0] = nx; const_cast<double*>(v.y)[0] = ny; const_cast<double*>(v.z)[0] = nz;
         star[6] = nx; star[7] = ny; star[8] = nz;
     }
 }
-__global__ __launch_bounds__(64) void head_one_kernel(View v, Program prog, HeadConsts* hc, double* star, double h) {
-    head_one_body(v, prog, hc, star, h, threadIdx.x);
+__global__ __launch_bounds__(64) void head_one_kernel(View v, Program prog, HeadConsts* hc, double* star, double h, double* lead, double h_lead) {
+    head_one_body(v, prog, hc, star, h, threadIdx.x, lead, h_lead);
 }
 
 // ------------------------------------------------------------------ streaming kernel
@@ -988,15 +1004,17 @@ int stream_block_count(long long lo, long long n, bool) {
     return (int)((pairs + BLOCK - 1) / BLOCK);
 }
 
-hipError_t launch_head(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, bool exact, hipStream_t st, double* star, double h) {
+hipError_t launch_head(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, bool exact, hipStream_t st, double* star, double h,
+                       double* lead, double h_lead) {
     const long long K = v.n_head < v.n ? v.n_head : v.n;
     bool one = K == 1 && v.vx != nullptr && v.m != nullptr;
     for (int o = 0; o < prog.nops && one; o++)
         if (prog.ops[o].kind == REBXAMD_OP_MOF && prog.ops[o].iarg == REBX_COORDINATES_BARYCENTRIC) one = false;   // there body 0 acts on itself
     if (one) {
-        hipLaunchKernelGGL(head_one_kernel, dim3(1), dim3(64), 0, st, v, prog, hc, star, h);
+        hipLaunchKernelGGL(head_one_kernel, dim3(1), dim3(64), 0, st, v, prog, hc, star, h, lead, h_lead);
         return hipGetLastError();
     }
+    if (lead != nullptr) return hipErrorInvalidValue;       // (the leading drift rides only in the one-body head pass)
     if (exact) hipLaunchKernelGGL(head_kernel<true>, dim3(1), dim3(64), 0, st, v, prog, hc, status, star, h);
     else hipLaunchKernelGGL(head_kernel<false>, dim3(1), dim3(64), 0, st, v, prog, hc, status, star, h);
     return hipGetLastError();

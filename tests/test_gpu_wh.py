@@ -89,6 +89,25 @@ def test_steps_carried_by_the_force_pass_equal_separate_passes(ctx, n, forces, m
         assert np.abs(out[0] - out[1]).max() <= 1e-13 * np.abs(out[1]).max()
 
 
+def test_acceleration_columns_are_scratch_for_the_stepping_run(ctx):
+    """Whatever the acceleration columns hold on entry has no influence on the run: body 0's acceleration starts from
+    zero inside the head pass, the forces on the other bodies never leave registers."""
+    n, dt, steps = 3001, 0.05, 5
+    cols, pp, _ = synthetic.disk(n, 0)
+    ops = build_ops(C5_STACK, pp)
+    out = []
+    for garbage in (False, True):
+        c = dict(cols)
+        if garbage:
+            rng = np.random.default_rng(1)
+            for k in ("ax", "ay", "az"):
+                c[k] = rng.normal(size=n) * 1e3
+        dp = device_particles(c, pp)
+        ctx.wh_steps(dp.view(), ops, dt, steps, 1)
+        out.append(state_of(dp))
+    assert np.array_equal(out[0], out[1])
+
+
 def eccentric_swarm(n, seed=11):
     """Star + massless bodies with e up to 0.95, all inclinations, a in [0.5, 3]."""
     rng = np.random.default_rng(seed)
