@@ -244,10 +244,31 @@ double rebx_rad_calc_particle_radius(const double G, const double c, const doubl
 
 /* Extensions to the plugin API (no counterpart in the reference). */
 
-/* The device copy of the per-particle parameters is rebuilt when a rebx_set_param_*,
- * add/remove call or a change of the particle array is seen.  A value overwritten in place
- * through a pointer obtained from rebx_get_param cannot be seen: call this afterwards. */
+/* The STRUCTURE of the per-particle parameter lists (which particle holds which parameter, and where
+ * its value lives) is cached and rebuilt when a rebx_set_param_*, add/remove call or a change of the
+ * particle array is seen; the VALUES are read again through the cached pointers on every call, as the
+ * reference reads them (src/core.c:601-622), so a value overwritten in place through a pointer obtained
+ * from rebx_get_param is picked up by itself.  Call this only after editing a list by hand (nodes
+ * linked or unlinked without the API). */
 void rebxamd_invalidate_params(struct rebx_extras* rebx);
+/* Bulk per-particle parameters.  Gives particle i (0 <= i < N) the parameter `name` with value
+ * values[i] without building N linked lists: one call and one copy of the column instead of N times
+ * rebx_set_param_double (src/core.c:552-565), which at 1e7-1e8 particles costs gigabytes of nodes.
+ * `name` is one of the per-particle double parameters the built-in effects and operators read:
+ * "beta", "R_tides", "k1", "tau_a", "tau_e", "tau_inc", "tau_mass", "tau_omega", "tau_Omega"; it must
+ * be registered with type double (the defaults are).  A NaN in values[i] means "not set on particle i";
+ * particles with index >= N have it not set.  The values are copied: call again to change them;
+ * values == NULL or N == 0 removes the column.  The linked lists stay authoritative: where a particle's
+ * own list holds `name` (rebx_set_param_double), that value is used and the column's entry ignored.
+ * The column is seen by this library's effects and operators only: rebx_get_param on a particle does
+ * not find it (there is no list node), and rebx_output_binary does not save it.  Indices follow the
+ * particle array at the time of each call; after removing or reordering particles set the column again.
+ * Returns 1, or 0 after reporting through the simulation's message channel (unknown or unregistered
+ * name, negative N). */
+int rebxamd_set_param_column(struct rebx_extras* rebx, const char* name, const double* values, int N);
+/* The stored copy of a column set by rebxamd_set_param_column and its length (NULL and 0 if none):
+ * for custom force callbacks that want to read it. */
+const double* rebxamd_get_param_column(struct rebx_extras* rebx, const char* name, int* N);
 /* 0 = fast arithmetic (default), 1 = reference-order arithmetic, no FMA contraction. */
 void rebxamd_set_mode(struct rebx_extras* rebx, int mode);
 /* Milliseconds spent by the last rebx_additional_forces / callback in: [0] packing host
@@ -298,12 +319,16 @@ typedef struct rebxamd_op {
 } rebxamd_op;
 
 #define REBXAMD_MAX_OPS 32
+#define REBXAMD_UNSET_BITS 0x7FF8000000000000ull
 #define REBXAMD_MAX_HEAD 64
 
 /* A set of particles resident in device memory, as fp64 columns of length n.
  *
- * Per-particle parameter columns use NaN for "not set on this particle"; a NULL
- * column means not set on any particle.
+ * Per-particle parameter columns mark "not set on this particle" with the quiet NaN whose payload
+ * is empty (REBXAMD_UNSET_BITS: the bits C's NAN macro, numpy.nan and std::nan("") hold); a NULL
+ * column means not set on any particle.  A NaN with any other bit pattern is a value and runs
+ * through the arithmetic, as a NaN-valued parameter does in the reference (which finds the
+ * parameter in the list and computes with it, e.g. src/modify_orbits_forces.c:78-108).
  *
  * n_head / tail_massless describe the mass layout: if tail_massless != 0 the
  * caller asserts that every particle with index >= n_head has m == 0 exactly

@@ -146,7 +146,10 @@ struct Loader {
     static void drop(struct rebx_param* p) { if (p) { free(p->name); free(p->value); free(p); } }
 
     // PARAM and REGISTERED_PARAM payloads (input.c:62-104); nullptr when unusable
+    int64_t value_bytes = 0;            // size of the PARAM_VALUE payload of the parameter read last
+
     struct rebx_param* read_param(Cursor& c) {
+        value_bytes = 0;
         struct rebx_param* p = (struct rebx_param*)calloc(1, sizeof(*p));
         if (!p) { warnings |= REBX_INPUT_BINARY_ERROR_NO_MEMORY; return nullptr; }
         p->type = REBX_TYPE_NONE;
@@ -159,7 +162,7 @@ struct Loader {
                 if (!take(c, r, d)) { warnings |= REBX_INPUT_BINARY_ERROR_CORRUPT; break; }
                 if (r.type == F_PARAM_TYPE) { int32_t t = 0; memcpy(&t, d, r.size < 4 ? (size_t)r.size : 4); p->type = (enum rebx_param_type)t; }
                 else if (r.type == F_NAME) { free(p->name); p->name = dup_bytes(d, r.size); if (p->name && r.size > 0) p->name[r.size - 1] = '\0'; }
-                else if (r.size > 0) { free(p->value); p->value = dup_bytes(d, r.size); }
+                else if (r.size > 0) { free(p->value); p->value = dup_bytes(d, r.size); value_bytes = p->value ? r.size : 0; }
                 else warnings |= REBX_INPUT_BINARY_ERROR_CORRUPT;       // an empty value reads as a failed fread there
             } else {
                 warnings |= REBX_INPUT_BINARY_WARNING_FIELD_UNKNOWN;
@@ -174,6 +177,16 @@ struct Loader {
         struct rebx_param* p = read_param(c);
         if (!p) return false;
         if (!p->value) { warnings |= REBX_INPUT_BINARY_WARNING_PARAM_VALUE_NULL; drop(p); return false; }
+        // The payload's size is the file's claim, the type says what readers of the value will touch:
+        // a number must have exactly its type's size, a force name must end inside the payload, and a
+        // value of a type nobody here can own or free (pointer, orbit, unknown) is not kept.
+        if (p->type == REBX_TYPE_FORCE) {
+            ((char*)p->value)[value_bytes - 1] = '\0';
+        } else if (value_size(p->type) == 0) {
+            warnings |= REBX_INPUT_BINARY_WARNING_PARAM_VALUE_NULL; drop(p); return false;
+        } else if ((size_t)value_bytes != value_size(p->type)) {
+            warnings |= REBX_INPUT_BINARY_ERROR_CORRUPT; drop(p); return false;
+        }
         if (p->type == REBX_TYPE_FORCE) {
             struct rebx_force* f = rebx_get_force(rebx, (const char*)p->value);
             if (!f) { warnings |= REBX_INPUT_BINARY_WARNING_FORCE_PARAM_NOT_LOADED; drop(p); return false; }

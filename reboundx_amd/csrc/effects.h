@@ -20,7 +20,7 @@ namespace rebxamd {
 
 struct V3 { double x, y, z; };
 
-// dynamic state of one particle plus its parameter columns (NaN = not set)
+// dynamic state of one particle plus its parameter columns (the unset marker = not set)
 struct Part {
     double x, y, z, vx, vy, vz, m;
     double beta, Rt, k1, ta, te, ti;
@@ -33,8 +33,6 @@ typedef SrcRec Src;
 // Separation of a particle from a source, shared by every fast-mode force that has the
 // same source: d = p - S, ri = 1/|d|.  `src` remembers which source it was computed for.
 struct Geo { double dx, dy, dz, ri; int src; };
-
-__device__ __forceinline__ bool is_set(double v) { return v == v; }
 
 // Reciprocal square root and reciprocal for the fast mode: the hardware estimate
 // (v_rsq_f64 / v_rcp_f64, good to about 2^-23) refined by one third-order step, so the
@@ -267,15 +265,15 @@ __device__ __forceinline__ void mof_fast(const Part& p, const Src& ref, V3& a) {
     const double dx = p.x - ref.x, dy = p.y - ref.y, dz = p.z - ref.z;
     const double r2 = dx * dx + dy * dy + dz * dz;
     a.x = a.y = a.z = 0.;
-    if (tau_a < INFINITY && tau_a > -INFINITY) {
+    if (fabs(tau_a) != INFINITY) {             // (true for a NaN value too: it has to come out as NaN)
         const double ta2 = 2. * tau_a, ya = fast_rcp(ta2);
         a.x = div_refined(dvx, ta2, ya); a.y = div_refined(dvy, ta2, ya); a.z = div_refined(dvz, ta2, ya);
     }
     if (tau_e < INFINITY || tau_inc < INFINITY) {
         const double vdotr = dx * dvx + dy * dvy + dz * dvz;
         double prefac = 0., zi = 0.;
-        if (tau_e < INFINITY && tau_e > -INFINITY) prefac = div_refined(div_refined(2 * vdotr, r2, fast_rcp(r2)), tau_e, fast_rcp(tau_e));
-        if (tau_inc < INFINITY && tau_inc > -INFINITY) zi = div_refined(2. * dvz, tau_inc, fast_rcp(tau_inc));
+        if (fabs(tau_e) != INFINITY) prefac = div_refined(div_refined(2 * vdotr, r2, fast_rcp(r2)), tau_e, fast_rcp(tau_e));
+        if (fabs(tau_inc) != INFINITY) zi = div_refined(2. * dvz, tau_inc, fast_rcp(tau_inc));
         a.x += prefac * dx;
         a.y += prefac * dy;
         a.z += prefac * dz + zi;

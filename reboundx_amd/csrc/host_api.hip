@@ -5,9 +5,11 @@
 // The linked lists stay the single source of truth, exactly as laid out by the reference, so
 // C programs and ctypes bindings can keep walking them.  What changes is who reads them on
 // the hot path: instead of 1-5 strcmp walks per particle per force per call, the lists are
-// flattened once per parameter change into fp64 columns (NaN = not set) plus short lists of
-// source particles, which live on the GPU; every call then only moves positions, velocities,
-// masses and accelerations.
+// walked once per change of their structure and flattened into fp64 columns (one marker value =
+// not set) plus short lists of source particles, which live on the GPU.  The walk also leaves a
+// flat table of pointers to the values, through which every call reads them again (they may be
+// overwritten in place); a call then moves positions, velocities, masses and accelerations, and
+// the parameter columns in which a value changed.
 #include "internal.h"
 
 #include <cmath>
@@ -16,6 +18,7 @@
 #include <cstring>
 #include <algorithm>
 #include <cfloat>
+#include <climits>
 #include <chrono>
 #include <mutex>
 #include <string>
@@ -82,8 +85,17 @@ enum { H_X, H_Y, H_Z, H_VX, H_VY, H_VZ, H_M, H_AX, H_AY, H_AZ, H_NDYN };
 enum { P_BETA, P_RT, P_K1, P_TA, P_TE, P_TI, P_TM, P_TOM, P_TON, P_NPAR };
 static const char* const kParamName[P_NPAR] = {"beta", "R_tides", "k1", "tau_a", "tau_e", "tau_inc", "tau_mass", "tau_omega", "tau_Omega"};
 
-struct SourceJ { int idx; double J, Req; };
-struct SourceC { int idx; double A, gamma; };
+// Where the reference would read a value on every call: the pointer a list walk ends at.  The walk is
+// cached (the structure of the lists changes rarely), the values are read through these on every call.
+struct ValueRef { int i, k; const double* p; };        // particle, dense column, value
+struct SourceJ { int idx; const double *J, *Req; };
+struct SourceC { int idx; const double *A, *gamma; };
+
+// what a NaN-valued parameter is uploaded as: a NaN that is not the "not set" marker, so that it
+// propagates through the kernels as it does through the reference's arithmetic
+constexpr unsigned long long kNaNValueBits = 0x7FF8000000000001ull;
+inline unsigned long long bits_of(double v) { return __builtin_bit_cast(unsigned long long, v); }
+inline double as_column_value(double v) { return v == v ? v : __builtin_bit_cast(double, kNaNValueBits); }
 
 struct Bridge {
     rebxamd_ctx* ctx = nullptr;
@@ -98,6 +110,8 @@ struct Bridge {
     double* h_par[P_NPAR] = {};             // pageable host columns (rebuilt rarely)
     double* d_par[P_NPAR] = {};
     bool par_used[P_NPAR] = {};             // column has at least one value set
+    std::vector<ValueRef> refs;             // every dense parameter found in a particle's list, by particle
+    std::vector<double> bulk[P_NPAR];       // columns given whole (rebxamd_set_param_column); NaN = not set
     // validity of the flattened parameters
     unsigned long long built_generation = 0;
     int built_n = -1;
@@ -602,6 +616,39 @@ extern "C" double rebx_rad_calc_particle_radius(const double G, const double c, 
 
 // ------------------------------------------------------------------ extensions
 extern "C" void rebxamd_invalidate_params(struct rebx_extras* rebx) { touch(rebx); }
+static int dense_index(const char* name) {
+    for (int k = 0; k < P_NPAR; k++)
+        if (name && strcmp(name, kParamName[k]) == 0) return k;
+    return -1;
+}
+extern "C" int rebxamd_set_param_column(struct rebx_extras* rebx, const char* name, const double* values, int N) {
+    if (!rebx) return 0;
+    const int k = dense_index(name);
+    char str[300];
+    if (k < 0) {
+        snprintf(str, sizeof(str), "REBOUNDx (MI355X) Error: '%s' is not a per-particle parameter that can be given as a column.\n", name ? name : "(null)");
+        rebx_error(rebx, str);
+        return 0;
+    }
+    if (rebx_get_type(rebx, name) != REBX_TYPE_DOUBLE) {        // as the per-particle setter insists (src/core.c:512-541)
+        snprintf(str, sizeof(str), "REBOUNDx Error: Need to register parameter name '%s' before using it. See examples.\n", name);
+        rebx_error(rebx, str);
+        return 0;
+    }
+    if (N < 0) { rebx_error(rebx, "REBOUNDx (MI355X) Error: negative length passed to rebxamd_set_param_column.\n"); return 0; }
+    Bridge* b = bridge_of(rebx, true);
+    if (values && N > 0) b->bulk[k].assign(values, values + N);
+    else std::vector<double>().swap(b->bulk[k]);
+    b->generation++;
+    return 1;
+}
+extern "C" const double* rebxamd_get_param_column(struct rebx_extras* rebx, const char* name, int* N) {
+    const int k = dense_index(name);
+    Bridge* b = rebx ? bridge_of(rebx, false) : nullptr;
+    const bool have = b && k >= 0 && !b->bulk[k].empty();
+    if (N) *N = have ? (int)b->bulk[k].size() : 0;
+    return have ? b->bulk[k].data() : nullptr;
+}
 extern "C" void rebxamd_set_mode(struct rebx_extras* rebx, int mode) {
     if (Bridge* b = bridge_of(rebx, true)) b->mode = mode ? REBXAMD_MODE_EXACT : REBXAMD_MODE_FAST;
 }
@@ -646,12 +693,12 @@ bool ensure_capacity(struct rebx_extras* rebx, Bridge* b, size_t n) {
     return true;
 }
 
-// Flattens every particle's parameter list: six dense columns (NaN = not set) and the short
-// lists of source-type parameters.  One walk per list, no matter how many forces are stacked.
+// Flattens every particle's parameter list: dense columns (rebxamd::unset_value() = not set) and the
+// short lists of source-type parameters.  One walk per list, no matter how many forces are stacked.
+// A column starts from the one given whole, if any; what a particle's own list holds wins over it.
 void flatten_params(struct rebx_extras* rebx, Bridge* b, const struct reb_particle* ps, int N) {
-    const double nan = std::nan("");
     struct Local {
-        bool used[P_NPAR] = {};
+        std::vector<ValueRef> refs;
         std::vector<int> radiation_sources, tides_primaries;
         std::vector<SourceJ> j2, j4;
         std::vector<SourceC> central;
@@ -659,21 +706,23 @@ void flatten_params(struct rebx_extras* rebx, Bridge* b, const struct reb_partic
     };
     const int nt = host_threads(N);
     std::vector<Local> local((size_t)nt);
-    // each thread walks the lists of its own particles; the short source lists are merged in index order afterwards
+    // each thread walks the lists of its own particles; the pieces are merged in index order afterwards
     parallel_chunks(N, nt, [&](int lo, int hi, int t) {
         Local& L = local[(size_t)t];
-        for (int k = 0; k < P_NPAR; k++)
-            for (int i = lo; i < hi; i++) b->h_par[k][i] = nan;
         for (int i = lo; i < hi; i++) {
+            if (!ps[i].ap) continue;
             const double *J2 = nullptr, *J4 = nullptr, *Req = nullptr, *A = nullptr, *gam = nullptr;
+            unsigned seen = 0;          // dense names already met in this list: the first match in list order wins, as a linear search finds it
             for (const struct rebx_node* node = (const struct rebx_node*)ps[i].ap; node; node = node->next) {
                 const struct rebx_param* p = (const struct rebx_param*)node->object;
                 const char* name = p->name;
                 bool dense = false;
                 for (int k = 0; k < P_NPAR; k++) {
                     if (strcmp(name, kParamName[k]) == 0) {
-                        // the first match in list order wins, as a linear search would find it
-                        if (p->value && std::isnan(b->h_par[k][i])) { b->h_par[k][i] = *(const double*)p->value; L.used[k] = true; }
+                        if (!(seen >> k & 1u)) {
+                            seen |= 1u << k;
+                            if (p->value) L.refs.push_back({i, k, (const double*)p->value});
+                        }
                         dense = true;
                         break;
                     }
@@ -688,16 +737,20 @@ void flatten_params(struct rebx_extras* rebx, Bridge* b, const struct reb_partic
                 else if (!strcmp(name, "tides_primary")) { if (p->value && (L.tides_primaries.empty() || L.tides_primaries.back() != i)) L.tides_primaries.push_back(i); }
                 else if (!strcmp(name, "primary")) { if (p->value && L.first_primary < 0) L.first_primary = i; }
             }
-            if (J2 && Req) L.j2.push_back({i, *J2, *Req});
-            if (J4 && Req) L.j4.push_back({i, *J4, *Req});
-            if (A && gam) L.central.push_back({i, *A, *gam});
+            if (J2 && Req) L.j2.push_back({i, J2, Req});
+            if (J4 && Req) L.j4.push_back({i, J4, Req});
+            if (A && gam) L.central.push_back({i, A, gam});
         }
     });
-    for (int k = 0; k < P_NPAR; k++) b->par_used[k] = false;
+    b->refs.clear();
     b->radiation_sources.clear(); b->tides_primaries.clear(); b->j2.clear(); b->j4.clear(); b->central.clear();
     b->first_primary = -1;
-    for (const Local& L : local) {
-        for (int k = 0; k < P_NPAR; k++) b->par_used[k] = b->par_used[k] || L.used[k];
+    size_t nrefs = 0;
+    for (const Local& L : local) nrefs += L.refs.size();
+    b->refs.reserve(nrefs);
+    for (Local& L : local) {
+        b->refs.insert(b->refs.end(), L.refs.begin(), L.refs.end());
+        std::vector<ValueRef>().swap(L.refs);
         b->radiation_sources.insert(b->radiation_sources.end(), L.radiation_sources.begin(), L.radiation_sources.end());
         b->tides_primaries.insert(b->tides_primaries.end(), L.tides_primaries.begin(), L.tides_primaries.end());
         b->j2.insert(b->j2.end(), L.j2.begin(), L.j2.end());
@@ -705,6 +758,41 @@ void flatten_params(struct rebx_extras* rebx, Bridge* b, const struct reb_partic
         b->central.insert(b->central.end(), L.central.begin(), L.central.end());
         if (b->first_primary < 0) b->first_primary = L.first_primary;
     }
+    // the columns somebody set: start from the column given whole (or "not set"), then the lists' values on top
+    for (int k = 0; k < P_NPAR; k++) b->par_used[k] = !b->bulk[k].empty();
+    for (const ValueRef& r : b->refs) b->par_used[r.k] = true;
+    const double unset = rebxamd::unset_value();
+    for (int k = 0; k < P_NPAR; k++) {
+        if (!b->par_used[k]) continue;
+        double* col = b->h_par[k];
+        const double* given = b->bulk[k].data();
+        const int ngiven = (int)std::min<size_t>(b->bulk[k].size(), (size_t)N);
+        parallel_chunks(N, nt, [&](int lo, int hi, int) {
+            for (int i = lo; i < hi; i++) col[i] = (i < ngiven && given[i] == given[i]) ? given[i] : unset;
+        });
+    }
+    parallel_chunks((int)std::min<size_t>(b->refs.size(), (size_t)INT_MAX), nt, [&](int lo, int hi, int) {
+        for (int r = lo; r < hi; r++) { const ValueRef& q = b->refs[(size_t)r]; b->h_par[q.k][q.i] = as_column_value(*q.p); }
+    });
+}
+
+// Reads every cached value pointer again; marks the columns in which a value moved since the last call.
+void refresh_values(Bridge* b, bool changed[P_NPAR]) {
+    for (int k = 0; k < P_NPAR; k++) changed[k] = false;
+    const int n = (int)b->refs.size();
+    if (n == 0) return;
+    const int nt = host_threads(n);
+    bool moved[64][P_NPAR] = {};
+    parallel_chunks(n, nt, [&](int lo, int hi, int t) {
+        for (int r = lo; r < hi; r++) {
+            const ValueRef& q = b->refs[(size_t)r];
+            const double v = as_column_value(*q.p);
+            double& slot = b->h_par[q.k][q.i];
+            if (bits_of(slot) != bits_of(v)) { slot = v; moved[t][q.k] = true; }
+        }
+    });
+    for (int t = 0; t < nt; t++)
+        for (int k = 0; k < P_NPAR; k++) changed[k] = changed[k] || moved[t][k];
 }
 
 struct Pending { struct rebx_force* force; const Builtin* builtin; };
@@ -723,8 +811,8 @@ bool ops_of_force(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* 
         if (b->radiation_sources.empty()) add(REBXAMD_OP_RADIATION, 0, 0, *c, 0.);
         for (int s : b->radiation_sources) add(REBXAMD_OP_RADIATION, s, 0, *c, 0.);
     } else if (fn == rebx_gravitational_harmonics) {
-        for (const SourceJ& s : b->j2) add(REBXAMD_OP_J2, s.idx, 0, s.J, s.Req);
-        for (const SourceJ& s : b->j4) add(REBXAMD_OP_J4, s.idx, 0, s.J, s.Req);
+        for (const SourceJ& s : b->j2) add(REBXAMD_OP_J2, s.idx, 0, *s.J, *s.Req);
+        for (const SourceJ& s : b->j4) add(REBXAMD_OP_J4, s.idx, 0, *s.J, *s.Req);
     } else if (fn == rebx_gr) {
         if (!c) { reb_error(sim, "REBOUNDx Error: Need to set speed of light in gr effect.  See examples in documentation.\n"); return false; }
         const int* it = (const int*)rebx_get_param(rebx, f->ap, "max_iterations");
@@ -736,7 +824,7 @@ bool ops_of_force(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* 
         if (!c) { reb_error(sim, "REBOUNDx Error: Need to set speed of light in gr effect.  See examples in documentation.\n"); return false; }
         add(REBXAMD_OP_GR_FULL, -1, sim->gravity_ignore_terms == 1 ? 1 : 0, *c, 0.);
     } else if (fn == rebx_central_force) {
-        for (const SourceC& s : b->central) add(REBXAMD_OP_CENTRAL, s.idx, 0, s.A, s.gamma);
+        for (const SourceC& s : b->central) add(REBXAMD_OP_CENTRAL, s.idx, 0, *s.A, *s.gamma);
     } else if (fn == rebx_tides_precession) {
         if (b->tides_primaries.empty()) add(REBXAMD_OP_TIDES, 0, 0, 0., 0.);
         for (int s : b->tides_primaries) add(REBXAMD_OP_TIDES, s, 0, 0., 0.);
@@ -808,7 +896,9 @@ bool stage_in(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* b, c
     }
     const bool rebuild = b->built_generation != b->generation || b->built_n != N || b->built_checksum != sum;
     const double tf = now_ms();
+    bool changed[P_NPAR];
     if (rebuild) flatten_params(rebx, b, particles, N);
+    else refresh_values(b, changed);        // the lists did not change; the values in them may have (src/core.c:614-622 hands out pointers)
     pack_ms += now_ms() - tf;
     t[1] = t[0] + pack_ms;              // time spent packing and flattening; the uploads ran underneath
 
@@ -817,6 +907,9 @@ bool stage_in(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* b, c
         for (int k = 0; k < P_NPAR && ok; k++)
             if (b->par_used[k]) ok = hipMemcpyAsync(b->d_par[k], b->h_par[k], bytes, hipMemcpyHostToDevice, st) == hipSuccess;
         b->built_generation = b->generation; b->built_n = N; b->built_checksum = sum;
+    } else {
+        for (int k = 0; k < P_NPAR && ok; k++)
+            if (changed[k]) ok = hipMemcpyAsync(b->d_par[k], b->h_par[k], bytes, hipMemcpyHostToDevice, st) == hipSuccess;
     }
     // (small systems: the copy is left queued ahead of the kernels; the wait is not worth its latency)
     if (!small_system(b, N)) ok = ok && hipStreamSynchronize(st) == hipSuccess;
@@ -1271,10 +1364,10 @@ double host_potential(struct rebx_extras* rebx, PotentialKind kind, double c) {
         rebxamd_op o; o.kind = k; o.src = src; o.iarg = 0; o.reserved = 0; o.a = a; o.b = bb; ops.push_back(o);
     };
     if (kind == POT_HARMONICS) {
-        for (const SourceJ& s : b->j2) add(REBXAMD_OP_J2, s.idx, s.J, s.Req);
-        for (const SourceJ& s : b->j4) add(REBXAMD_OP_J4, s.idx, s.J, s.Req);
+        for (const SourceJ& s : b->j2) add(REBXAMD_OP_J2, s.idx, *s.J, *s.Req);
+        for (const SourceJ& s : b->j4) add(REBXAMD_OP_J4, s.idx, *s.J, *s.Req);
     } else if (kind == POT_CENTRAL) {
-        for (const SourceC& s : b->central) add(REBXAMD_OP_CENTRAL, s.idx, s.A, s.gamma);
+        for (const SourceC& s : b->central) add(REBXAMD_OP_CENTRAL, s.idx, *s.A, *s.gamma);
     } else if (kind == POT_TIDES) {
         // tides_precession.c:190-199: the LAST particle carrying "primary" wins (H is overwritten), else index 0
         int src = 0;
@@ -1353,9 +1446,12 @@ bool state_back(struct rebx_extras* rebx, Bridge* b, struct reb_particle* ps, in
     });
     return true;
 }
-// a parameter column nobody set was not uploaded: operators that take it unconditionally get the NaN column
+// a parameter column nobody set was not uploaded: operators that take it unconditionally get a column of "not set"
 const double* column_or_nan(Bridge* b, int k, int N) {
-    if (!b->par_used[k]) (void)hipMemcpy(b->d_par[k], b->h_par[k], (size_t)N * sizeof(double), hipMemcpyHostToDevice);
+    if (!b->par_used[k]) {
+        for (int i = 0; i < N; i++) b->h_par[k][i] = rebxamd::unset_value();
+        (void)hipMemcpy(b->d_par[k], b->h_par[k], (size_t)N * sizeof(double), hipMemcpyHostToDevice);
+    }
     return b->d_par[k];
 }
 void report_device_error(struct reb_simulation* sim, Bridge* b, const char* what) {

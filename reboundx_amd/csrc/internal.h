@@ -6,6 +6,15 @@
 
 namespace rebxamd {
 
+// "Not set on this particle" in a per-particle parameter column: the quiet NaN with an empty payload
+// (REBXAMD_UNSET_BITS: what C's NAN, numpy.nan and std::nan("") hold) and no other value.  A NaN with
+// any other bit pattern is a value: it runs through the arithmetic and poisons what it touches, as a
+// NaN-valued parameter does in the reference.
+__host__ __device__ __forceinline__ bool is_set(double v) {
+    return __builtin_bit_cast(unsigned long long, v) != REBXAMD_UNSET_BITS;
+}
+__host__ __device__ __forceinline__ double unset_value() { return __builtin_bit_cast(double, (unsigned long long)REBXAMD_UNSET_BITS); }
+
 // One elementary pass, with everything that does not depend on the particle precomputed
 // on the host (in the same fp64 arithmetic the reference uses for these scalars).
 struct DevOp {

@@ -96,7 +96,7 @@ struct DirectArgs {
 __device__ __forceinline__ bool set(const double* col, long long i, double& out) {
     if (col == nullptr) return false;
     const double v = col[i];
-    if (v != v) return false;
+    if (!is_set(v)) return false;
     out = v;
     return true;
 }
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(OB) void mass_growth_kernel(double* m, const double
     const long long i = (long long)blockIdx.x * OB + threadIdx.x;
     if (i >= n) return;
     const double t = tau_mass[i];
-    if (t == t) { const double mi = m[i]; m[i] = mi + mi * dt / t; }
+    if (is_set(t)) { const double mi = m[i]; m[i] = mi + mi * dt / t; }
 }
 
 // per-workgroup sums of (m, m x, m y, m z, m vx, m vy, m vz)

@@ -14,7 +14,7 @@ namespace rebxamd {
 
 static constexpr int PB = 256;
 
-// what one thread holds of its particle (parameter columns: NaN = not set)
+// what one thread holds of its particle (parameter columns: the unset marker = not set)
 struct PotBody { double x, y, z, m, Rt, k1; };
 
 __device__ __forceinline__ double potential_term(const DevOp& op, const View& v, long long i, const PotBody& b, double G) {
@@ -48,13 +48,13 @@ __device__ __forceinline__ double potential_term(const DevOp& op, const View& v,
     case REBXAMD_OP_TIDES: {
         const double mratio = mi / ms;
         if (mratio < DBL_MIN) return 0.;
-        const double R0 = (v.Rt && v.Rt[s] == v.Rt[s]) ? v.Rt[s] : 0.;
-        const double k10 = (v.k1 && v.k1[s] == v.k1[s]) ? v.k1[s] : 0.;
+        const double R0 = (v.Rt && is_set(v.Rt[s])) ? v.Rt[s] : 0.;
+        const double k10 = (v.k1 && is_set(v.k1[s])) ? v.k1[s] : 0.;
         const double fac0 = k10 * R0 * R0 * R0 * R0 * R0;
         double fac = 0.;
         fac += fac0 * mratio;
-        const double Rp = b.Rt == b.Rt ? b.Rt : 0.;
-        const double k1p = b.k1 == b.k1 ? b.k1 : 0.;
+        const double Rp = is_set(b.Rt) ? b.Rt : 0.;
+        const double k1p = is_set(b.k1) ? b.k1 : 0.;
         fac += k1p * Rp * Rp * Rp * Rp * Rp / mratio;
         return -3. / 6. * G * (ms + mi) * mi / (r2 * r2 * r2) * fac;
     }
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(PB) void potential_kernel(View v, Program prog, dou
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool in = i < v.n;
     // the particle is read once for all ops (read-once columns: nontemporal)
-    const double nan = __builtin_nan("");
+    const double nan = unset_value();
     PotBody b = {0., 0., 0., 0., nan, nan};
     if (in) {
         b.x = __builtin_nontemporal_load(v.x + i); b.y = __builtin_nontemporal_load(v.y + i); b.z = __builtin_nontemporal_load(v.z + i);

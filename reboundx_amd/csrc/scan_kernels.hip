@@ -198,7 +198,7 @@ template <bool WITH_ACC>
 struct ScanRaw {
     double m, x, y, z, vx, vy, vz, ta, te, ti, nx, ny, nz;
     __device__ __forceinline__ void load(const View& v, const double* nax, const double* nay, const double* naz, long long i) {
-        const double nan = __builtin_nan("");
+        const double nan = unset_value();
         m = x = y = z = vx = vy = vz = nx = ny = nz = 0.;
         ta = te = ti = nan;
         if (i < v.n) {
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, cons
             const double eta = S[0], mi = own[0];
             Part p;
             p.x = cur.x; p.y = cur.y; p.z = cur.z; p.vx = cur.vx; p.vy = cur.vy; p.vz = cur.vz; p.m = mi;
-            p.beta = p.Rt = p.k1 = __builtin_nan("");
+            p.beta = p.Rt = p.k1 = unset_value();
             p.ta = cur.ta; p.te = cur.te; p.ti = cur.ti;
             if constexpr (KIND == SCAN_GR) {
                 if (i >= first_acting) {

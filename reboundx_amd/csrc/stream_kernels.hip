@@ -35,7 +35,7 @@ static constexpr int WAVES = BLOCK / 64;
 // ------------------------------------------------------------------ small helpers
 
 __device__ __forceinline__ double ld_or_nan(const double* col, long long i) {
-    return col ? col[i] : __builtin_nan("");
+    return col ? col[i] : unset_value();
 }
 
 __device__ __forceinline__ void load_src(const View& v, int idx, Src& S) {
@@ -445,7 +445,7 @@ __device__ __forceinline__ void ldpair(const double* col, long long i0, double& 
 __device__ __forceinline__ double ldone(const double* col, long long i) { return __builtin_nontemporal_load(col + i); }
 
 __device__ __forceinline__ void part_defaults(Part& p) {
-    const double nan = __builtin_nan("");
+    const double nan = unset_value();
     p.x = p.y = p.z = p.vx = p.vy = p.vz = p.m = 0.;
     p.beta = p.Rt = p.k1 = p.ta = p.te = p.ti = nan;
 }

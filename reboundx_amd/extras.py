@@ -351,6 +351,28 @@ class Extras(Structure):
     def invalidate_params(self):
         lib.rebxamd_invalidate_params(byref(self))
 
+    def set_param_column(self, name, values):
+        """Gives particle i the per-particle double parameter `name` = values[i] (NaN = not set) in one
+        call instead of one list node per particle; values=None removes the column.  A parameter of that
+        name in a particle's own list wins over the column's entry."""
+        if values is None:
+            ok = lib.rebxamd_set_param_column(byref(self), name.encode("ascii"), None, 0)
+        else:
+            import numpy as np
+            col = np.ascontiguousarray(values, dtype=np.float64)
+            ok = lib.rebxamd_set_param_column(byref(self), name.encode("ascii"), col.ctypes.data_as(POINTER(c_double)), c_int(len(col)))
+        self.process_messages()
+        return bool(ok)
+
+    def get_param_column(self, name):
+        """A copy of the column given with set_param_column, or None."""
+        import numpy as np
+        n = c_int(0)
+        ptr = lib.rebxamd_get_param_column(byref(self), name.encode("ascii"), byref(n))
+        if not ptr:
+            return None
+        return np.ctypeslib.as_array(ptr, shape=(n.value,)).copy()
+
     def set_mode(self, mode):
         lib.rebxamd_set_mode(byref(self), 1 if mode in (1, "exact") else 0)
 
@@ -481,6 +503,10 @@ lib.rebx_rad_calc_particle_radius.argtypes = [c_double] * 7
 lib.rebx_rad_calc_particle_radius.restype = c_double
 lib.rebxamd_invalidate_params.argtypes = [_P(Extras)]
 lib.rebxamd_set_mode.argtypes = [_P(Extras), c_int]
+lib.rebxamd_set_param_column.argtypes = [_P(Extras), c_char_p, _P(c_double), c_int]
+lib.rebxamd_set_param_column.restype = c_int
+lib.rebxamd_get_param_column.argtypes = [_P(Extras), c_char_p, _P(c_int)]
+lib.rebxamd_get_param_column.restype = _P(c_double)
 lib.rebxamd_last_timings.argtypes = [_P(Extras), _P(c_double)]
 for _n in ("rebx_gr", "rebx_gr_full", "rebx_gr_potential", "rebx_radiation_forces", "rebx_modify_orbits_forces",
            "rebx_tides_precession", "rebx_central_force", "rebx_gravitational_harmonics"):
@@ -528,6 +554,6 @@ PLUGIN_API_SYMBOLS = (
     "rebx_additional_forces", "rebx_reset_accelerations", "rebx_gr", "rebx_gr_full", "rebx_gr_potential",
     "rebx_radiation_forces", "rebx_modify_orbits_forces", "rebx_tides_precession", "rebx_central_force",
     "rebx_gravitational_harmonics", "rebx_rad_calc_beta", "rebx_rad_calc_particle_radius",
-    "rebxamd_invalidate_params", "rebxamd_set_mode", "rebxamd_last_timings",
+    "rebxamd_invalidate_params", "rebxamd_set_mode", "rebxamd_last_timings", "rebxamd_set_param_column", "rebxamd_get_param_column",
     "rebx_build_str", "rebx_version_str", "rebx_githash_str",
 )

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cstdint>
 #include "reboundx_amd.h"
 
 static struct reb_simulation* make_sim(int n) {
@@ -50,6 +51,17 @@ int main(int argc, char** argv) {
         rebx_set_param_uint32(rebx, (struct rebx_node**)&sim->particles[i].ap, "my_count", 7u * i);
     }
     rebx_set_param_int(rebx, (struct rebx_node**)&sim->particles[0].ap, "primary", 1);
+    {   // a parameter given as a whole column: copied, replaced, refused for names that are not per-particle doubles
+        double colv[4] = {__builtin_nan(""), -1., -2., -3.};
+        int nn = 0;
+        assert(rebxamd_set_param_column(rebx, "tau_e", colv, 4) == 1);
+        colv[2] = 9.;
+        assert(rebxamd_get_param_column(rebx, "tau_e", &nn)[2] == -2. && nn == 4);
+        assert(rebxamd_set_param_column(rebx, "tau_e", colv, 3) == 1 && rebxamd_get_param_column(rebx, "tau_e", &nn)[2] == 9. && nn == 3);
+        assert(rebxamd_set_param_column(rebx, "J2", colv, 4) == 0);
+        assert(rebxamd_set_param_column(rebx, "tau_inc", colv, 4) == 1 && rebxamd_set_param_column(rebx, "tau_inc", NULL, 0) == 1);
+        assert(rebxamd_get_param_column(rebx, "tau_inc", &nn) == NULL && nn == 0);
+    }
     assert(*(double*)rebx_get_param(rebx, (struct rebx_node*)sim->particles[2].ap, "tau_a") == -4e4);
     sim->post_timestep_modifications(sim);          // runs the kick-free operator list: integrate_force needs a GPU and reports
     rebx_output_binary(rebx, (char*)path);
@@ -77,6 +89,47 @@ int main(int argc, char** argv) {
         rebx_free(r3);
         free_sim(s3);
         remove(tmp);
+    }
+    // files that lie about a value: every PARAM_TYPE record (type 6, 4 bytes) is overwritten with every type
+    // code in turn, so that 4-byte values claim to be doubles, doubles claim to be force names with no NUL
+    // inside, and values claim types nobody frees.  Whatever the loader keeps is then read the way the force
+    // evaluation reads it; the sanitizers see any read behind a value and any value left behind.
+    for (size_t o = 64; o + 20 <= len; o++) {
+        int32_t type; int64_t size;
+        memcpy(&type, buf + o, 4); memcpy(&size, buf + o + 8, 8);
+        if (type != 6 || size != 4 || memcmp(buf + o + 4, "\0\0\0\0", 4) != 0) continue;
+        int32_t original;
+        memcpy(&original, buf + o + 16, 4);
+        for (int32_t t = 0; t <= 8; t++) {
+            if (t == original) continue;
+            char tmp[256];
+            snprintf(tmp, sizeof(tmp), "%s.lie", path);
+            memcpy(buf + o + 16, &t, 4);
+            FILE* g = fopen(tmp, "wb");
+            fwrite(buf, 1, len, g);
+            fclose(g);
+            struct reb_simulation* s3 = make_sim(4);
+            struct rebx_extras* r3 = rebx_create_extras_from_binary(s3, tmp);
+            double sink = 0.;
+            auto read_list = [&](struct rebx_node* ap) {
+                for (; ap; ap = ap->next) {
+                    const struct rebx_param* q = (const struct rebx_param*)ap->object;
+                    if (!q->value) continue;
+                    if (q->type == REBX_TYPE_DOUBLE) sink += *(const double*)q->value;
+                    else if (q->type == REBX_TYPE_INT) sink += *(const int*)q->value;
+                    else if (q->type == REBX_TYPE_UINT32) sink += *(const uint32_t*)q->value;
+                    else if (q->type == REBX_TYPE_FORCE) sink += (double)strlen(((const struct rebx_force*)q->value)->name);
+                }
+            };
+            for (int i = 0; i < s3->N; i++) read_list((struct rebx_node*)s3->particles[i].ap);
+            for (struct rebx_node* n = r3->allocated_forces; n; n = n->next) read_list(((struct rebx_force*)n->object)->ap);
+            for (struct rebx_node* n = r3->allocated_operators; n; n = n->next) read_list(((struct rebx_operator*)n->object)->ap);
+            if (sink == 12345.678) printf("unlikely\n");
+            rebx_free(r3);
+            free_sim(s3);
+            remove(tmp);
+        }
+        memcpy(buf + o + 16, &original, 4);
     }
     rebx_free(rebx2);
     free_sim(sim2);

@@ -160,7 +160,10 @@ def test_callback_on_a_scratch_copy_updates_the_copy_only():
     sim.free_particle_params()
 
 
-def test_parameter_changes_are_picked_up_and_in_place_writes_need_invalidate():
+def test_parameter_changes_are_picked_up_also_when_written_through_a_raw_pointer():
+    """The reference reads every value from the lists on every call (core.c:601-622), so a caller may keep
+    the pointer rebx_get_param returns and overwrite the value: per-particle columns (beta) and source
+    parameters (J2) alike must follow without any further call."""
     cols = gravity(synthetic.twoplanets())
     sim = sim_from(cols)
     rebx = Extras(sim)
@@ -176,22 +179,192 @@ def test_parameter_changes_are_picked_up_and_in_place_writes_need_invalidate():
         sim.call_additional_forces()
         return acc_of(ps, 3)
 
-    def expected(b1, b2):
+    def expected(b1, b2, J2=None):
         ref = oracle.Sim(cols)
+        if J2 is not None:
+            oracle.gravitational_harmonics(ref, np.array([J2, np.nan, np.nan]), None, np.array([1e-3, np.nan, np.nan]))
         oracle.radiation_forces(ref, 1e4, np.array([np.nan, b1, b2]), None)
         return np.array(ref.acc)
 
     assert np.array_equal(evaluate(), expected(0.5, np.nan))
-    ps[1].params["beta"] = 0.25                      # update through the API: seen
+    ps[1].params["beta"] = 0.25                      # update through the API
     assert np.array_equal(evaluate(), expected(0.25, np.nan))
-    ps[2].params["beta"] = 0.1                       # new parameter on another particle: seen
+    ps[2].params["beta"] = 0.1                       # new parameter on another particle
     assert np.array_equal(evaluate(), expected(0.25, 0.1))
-    valptr = lib.rebx_get_param(ctypes.byref(rebx), ps[1].ap, b"beta")
-    ctypes.cast(valptr, ctypes.POINTER(ctypes.c_double))[0] = 0.75      # write through the raw pointer: not seen ...
-    assert np.array_equal(evaluate(), expected(0.25, 0.1))
-    rebx.invalidate_params()                         # ... until the caller says so
+    beta1 = ctypes.cast(lib.rebx_get_param(ctypes.byref(rebx), ps[1].ap, b"beta"), ctypes.POINTER(ctypes.c_double))
+    beta1[0] = 0.75                                  # write through the raw pointer
     assert np.array_equal(evaluate(), expected(0.75, 0.1))
+    assert np.array_equal(evaluate(), expected(0.75, 0.1))
+    beta1[0] = 0.125
+    assert np.array_equal(evaluate(), expected(0.125, 0.1))
+    rebx.add_force(rebx.load_force("gravitational_harmonics"))          # runs first (head insertion)
+    ps[0].params["J2"] = 1e-3
+    ps[0].params["R_eq"] = 1e-3
+    assert np.array_equal(evaluate(), expected(0.125, 0.1, 1e-3))
+    J2 = ctypes.cast(lib.rebx_get_param(ctypes.byref(rebx), ps[0].ap, b"J2"), ctypes.POINTER(ctypes.c_double))
+    J2[0] = 4e-3
+    assert np.array_equal(evaluate(), expected(0.125, 0.1, 4e-3))
     sim.free_particle_params()
+
+
+OTHER_NAN = np.array([0x7FF8000000000001], dtype=np.uint64).view(np.float64)[0]       # a NaN that is not the "not set" marker
+
+
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+@pytest.mark.parametrize("case", ["beta", "tau_a", "tau_e_with_tau_inc", "tau_e_alone", "R_tides"])
+def test_a_parameter_whose_value_is_nan_is_a_parameter_and_poisons_what_the_reference_poisons(case, mode):
+    """A parameter set to NaN is found in the list and computed with (core.c:614-622; e.g.
+    modify_orbits_forces.c:94-108): the accelerations it enters become NaN -- its own particle's, and the
+    source's through the back-reaction -- and nothing else does.  (tau_e alone: the reference's test
+    `tau_e < INFINITY || tau_inc < INFINITY`, modify_orbits_forces.c:110, is false for NaN, so the term is
+    skipped and nothing is poisoned.)  The checker takes the same columns with the value NaN marked as a value."""
+    cols = gravity(synthetic.twoplanets())
+    sim = sim_from(cols)
+    rebx = Extras(sim)
+    rebx.set_mode(mode)
+    nan = float("nan")
+    ps = sim.particles
+    un = np.nan
+    if case == "beta":
+        f = rebx.load_force("radiation_forces"); f.params["c"] = 1e4
+        ps[1].params["beta"] = nan; ps[2].params["beta"] = 0.3
+        stack, pp = [("radiation_forces", {"c": 1e4})], {"beta": np.array([un, OTHER_NAN, 0.3])}
+    elif case == "R_tides":
+        f = rebx.load_force("tides_precession")
+        ps[0].params["R_tides"] = 1e-3; ps[0].params["k1"] = 0.4
+        ps[1].params["R_tides"] = nan; ps[1].params["k1"] = 0.3
+        stack, pp = [("tides_precession", {})], {"R_tides": np.array([1e-3, OTHER_NAN, un]), "k1": np.array([.4, .3, un])}
+    else:
+        f = rebx.load_force("modify_orbits_forces"); f.params["coordinates"] = 2
+        ps[0].params["primary"] = 1
+        ps[2].params["tau_a"] = -1e4
+        pp = {"tau_a": np.array([un, un, -1e4]), "tau_e": np.array([un, un, un]), "tau_inc": np.array([un, un, un]), "primary": np.array([1, 0, 0], dtype=np.uint8)}
+        if case == "tau_a":
+            ps[1].params["tau_a"] = nan; pp["tau_a"][1] = OTHER_NAN
+        else:
+            ps[1].params["tau_e"] = nan; pp["tau_e"][1] = OTHER_NAN
+            if case == "tau_e_with_tau_inc":
+                ps[1].params["tau_inc"] = -1e3; pp["tau_inc"][1] = -1e3
+        stack = [("modify_orbits_forces", {"coordinates": 2})]
+    rebx.add_force(f)
+    sim.call_additional_forces()
+    got = acc_of(ps, 3)
+    ref = oracle.Sim(cols)
+    oracle.apply_forces(ref, stack, pp)
+    want = np.array(ref.acc)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), (got, want)
+    assert np.isnan(want).any() == (case != "tau_e_alone")
+    ok = ~np.isnan(want)
+    if mode == "exact":
+        assert np.array_equal(got[ok], want[ok])
+    else:
+        assert (np.abs(got[ok] - want[ok]) <= TOL * np.abs(want[ok])).all()
+    sim.free_particle_params()
+
+
+def big_array_sim(cols):
+    n = len(cols["x"])
+    sim = Simulation()
+    arr = (Particle * n)()
+    view = np.frombuffer(arr, dtype=np.float64).reshape(n, 16)
+    for j, k in enumerate(("x", "y", "z", "vx", "vy", "vz", "ax", "ay", "az", "m")):
+        view[:, j] = cols[k]
+    sim._store = arr
+    sim._particles = ctypes.cast(arr, ctypes.POINTER(Particle))
+    sim.N = n
+    return sim, arr, view
+
+
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_parameter_columns_equal_one_hundred_thousand_per_particle_setters_bit_for_bit(mode):
+    """rebxamd_set_param_column against rebx_set_param_double on every particle (core.c:552-565), N = 1e5,
+    radiation + tides + drag stacked, through sim->additional_forces: the same accelerations to the bit.
+    Then the precedence rules: a particle's own list wins over its column entry, a column shorter than the
+    array leaves the rest not set, and removing the column removes the force's effect."""
+    n = 100_000
+    cols, pp, _ = synthetic.disk(n, 2, seed=5)
+    cols["m"][3:] = 1e-12                           # tides and the drag's back-reaction act on massive bodies
+    names = ("beta", "R_tides", "k1", "tau_a", "tau_e", "tau_inc")
+    rng = np.random.default_rng(11)
+    pp = {k: pp[k].copy() for k in names}
+    pp["R_tides"][3:] = 1e-5; pp["k1"][3:] = 0.3
+    pp["R_tides"][0] = 1e-3; pp["k1"][0] = 0.4
+    for k in names:                                 # holes everywhere: a third of the bodies lack each parameter
+        holes = rng.random(n) < 0.33
+        holes[0] = k not in ("R_tides", "k1")
+        pp[k][holes] = np.nan
+
+    def build(with_columns):
+        sim, arr, view = big_array_sim(cols)
+        rebx = Extras(sim)
+        rebx.set_mode(mode)
+        for name in ("modify_orbits_forces", "tides_precession", "radiation_forces"):
+            f = rebx.load_force(name)
+            if name == "radiation_forces":
+                f.params["c"] = C
+            if name == "modify_orbits_forces":
+                f.params["coordinates"] = 2
+            rebx.add_force(f)
+        arr[0]._sim = ctypes.pointer(sim)
+        arr[0].params["primary"] = 1
+        if with_columns:
+            for k in names:
+                assert rebx.set_param_column(k, pp[k])
+        else:
+            ap = ctypes.c_void_p.from_buffer
+            for k in names:
+                key = k.encode("ascii")
+                for i in np.nonzero(~np.isnan(pp[k]))[0]:
+                    lib.rebx_set_param_double(ctypes.byref(rebx), ctypes.byref(ap(arr[i], Particle.ap.offset)), key, float(pp[k][i]))
+        return sim, arr, view, rebx
+
+    sim_l, arr_l, view_l, rebx_l = build(False)
+    sim_l.call_additional_forces()
+    want = view_l[:, 6:9].copy()
+    sim_c, arr_c, view_c, rebx_c = build(True)
+    sim_c.call_additional_forces()
+    got = view_c[:, 6:9].copy()
+    assert np.isfinite(want).all() and np.abs(want - np.array([cols["ax"], cols["ay"], cols["az"]]).T).max() > 0
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    some = int(np.nonzero(~np.isnan(pp["beta"]))[0][5])
+    assert not arr_c[some].ap and arr_l[some].ap          # columns make no list nodes
+
+    ref = oracle.Sim(cols)                          # and both are the checker's answer
+    pp_ref = dict(pp); pp_ref["primary"] = np.zeros(n, dtype=np.uint8); pp_ref["primary"][0] = 1
+    oracle.apply_forces(ref, [("radiation_forces", {"c": C}), ("tides_precession", {}), ("modify_orbits_forces", {"coordinates": 2})], pp_ref)
+    refacc = np.array(ref.acc).T
+    if mode == "exact":
+        assert ulp_diff(got[1:], refacc[1:]).max() == 0
+    assert rel_err(got.T, refacc.T).max() <= TOL
+
+    def again(sim, view):
+        for j, k in enumerate(("ax", "ay", "az")):
+            view[:, 6 + j] = cols[k]
+        sim.call_additional_forces()
+        return view[:, 6:9].copy()
+
+    # a list entry wins over the column; the list-only simulation with the same value agrees
+    i = 4242
+    arr_c[i]._sim = ctypes.pointer(sim_c); arr_l[i]._sim = ctypes.pointer(sim_l)
+    arr_c[i].params["tau_a"] = -77.; arr_l[i].params["tau_a"] = -77.
+    a_c, a_l = again(sim_c, view_c), again(sim_l, view_l)
+    assert np.array_equal(a_c.view(np.uint64), a_l.view(np.uint64))
+    assert not np.array_equal(a_c[i], got[i])
+    # a shorter column: bodies behind its end have the parameter not set
+    half = n // 2
+    assert rebx_c.set_param_column("beta", pp["beta"][:half])
+    pp_half = dict(pp_ref); pp_half["beta"] = pp["beta"].copy(); pp_half["beta"][half:] = np.nan
+    pp_half["tau_a"] = pp["tau_a"].copy(); pp_half["tau_a"][i] = -77.
+    ref = oracle.Sim(cols)
+    oracle.apply_forces(ref, [("radiation_forces", {"c": C}), ("tides_precession", {}), ("modify_orbits_forces", {"coordinates": 2})], pp_half)
+    assert rel_err(again(sim_c, view_c).T, np.array(ref.acc)).max() <= TOL
+    # removing the columns: only the list entry is left
+    for k in names:
+        assert rebx_c.set_param_column(k, None)
+    left = again(sim_c, view_c)
+    moved = np.nonzero((left != np.array([cols["ax"], cols["ay"], cols["az"]]).T).any(axis=1))[0]
+    assert set(moved) == {0, i}
+    sim_c.free_particle_params(); sim_l.free_particle_params()
 
 
 def test_missing_required_parameters_report_errors_and_leave_accelerations_alone():

@@ -157,6 +157,39 @@ def test_unregistered_and_duplicate_parameter_names():
     assert not ap.value
 
 
+def test_parameter_column_is_stored_whole_and_rejects_names_it_cannot_hold():
+    """rebxamd_set_param_column: the bulk form of rebx_set_param_double (core.c:552-565) for the per-particle
+    doubles the built-in effects read.  Host behaviour only: what is kept, what is refused."""
+    import numpy as np
+    sim = make_sim()
+    rebx = Extras(sim)
+    assert rebx.get_param_column("tau_a") is None
+    col = np.array([np.nan, -1e4])
+    assert rebx.set_param_column("tau_a", col)
+    col[1] = 5.                                     # the values were copied
+    got = rebx.get_param_column("tau_a")
+    assert np.isnan(got[0]) and got[1] == -1e4 and len(got) == 2
+    assert len(sim.particles[1].params) == 0        # no list node was made
+    assert rebx.set_param_column("tau_a", np.array([1., 2., 3.]))       # replaced whole
+    assert list(rebx.get_param_column("tau_a")) == [1., 2., 3.]
+    assert rebx.set_param_column("tau_a", None)
+    assert rebx.get_param_column("tau_a") is None
+    with pytest.raises(RuntimeError, match="can be given as a column"):
+        rebx.set_param_column("J2", np.array([1e-3, np.nan]))           # a source parameter: stays in the lists
+    with pytest.raises(RuntimeError, match="can be given as a column"):
+        rebx.set_param_column("primary", np.array([1., np.nan]))
+    # an extras object whose registry lacks the name refuses it, as the per-particle setter does (core.c:518-524)
+    bare = Simulation()
+    bare.add(m=1.)
+    raw = Extras.__new__(Extras)
+    lib.rebx_initialize(ctypes.byref(bare), ctypes.byref(raw))
+    ok = lib.rebxamd_set_param_column(ctypes.byref(raw), b"beta", col.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 2)
+    assert ok == 0
+    with pytest.raises(RuntimeError, match="Need to register parameter name 'beta'"):
+        bare.process_messages()
+    lib.rebx_free_pointers(ctypes.byref(raw))
+
+
 def test_params_move_with_particles_and_pointer_params_are_borrowed():
     sim = make_sim()
     rebx = Extras(sim)
