@@ -468,11 +468,20 @@ int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_o
  * dt/tau_* (view->tau_a/tau_e/tau_inc and the two extra columns, NaN = not set; *p_param = the
  * operator's "p", NULL = unset) in the given coordinates with the reference's back-reactions
  * (src/modify_orbits_direct.c:81-132, src/rebxtools.c:137-215).  `primary` = reference particle
- * for REBX_COORDINATES_PARTICLE.  The massive bodies must be a prefix of at most 64 particles
- * followed by massless ones (the reference's chain over massive bodies is sequential). */
+ * for REBX_COORDINATES_PARTICLE.  With the massive bodies in a prefix of at most 64 particles
+ * followed by massless ones, one thread walks the prefix exactly as the reference does and the
+ * massless bodies run in parallel.  Any other layout (the reference's chain, in which every massive
+ * body shifts the bodies before it ahead of their own step, is then long): the pushes are found as
+ * the fixed point of a parallel map over suffix sums -- rounds until they stop moving -- and one
+ * thread walks the chain sequentially should the rounds not settle; results agree with the
+ * sequential walk to rounding of the sums (1e-12 of the state).  That path synchronises the stream
+ * once.  rebxamd_direct_chain: max_rounds >= 0 sets the number of rounds tried before the
+ * sequential walk (default 12; 0 = always walk); *last_rounds (may be NULL) = rounds the last
+ * long-chain call took, -1 if it walked. */
 int rebxamd_modify_mass(rebxamd_ctx* ctx, const rebxamd_view* view, const double* tau_mass, double dt, void* stream);
 int rebxamd_modify_orbits_direct(rebxamd_ctx* ctx, const rebxamd_view* view, int coordinates, int primary, const double* p_param,
                                  const double* tau_omega, const double* tau_Omega, double dt, void* stream);
+int rebxamd_direct_chain(rebxamd_ctx* ctx, int max_rounds, int* last_rounds);
 
 /* Potential energy of each op in `ops` (J2, J4, central_force, tides_precession, gr_potential),
  * summed over the particles of `view`: out[k] (host memory, nops doubles) is what the

@@ -70,6 +70,7 @@ _sig = {
     "rebxamd_drift": (c_int, [c_void_p, POINTER(View), c_double, c_int, c_void_p]),
     "rebxamd_fetch_warnings": (c_int, [c_void_p, POINTER(c_uint32), c_void_p]),
     "rebxamd_timing_enable": (c_int, [c_void_p, c_int]),
+    "rebxamd_direct_chain": (c_int, [c_void_p, c_int, POINTER(c_int)]),
     "rebxamd_fixed_stacks": (c_int, [c_void_p, c_int]),
     "rebxamd_carried_steps": (c_int, [c_void_p, c_int]),
     "rebxamd_timing_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int)]),

@@ -37,6 +37,8 @@ struct rebxamd_ctx {
     bool timing = false;
     bool carried_steps = true;  // Wisdom-Holman runs: kick and drift ride in the force pass when the layout allows
     bool fixed_stacks = true;   // stacks with a kernel instance of their own use it
+    int chain_rounds = 12;      // modify_orbits_direct on long chains: rounds of the fixed-point iteration before the sequential walk takes over
+    int chain_last_rounds = 0;  // rounds the last such call took, -1 if it fell back to the sequential walk
     bool fixed_scratch = false; // the buffers above are slices of a fixed array: never grown, never freed
     std::vector<hipEvent_t> ev;         // pairs: start, stop
     size_t ev_used = 0;
@@ -1047,6 +1049,13 @@ extern "C" int rebxamd_modify_mass(rebxamd_ctx* ctx, const rebxamd_view* view, c
     return REBXAMD_OK;
 }
 
+extern "C" int rebxamd_direct_chain(rebxamd_ctx* ctx, int max_rounds, int* last_rounds) {
+    if (!ctx) return REBXAMD_ERR_ARG;
+    if (max_rounds >= 0) ctx->chain_rounds = max_rounds > 64 ? 64 : max_rounds;
+    if (last_rounds) *last_rounds = ctx->chain_last_rounds;
+    return REBXAMD_OK;
+}
+
 extern "C" int rebxamd_modify_orbits_direct(rebxamd_ctx* ctx, const rebxamd_view* view, int coordinates, int primary, const double* p_param,
                                             const double* tau_omega, const double* tau_Omega, double dt, void* stream) {
     const int rc = check_step_view(ctx, view, "rebxamd_modify_orbits_direct: bad argument", true, false);
@@ -1055,11 +1064,29 @@ extern "C" int rebxamd_modify_orbits_direct(rebxamd_ctx* ctx, const rebxamd_view
     if (coordinates != REBX_COORDINATES_JACOBI && coordinates != REBX_COORDINATES_BARYCENTRIC && coordinates != REBX_COORDINATES_PARTICLE)
         return fail(ctx, REBXAMD_ERR_ARG, "modify_orbits_direct: unknown coordinates");
     const long long K = view->n_head < view->n ? view->n_head : view->n;
-    if (!((view->tail_massless != 0 || K == view->n) && K >= 1 && K <= REBXAMD_MAX_HEAD))
-        return fail(ctx, REBXAMD_ERR_UNSUPPORTED, "modify_orbits_direct walks the massive bodies sequentially: they must form a prefix of at most 64 particles followed by massless ones");
-    if (coordinates == REBX_COORDINATES_PARTICLE && (primary < 0 || primary >= K))
-        return fail(ctx, REBXAMD_ERR_PARAM, "modify_orbits_direct: PARTICLE coordinates need a primary inside the massive prefix");
+    if (coordinates == REBX_COORDINATES_PARTICLE && (primary < 0 || primary >= view->n))
+        return fail(ctx, REBXAMD_ERR_PARAM, "modify_orbits_direct: PARTICLE coordinates need a primary among the particles");
     HIP_TRY(hipSetDevice(ctx->device));
+    if (!((view->tail_massless != 0 || K == view->n) && K >= 1 && K <= REBXAMD_MAX_HEAD && (coordinates != REBX_COORDINATES_PARTICLE || primary < K))) {
+        // massive bodies anywhere: the chain of pushes as a fixed-point iteration over suffix sums, the sequential walk if it does not settle
+        hipStream_t st = (hipStream_t)stream;
+        const View v = make_view(view);
+        const int rc2 = ensure(ctx, &ctx->scan, &ctx->scan_cap, (size_t)direct_chain_doubles(v.n) * sizeof(double), st);
+        if (rc2 != REBXAMD_OK) return rc2;
+        const double pp = p_param ? *p_param : 0.;
+        const int has_p = p_param ? 1 : 0;
+        const unsigned* ctl = nullptr;
+        HIP_TRY(launch_direct_chain_rounds(v, coordinates, primary, pp, has_p, tau_omega, tau_Omega, dt, view->G, ctx->scan, ctx->chain_rounds, &ctl, st));
+        if (coordinates != REBX_COORDINATES_PARTICLE) {
+            unsigned state[2] = {0, 0};
+            const int rc3 = read_back(ctx, state, ctl, sizeof(state), st);
+            if (rc3 != REBXAMD_OK) return rc3;
+            ctx->chain_last_rounds = state[0] ? (int)state[1] : -1;
+            if (!state[0]) HIP_TRY(launch_direct_chain_sequential(v, coordinates, primary, pp, has_p, tau_omega, tau_Omega, dt, view->G, ctx->scan, st));
+        } else ctx->chain_last_rounds = 1;
+        HIP_TRY(launch_direct_chain_finish(v, coordinates, primary, pp, has_p, tau_omega, tau_Omega, dt, view->G, ctx->scan, st));
+        return REBXAMD_OK;
+    }
     HIP_TRY(launch_modify_orbits_direct(make_view(view), K, coordinates, primary, p_param ? *p_param : 0., p_param ? 1 : 0, tau_omega, tau_Omega, dt,
                                         view->G, ctx->star, (hipStream_t)stream));
     return REBXAMD_OK;

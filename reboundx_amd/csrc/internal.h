@@ -161,6 +161,13 @@ hipError_t launch_im_begin(double* const keep[3], const double* const v[3], doub
 
 // operators modify_mass and modify_orbits_direct (operator_kernels.hip)
 long long operator_partial_doubles(long long n);
+long long direct_chain_doubles(long long n);
+hipError_t launch_direct_chain_rounds(const View& v, int coordinates, int refindex, double p_param, int has_p, const double* tau_omega,
+                                      const double* tau_Omega, double dt, double G, double* ws, int max_rounds, const unsigned** ctl_out, hipStream_t st);
+hipError_t launch_direct_chain_sequential(const View& v, int coordinates, int refindex, double p_param, int has_p, const double* tau_omega,
+                                          const double* tau_Omega, double dt, double G, double* ws, hipStream_t st);
+hipError_t launch_direct_chain_finish(const View& v, int coordinates, int refindex, double p_param, int has_p, const double* tau_omega,
+                                      const double* tau_Omega, double dt, double G, double* ws, hipStream_t st);
 hipError_t launch_modify_mass(const View& v, const double* tau_mass, double dt, double* ws, hipStream_t st);
 hipError_t launch_modify_orbits_direct(const View& v, long long K, int coordinates, int refindex, double p_param, int has_p,
                                        const double* tau_omega, const double* tau_Omega, double dt, double G, double* hc16, hipStream_t st);

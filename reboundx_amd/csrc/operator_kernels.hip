@@ -12,7 +12,16 @@
 // (star, planets) followed by massless ones the chain is short: the massless tail is independent
 // (its pushes are zero) and runs in parallel against the unmodified head, then one thread walks
 // the head.
+//
+// With massive bodies anywhere (or a massive prefix longer than 64) the chain is long: body i is
+// stepped from the state the bodies behind it have already shifted it to, about a centre of mass
+// those shifts have moved.  Unrolled, both are suffix sums of the pushes s_k = massratio_k * diff_k
+// of the bodies k > i, so the chain is a fixed-point problem  s = F(suffix sums of s)  whose map F
+// is a parallel pass and whose coupling is weak (mass ratio times dt/tau per body): it is iterated
+// from s = 0 until the pushes stop moving (two to four rounds in practice), with the sequential
+// walk (one thread, running sums) as the fallback should the rounds not contract.
 #include "internal.h"
+#include "scan_ops.h"
 #include <float.h>
 
 namespace rebxamd {
@@ -288,6 +297,345 @@ hipError_t launch_modify_orbits_direct(const View& v, long long K, int coordinat
     if (coordinates == REBX_COORDINATES_BARYCENTRIC && v.n > K) {
         const long long nb = (v.n - K + OB - 1) / OB;
         hipLaunchKernelGGL(shift_kernel, dim3((unsigned)nb), dim3(OB), 0, st, v, K, hc16 + 8);
+    }
+    return hipGetLastError();
+}
+
+
+// ------------------------------------------------------------------ modify_orbits_direct, massive bodies anywhere
+//
+// Reference loop (src/rebxtools.c:164-214), i = N-1 .. 0, with the pushes written out:
+//   state of body i when its turn comes      p_i - S_i,          S_i = sum_{k>i} s_k
+//   Jacobi: reference point of body i        (P_i + T_i) / M_i,  M_i = sum_{k<i} m_k,  P_i = sum_{k<i} m_k p_k,
+//           (the centre of mass of all bodies, taken before the loop, with the shifted bodies i..N-1
+//           removed one by one: reb_get_com_without_particle)     T_i = sum_{k>=i} m_k S_k
+//   barycentric: the centre of mass of all bodies before the loop; PARTICLE: the primary before the loop
+//   diff_i = step(p_i - S_i) - (p_i - S_i),  s_i = massratio_i diff_i
+//   body i ends at   Jacobi, PARTICLE: (p_i - S_i) + diff_i - s_i      barycentric: p_i + diff_i - sum_k s_k
+// Columns of the workspace are stored one after the other (component c of body i at [c * n + i]).
+struct ChainArgs {
+    DirectArgs a;
+    long long n;
+    double* s;          // 6 columns: pushes, current iterate
+    double* S;          // 6 columns: S_i
+    double* T;          // 6 columns: T_i (Jacobi)
+    double* P;          // 7 columns: M_i, P_i (Jacobi)
+    double* table;      // workgroup totals of the scan in flight (7 per workgroup)
+    double* tot;        // [0..6] sum of m, m p over all bodies; [8..13] sum of the pushes; [16..21] scratch totals
+    double* delta;      // per workgroup: sum |s_new - s_old| (6), sum massratio * |state| for positions and velocities (2)
+    double* conv;       // [0] relative change of the round before
+    unsigned* ctl;      // [0] the pushes have stopped moving, [1] rounds run
+};
+
+enum { CHAIN_P = 0, CHAIN_S = 1, CHAIN_T = 2 };
+
+template <int WHAT>
+__device__ __forceinline__ void chain_elem(const View& v, const ChainArgs& c, long long i, double (&q)[7]) {
+#pragma clang fp contract(off)
+    if (i >= c.n) {
+#pragma unroll
+        for (int k = 0; k < 7; k++) q[k] = 0.;
+        return;
+    }
+    if (WHAT == CHAIN_P) {
+        const double m = v.m[i];
+        q[0] = m; q[1] = m * v.x[i]; q[2] = m * v.y[i]; q[3] = m * v.z[i]; q[4] = m * v.vx[i]; q[5] = m * v.vy[i]; q[6] = m * v.vz[i];
+    } else if (WHAT == CHAIN_S) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) q[k] = c.s[k * c.n + i];
+        q[6] = 0.;
+    } else {
+        const double m = v.m[i];
+#pragma unroll
+        for (int k = 0; k < 6; k++) q[k] = m * c.S[k * c.n + i];
+        q[6] = 0.;
+    }
+}
+
+template <int WHAT>
+__global__ __launch_bounds__(SB) void chain_totals(View v, ChainArgs c, int skip_when_done) {
+    __shared__ double lds[SW][7];
+    if (skip_when_done && c.ctl[0]) return;
+    double q[7];
+    chain_elem<WHAT>(v, c, (long long)blockIdx.x * SB + threadIdx.x, q);
+    block_total<7>(q, lds);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; k++) c.table[(long long)blockIdx.x * 7 + k] = q[k];
+    }
+}
+
+// the table of workgroup totals scanned by scan_of_totals; then every workgroup scans its own elements on top of its entry
+template <int WHAT>
+__global__ __launch_bounds__(SB) void chain_write(View v, ChainArgs c, int skip_when_done) {
+    __shared__ double lds[SW][7];
+    if (skip_when_done && c.ctl[0]) return;
+    const long long i = (long long)blockIdx.x * SB + threadIdx.x;
+    double q[7], own[7], tot[7];
+    chain_elem<WHAT>(v, c, i, q);
+#pragma unroll
+    for (int k = 0; k < 7; k++) own[k] = q[k];
+    block_scan<7, WHAT != CHAIN_P>(q, tot, lds);
+    if (i >= c.n) return;
+    const double* base = c.table + (long long)blockIdx.x * 7;
+    if (WHAT == CHAIN_P) {
+#pragma unroll
+        for (int k = 0; k < 7; k++) c.P[k * c.n + i] = base[k] + (q[k] - own[k]);          // bodies before i
+    } else if (WHAT == CHAIN_S) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) c.S[k * c.n + i] = base[k] + (q[k] - own[k]);          // bodies behind i
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; k++) c.T[k * c.n + i] = base[k] + q[k];                     // body i and the bodies behind it
+    }
+}
+
+__global__ void chain_begin(ChainArgs c) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { c.ctl[0] = 0; c.ctl[1] = 0; c.conv[0] = 0.; }
+}
+
+// One round of the map (FINAL = false: new pushes and how far they moved) or the last pass (FINAL = true: the bodies' new states).
+template <int COORD, bool FINAL>
+__global__ __launch_bounds__(SB) void chain_map(View v, ChainArgs c) {
+#pragma clang fp contract(off)
+    __shared__ double lds[SW][8];
+    if (!FINAL && c.ctl[0]) return;
+    const long long i = (long long)blockIdx.x * SB + threadIdx.x, n = c.n;
+    double q[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+    if (i < n) {
+        const PV orig = load_pv(v, i);
+        PV cur = orig;
+        double Si[6] = {0., 0., 0., 0., 0., 0.};
+        if (COORD != REBX_COORDINATES_PARTICLE) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) Si[k] = c.S[k * n + i];
+            cur.x -= Si[0]; cur.y -= Si[1]; cur.z -= Si[2]; cur.vx -= Si[3]; cur.vy -= Si[4]; cur.vz -= Si[5];
+        }
+        PV com;
+        double mr = 0.;
+        bool skip = false;
+        if (COORD == REBX_COORDINATES_PARTICLE) {
+            com = load_pv(v, c.a.refindex);
+            skip = i == c.a.refindex;
+            mr = orig.m / (com.m + orig.m);
+        } else if (COORD == REBX_COORDINATES_BARYCENTRIC) {
+            const double M = c.tot[0];
+            com.m = M;
+            com.x = c.tot[1]; com.y = c.tot[2]; com.z = c.tot[3]; com.vx = c.tot[4]; com.vy = c.tot[5]; com.vz = c.tot[6];
+            if (M > 0.) { com.x /= M; com.y /= M; com.z /= M; com.vx /= M; com.vy /= M; com.vz /= M; }
+            mr = orig.m / com.m;
+        } else {
+            const double M = c.P[i];
+            com.m = M;
+            com.x = c.P[1 * n + i] + c.T[0 * n + i]; com.y = c.P[2 * n + i] + c.T[1 * n + i]; com.z = c.P[3 * n + i] + c.T[2 * n + i];
+            com.vx = c.P[4 * n + i] + c.T[3 * n + i]; com.vy = c.P[5 * n + i] + c.T[4 * n + i]; com.vz = c.P[6 * n + i] + c.T[5 * n + i];
+            if (M > 0.) { com.x /= M; com.y /= M; com.z /= M; com.vx /= M; com.vy /= M; com.vz /= M; }
+            skip = i == 0;
+            mr = orig.m / (com.m + orig.m);
+        }
+        const PV mod = skip ? cur : direct_step(v, c.a, i, cur, com);
+        const double d[6] = {mod.x - cur.x, mod.y - cur.y, mod.z - cur.z, mod.vx - cur.vx, mod.vy - cur.vy, mod.vz - cur.vz};
+        double sn[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) sn[k] = (skip || orig.m == 0.) ? 0. : mr * d[k];
+        if (!FINAL) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const double old = c.s[k * n + i];
+                q[k] = fabs(sn[k] - old);
+                c.s[k * n + i] = sn[k];
+            }
+            if (!skip && orig.m != 0.) {
+                q[6] = fabs(mr) * fmax(fabs(cur.x - com.x), fmax(fabs(cur.y - com.y), fabs(cur.z - com.z)));
+                q[7] = fabs(mr) * fmax(fabs(cur.vx - com.vx), fmax(fabs(cur.vy - com.vy), fabs(cur.vz - com.vz)));
+            }
+        } else {
+            PV out = mod;
+            if (COORD == REBX_COORDINATES_BARYCENTRIC) {
+                // every body takes every push: the ones behind it already sit in `cur`, the rest is the total minus those
+                out.x -= c.tot[8] - Si[0]; out.y -= c.tot[9] - Si[1]; out.z -= c.tot[10] - Si[2];
+                out.vx -= c.tot[11] - Si[3]; out.vy -= c.tot[12] - Si[4]; out.vz -= c.tot[13] - Si[5];
+            } else if (!skip) {
+                out.x -= sn[0]; out.y -= sn[1]; out.z -= sn[2]; out.vx -= sn[3]; out.vy -= sn[4]; out.vz -= sn[5];
+            }
+            if (!(COORD == REBX_COORDINATES_PARTICLE && skip)) store_pv(v, i, out);
+        }
+    }
+    if (!FINAL) {
+        block_total<8>(q, lds);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) c.delta[(long long)blockIdx.x * 8 + k] = q[k];
+        }
+    }
+}
+
+// Adds up what the round moved and decides whether the pushes have settled: the change of every component
+// within rounding of the pushes themselves (64 ulp of sum massratio |state|), or no longer shrinking at a
+// level (1e-10 of that sum) that only the rounding of the orbit conversions explains.
+__global__ __launch_bounds__(SOT) void chain_check(ChainArgs c, long long nb) {
+    __shared__ double red[SOT / 64][8];
+    if (c.ctl[0]) return;
+    double q[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+    for (long long b = threadIdx.x; b < nb; b += SOT)
+#pragma unroll
+        for (int k = 0; k < 8; k++) q[k] += c.delta[b * 8 + k];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 8; k++) q[k] = wave_total(q[k], lane);
+    if (lane == 0) for (int k = 0; k < 8; k++) red[wave][k] = q[k];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double t[8];
+    for (int k = 0; k < 8; k++) { t[k] = 0.; for (int w = 0; w < SOT / 64; w++) t[k] += red[w][k]; }
+    double rel = 0.;
+    bool settled = true;
+    for (int k = 0; k < 6; k++) {
+        const double size = t[k < 3 ? 6 : 7];
+        if (!(t[k] <= 64. * DBL_EPSILON * size)) settled = false;
+        const double r = size > 0. ? t[k] / size : (t[k] > 0. ? HUGE_VAL : 0.);
+        if (!(r <= rel)) rel = r;           // (a NaN sticks)
+    }
+    const unsigned rounds = c.ctl[1] + 1u;
+    const double before = c.conv[0];
+    if (!settled && rounds >= 2u && rel <= 1e-10 && rel > 0.25 * before) settled = true;
+    c.conv[0] = rel;
+    c.ctl[1] = rounds;
+    if (settled) c.ctl[0] = 1u;
+}
+
+// The reference's walk, one thread, with the shifts carried as running sums: leaves the pushes in c.s.
+template <int COORD>
+__global__ void chain_sequential(View v, ChainArgs c) {
+#pragma clang fp contract(off)
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const long long n = c.n;
+    PV com;
+    com.m = c.tot[0];
+    com.x = c.tot[1]; com.y = c.tot[2]; com.z = c.tot[3]; com.vx = c.tot[4]; com.vy = c.tot[5]; com.vz = c.tot[6];
+    if (com.m > 0.) { com.x /= com.m; com.y /= com.m; com.z /= com.m; com.vx /= com.m; com.vy /= com.m; com.vz /= com.m; }
+    double S[6] = {0., 0., 0., 0., 0., 0.};
+    for (long long i = n - 1; i >= 0; i--) {
+        PV p = load_pv(v, i);
+        const double m = p.m;
+        p.x -= S[0]; p.y -= S[1]; p.z -= S[2]; p.vx -= S[3]; p.vy -= S[4]; p.vz -= S[5];
+        bool skip = false;
+        if (COORD == REBX_COORDINATES_JACOBI) {
+            skip = i == 0;
+            if (!skip) {
+                com.x = com.x * com.m - p.x * p.m; com.y = com.y * com.m - p.y * p.m; com.z = com.z * com.m - p.z * p.m;
+                com.vx = com.vx * com.m - p.vx * p.m; com.vy = com.vy * com.m - p.vy * p.m; com.vz = com.vz * com.m - p.vz * p.m;
+                com.m -= p.m;
+                if (com.m > 0.) { com.x /= com.m; com.y /= com.m; com.z /= com.m; com.vx /= com.m; com.vy /= com.m; com.vz /= com.m; }
+            }
+        }
+        double sn[6] = {0., 0., 0., 0., 0., 0.};
+        if (!skip && m != 0.) {
+            const PV mod = direct_step(v, c.a, i, p, com);
+            const double mr = COORD == REBX_COORDINATES_JACOBI ? m / (com.m + m) : m / com.m;
+            sn[0] = mr * (mod.x - p.x); sn[1] = mr * (mod.y - p.y); sn[2] = mr * (mod.z - p.z);
+            sn[3] = mr * (mod.vx - p.vx); sn[4] = mr * (mod.vy - p.vy); sn[5] = mr * (mod.vz - p.vz);
+        }
+        for (int k = 0; k < 6; k++) { c.s[k * n + i] = sn[k]; S[k] += sn[k]; }
+    }
+}
+
+// PARTICLE coordinates: the primary takes every push
+__global__ void chain_primary(View v, ChainArgs c) {
+#pragma clang fp contract(off)
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    PV p = load_pv(v, c.a.refindex);
+    p.x -= c.tot[8]; p.y -= c.tot[9]; p.z -= c.tot[10]; p.vx -= c.tot[11]; p.vy -= c.tot[12]; p.vz -= c.tot[13];
+    store_pv(v, c.a.refindex, p);
+}
+
+__global__ __launch_bounds__(SB) void chain_zero(double* s, long long count) {
+    const long long i = (long long)blockIdx.x * SB + threadIdx.x;
+    if (i < count) s[i] = 0.;
+}
+
+long long direct_chain_doubles(long long n) {
+    const long long nb = (n + SB - 1) / SB;
+    return 25 * n + 15 * nb + 64;
+}
+
+static ChainArgs chain_args(const View& v, int coordinates, int refindex, double p_param, int has_p, const double* tau_omega, const double* tau_Omega,
+                            double dt, double G, double* ws) {
+    const long long n = v.n, nb = (n + SB - 1) / SB;
+    ChainArgs c;
+    c.a.coordinates = coordinates; c.a.refindex = refindex; c.a.has_p = has_p; c.a.p_param = p_param; c.a.dt = dt; c.a.G = G;
+    c.a.tau_omega = tau_omega; c.a.tau_Omega = tau_Omega;
+    c.n = n;
+    c.s = ws; c.S = c.s + 6 * n; c.T = c.S + 6 * n; c.P = c.T + 6 * n;
+    c.table = c.P + 7 * n; c.delta = c.table + 7 * nb;
+    c.tot = c.delta + 8 * nb; c.conv = c.tot + 32; c.ctl = (unsigned*)(c.conv + 8);
+    return c;
+}
+
+template <int WHAT>
+static void chain_scan(const View& v, const ChainArgs& c, double* totals, bool totals_only, int skip_when_done, hipStream_t st) {
+    const long long nb = (c.n + SB - 1) / SB;
+    hipLaunchKernelGGL(chain_totals<WHAT>, dim3((unsigned)nb), dim3(SB), 0, st, v, c, skip_when_done);
+    // (once the pushes have settled the passes around this one return at once; scanning the stale table again does no harm,
+    // the last pass builds table and totals afresh)
+    if (WHAT == CHAIN_P) hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(7), dim3(SOT), 0, st, c.table, nb, totals);
+    else hipLaunchKernelGGL((scan_of_totals<7, true>), dim3(7), dim3(SOT), 0, st, c.table, nb, totals);
+    if (!totals_only) hipLaunchKernelGGL(chain_write<WHAT>, dim3((unsigned)nb), dim3(SB), 0, st, v, c, skip_when_done);
+}
+
+template <int COORD>
+static void chain_rounds(const View& v, const ChainArgs& c, int rounds, hipStream_t st) {
+    const long long nb = (c.n + SB - 1) / SB;
+    for (int r = 0; r < rounds; r++) {
+        if (COORD != REBX_COORDINATES_PARTICLE && r > 0) {
+            chain_scan<CHAIN_S>(v, c, c.tot + 8, false, 1, st);
+            if (COORD == REBX_COORDINATES_JACOBI) chain_scan<CHAIN_T>(v, c, c.tot + 16, false, 1, st);
+        }
+        hipLaunchKernelGGL((chain_map<COORD, false>), dim3((unsigned)nb), dim3(SB), 0, st, v, c);
+        hipLaunchKernelGGL(chain_check, dim3(1), dim3(SOT), 0, st, c, nb);
+    }
+}
+
+// Queues the rounds of the fixed-point iteration (PARTICLE coordinates: the one pass that forms the pushes).
+// `ctl_out`: where the host reads {settled, rounds run} from afterwards.
+hipError_t launch_direct_chain_rounds(const View& v, int coordinates, int refindex, double p_param, int has_p, const double* tau_omega,
+                                      const double* tau_Omega, double dt, double G, double* ws, int max_rounds, const unsigned** ctl_out, hipStream_t st) {
+    const ChainArgs c = chain_args(v, coordinates, refindex, p_param, has_p, tau_omega, tau_Omega, dt, G, ws);
+    const long long n = v.n;
+    hipLaunchKernelGGL(chain_begin, dim3(1), dim3(64), 0, st, c);
+    // s, S and T start at zero (first round: nobody has been pushed yet)
+    hipLaunchKernelGGL(chain_zero, dim3((unsigned)((18 * n + SB - 1) / SB)), dim3(SB), 0, st, c.s, 18 * n);
+    if (coordinates != REBX_COORDINATES_PARTICLE) chain_scan<CHAIN_P>(v, c, c.tot, coordinates == REBX_COORDINATES_BARYCENTRIC, 0, st);
+    if (coordinates == REBX_COORDINATES_JACOBI) chain_rounds<REBX_COORDINATES_JACOBI>(v, c, max_rounds, st);
+    else if (coordinates == REBX_COORDINATES_BARYCENTRIC) chain_rounds<REBX_COORDINATES_BARYCENTRIC>(v, c, max_rounds, st);
+    else chain_rounds<REBX_COORDINATES_PARTICLE>(v, c, 1, st);
+    *ctl_out = c.ctl;
+    return hipGetLastError();
+}
+
+// The fallback: the pushes from the sequential walk (Jacobi and barycentric coordinates).
+hipError_t launch_direct_chain_sequential(const View& v, int coordinates, int refindex, double p_param, int has_p, const double* tau_omega,
+                                          const double* tau_Omega, double dt, double G, double* ws, hipStream_t st) {
+    const ChainArgs c = chain_args(v, coordinates, refindex, p_param, has_p, tau_omega, tau_Omega, dt, G, ws);
+    if (coordinates == REBX_COORDINATES_JACOBI) hipLaunchKernelGGL(chain_sequential<REBX_COORDINATES_JACOBI>, dim3(1), dim3(64), 0, st, v, c);
+    else hipLaunchKernelGGL(chain_sequential<REBX_COORDINATES_BARYCENTRIC>, dim3(1), dim3(64), 0, st, v, c);
+    return hipGetLastError();
+}
+
+// The last pass: sums of the settled pushes, then every body's new state.
+hipError_t launch_direct_chain_finish(const View& v, int coordinates, int refindex, double p_param, int has_p, const double* tau_omega,
+                                      const double* tau_Omega, double dt, double G, double* ws, hipStream_t st) {
+    const ChainArgs c = chain_args(v, coordinates, refindex, p_param, has_p, tau_omega, tau_Omega, dt, G, ws);
+    const long long nb = (v.n + SB - 1) / SB;
+    chain_scan<CHAIN_S>(v, c, c.tot + 8, coordinates == REBX_COORDINATES_PARTICLE, 0, st);
+    if (coordinates == REBX_COORDINATES_JACOBI) {
+        chain_scan<CHAIN_T>(v, c, c.tot + 16, false, 0, st);
+        hipLaunchKernelGGL((chain_map<REBX_COORDINATES_JACOBI, true>), dim3((unsigned)nb), dim3(SB), 0, st, v, c);
+    } else if (coordinates == REBX_COORDINATES_BARYCENTRIC) {
+        hipLaunchKernelGGL((chain_map<REBX_COORDINATES_BARYCENTRIC, true>), dim3((unsigned)nb), dim3(SB), 0, st, v, c);
+    } else {
+        hipLaunchKernelGGL((chain_map<REBX_COORDINATES_PARTICLE, true>), dim3((unsigned)nb), dim3(SB), 0, st, v, c);
+        hipLaunchKernelGGL(chain_primary, dim3(1), dim3(64), 0, st, v, c);
     }
     return hipGetLastError();
 }

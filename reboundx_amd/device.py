@@ -89,6 +89,13 @@ class Context:
                                                      tau_omega.data_ptr() if tau_omega is not None else None,
                                                      tau_Omega.data_ptr() if tau_Omega is not None else None, float(dt), self._stream()))
 
+    def direct_chain(self, max_rounds=-1):
+        """modify_orbits_direct on layouts with massive bodies anywhere: sets the rounds of the fixed-point iteration tried
+        before the sequential walk (-1: leave as is; 0: always walk) and returns the rounds the last such call took (-1: walked)."""
+        last = ctypes.c_int(0)
+        self._check(lib.rebxamd_direct_chain(self._h, int(max_rounds), ctypes.byref(last)))
+        return last.value
+
     def potentials(self, view, ops):
         """Potential energy of each op (J2, J4, central_force, tides_precession, gr_potential)."""
         arr = (Op * max(len(ops), 1))(*ops)
