@@ -152,10 +152,32 @@ def c5_section(ctx, n, steps, mode, device):
     # mass and the six parameters read (104 B), positions and velocities written (48 B); the
     # accelerations stay in registers
     bytes_per_step = 152 * n
-    return {"n": n, "steps": steps, "effects": 5, "us_per_step_host_synced": synced * 1e6, "us_per_step_queued": queued * 1e6,
-            "particle_steps_per_s": n / queued, "state_finite": finite,
-            "roofline": {"bound": "hbm", "achieved": bytes_per_step / queued / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": bytes_per_step / queued / 1e9 / HBM_PEAK_GBS}}
+    out = {"n": n, "steps": steps, "effects": 5, "us_per_step_host_synced": synced * 1e6, "us_per_step_queued": queued * 1e6,
+           "particle_steps_per_s": n / queued, "state_finite": finite,
+           "roofline": {"bound": "hbm", "achieved": bytes_per_step / queued / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": bytes_per_step / queued / 1e9 / HBM_PEAK_GBS}}
+    # the shape of BASELINE configuration 1 (star + planet + grains under radiation forces) at this size: the massive head steps in
+    # Jacobi coordinates in one wavefront (three small launches per step), the grains in the same kind of pass, which also adds the
+    # pull of both head bodies; positions, velocities and beta read (56 B), positions and velocities written (48 B)
+    del dp
+    steps1 = max(1, steps // 4)
+    cols, pp, _ = synthetic.disk(n + 2, 1)
+    host = dict(cols)
+    host["beta"] = pp["beta"]
+    dq = DeviceParticles.from_host(host, device=device, n_head=2, tail_massless=True)
+    ops1 = build_ops([("radiation_forces", {"c": C})], {k: v[:2] for k, v in pp.items()})
+    v1 = dq.view()
+    ctx.wh_steps(v1, ops1, dt, 20, mode)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.wh_steps(v1, ops1, dt, steps1, mode)
+    torch.cuda.synchronize()
+    q1 = (time.perf_counter() - t0) / steps1
+    out["star_planet_grains"] = {"n": n, "steps": steps1, "effects": 1, "us_per_step_queued": q1 * 1e6, "particle_steps_per_s": n / q1,
+                                 "state_finite": bool(torch.isfinite(dq.cols["x"]).all().item()),
+                                 "roofline": {"bound": "hbm", "achieved": 104 * n / q1 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": 104 * n / q1 / 1e9 / HBM_PEAK_GBS}}
+    return out
 
 
 def c3_section(ctx, n, mode, device):

@@ -26,6 +26,7 @@ struct rebxamd_ctx {
     const unsigned* gf_stop = nullptr;  // caller's stop word for rebxamd_grfull_sweep (rebxamd_grfull_stop_word)
     double* chunk_sums = nullptr;       // second-stage scratch of the back-reaction reduction
     void* hpin = nullptr;               // 512 B of pinned host memory: small results come back through it (no staging copy inside the runtime)
+    double* whead = nullptr;            // Jacobi state of a head of several massive bodies between Wisdom-Holman steps (8 x 64 doubles)
     double* star = nullptr;             // 3 x 16 doubles: records of body 0 around Wisdom-Holman drifts (two alternate between steps, one for the leading half drift)
     double* integ = nullptr;            // stage columns of the force integrators
     size_t integ_cap = 0;
@@ -101,6 +102,7 @@ extern "C" int rebxamd_create(int device, rebxamd_ctx** out) {
         hipMalloc((void**)&ctx->ll, sizeof(long long)) != hipSuccess ||
         hipMalloc((void**)&ctx->gf_flag, 4 * sizeof(unsigned)) != hipSuccess ||
         hipMalloc((void**)&ctx->star, 48 * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&ctx->whead, 8 * REBXAMD_MAX_HEAD * sizeof(double)) != hipSuccess ||
         hipHostMalloc(&ctx->hpin, 512, hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void**)&ctx->chunk_sums, sizeof(double) * REBXAMD_MAX_OPS * 64 * 3) != hipSuccess ||
         hipMemset(ctx->hc, 0, 4 * sizeof(HeadConsts)) != hipSuccess ||
@@ -123,6 +125,7 @@ extern "C" void rebxamd_destroy(rebxamd_ctx* ctx) {
     if (ctx->gf) (void)hipFree(ctx->gf);
     if (ctx->gf_flag) (void)hipFree(ctx->gf_flag);
     if (ctx->star) (void)hipFree(ctx->star);
+    if (ctx->whead) (void)hipFree(ctx->whead);
     if (ctx->hpin) (void)hipHostFree(ctx->hpin);
     if (ctx->chunk_sums) (void)hipFree(ctx->chunk_sums);
     if (ctx->scan) (void)hipFree(ctx->scan);
@@ -319,7 +322,7 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
 
     const bool wh = step && step->epi == EPI_WH;
     const bool applies = step && step->epi == EPI_APPLY;      // the pass also applies a prefix-sum force (any-mass-layout pass only)
-    if (step && !applies && !(sparse && (wh ? K == 1 : v.n > K))) return STEP_NOT_CARRIED;
+    if (step && !applies && !(sparse && (wh ? (K == 1 || step->wh_head == (int)K) : v.n > K))) return STEP_NOT_CARRIED;
     if (applies && (sparse || prog.gr_op >= 0 || prog.mofcom_op >= 0 || target_lo >= 0 || pushes_only)) return STEP_NOT_CARRIED;
     HeadConsts* const hc = ctx->hc + ctx->hc_stage;
     if (sparse) {
@@ -332,7 +335,13 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
         }
         // in a Wisdom-Holman run the head pass (one body) also records and drifts that body
         // (unless the previous step's pass has already filled this step's tables)
-        if (!(wh && step->head_ready))
+        if (wh && step->wh_head > 1) {
+            // star + planets: the head pass leaves the additional accelerations of the head bodies in their columns and the
+            // tables of this step; the head's own Wisdom-Holman step (gravity among its bodies, Jacobi kick, drift to the
+            // next force evaluation) follows and records the frame of the massless bodies for the pass below
+            HIP_TRY(launch_head(v, prog, hc, ctx->status, exact, st));
+            HIP_TRY(launch_wh_head_step(v, K, prog.G, step->dtk, step->h, ctx->whead, const_cast<double*>(step->star), exact, st));
+        } else if (!(wh && step->head_ready))
             HIP_TRY(launch_head(v, prog, hc, ctx->status, exact, st, wh ? const_cast<double*>(step->star) : nullptr, wh ? step->h : 0.,
                                 (wh && step->lead_in_head) ? const_cast<double*>(step->star0) : nullptr, wh ? step->h0 : 0.));
         if (v.n > K) {
@@ -837,10 +846,38 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
     if (nsteps < 0 || nops < 0 || (nops > 0 && !ops)) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_steps: bad argument");
     if (view->n == 0 || nsteps == 0) return REBXAMD_OK;
     if (!view->m) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_steps: mass column missing");
-    if (!(view->n_head <= 1 && view->tail_massless)) return fail(ctx, REBXAMD_ERR_UNSUPPORTED, "rebxamd_wh_steps handles one massive body at index 0 followed by massless ones (n_head = 1, tail_massless = 1)");
+    const long long K = view->n_head < view->n ? view->n_head : view->n;
+    if (!(K <= REBXAMD_MAX_HEAD && (view->tail_massless || K == view->n)))
+        return fail(ctx, REBXAMD_ERR_UNSUPPORTED, "rebxamd_wh_steps handles a prefix of at most 64 massive bodies (star, planets) followed by massless ones (n_head <= 64, tail_massless = 1)");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     const bool exact = mode == REBXAMD_MODE_EXACT;
+    if (K > 1) {
+        // Star + planets + massless bodies.  The head steps in Jacobi coordinates in one wavefront; the pass over the massless
+        // bodies carries forces, the pull of the head bodies, kick and drift about the head's centre of mass.
+        if (nops > 0 && !one_streaming_run(ops, nops))
+            return fail(ctx, REBXAMD_ERR_UNSUPPORTED, "rebxamd_wh_steps with several massive bodies: the force stack must be one streaming run (no gr_full, one gr, one Jacobi/barycentric modify_orbits_forces)");
+        for (int k = 0; k < nops; k++) {
+            const bool com = ops[k].kind == REBXAMD_OP_MOF && ops[k].iarg != REBX_COORDINATES_PARTICLE;
+            const int src = (ops[k].kind == REBXAMD_OP_GR || ops[k].kind == REBXAMD_OP_GR_POTENTIAL) ? 0 : ops[k].src;
+            if (!com && (src < 0 || src >= K)) return fail(ctx, REBXAMD_ERR_UNSUPPORTED, "rebxamd_wh_steps: every op's source must be one of the massive bodies");
+        }
+        if (!view->x || !view->ax || !view->ay || !view->az) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_steps: position/acceleration columns missing");
+        const View v = make_view(view);
+        double* const lead = ctx->star + 32;
+        HIP_TRY(launch_wh_head_begin(v, K, view->G, 0.5 * dt, ctx->whead, lead, exact, st));
+        struct StageReset { rebxamd_ctx* c; ~StageReset() { c->hc_stage = 0; } } stage_reset{ctx};
+        ctx->hc_stage = 0;
+        for (int64_t k = 0; k < nsteps; k++) {
+            const double h = k + 1 < nsteps ? dt : 0.5 * dt;
+            StepArgs sa = {h, dt, ctx->star + 16 * (int)(k & 1), EPI_WH, 0., 0., 0., {nullptr, nullptr, nullptr}, nullptr, k == 0 ? lead : nullptr, 0.5 * dt, {}};
+            sa.wh_head = (int)K;
+            rc = run_streaming(ctx, view, ops, 0, nops, mode, st, -1, nullptr, false, &sa);
+            if (rc == STEP_NOT_CARRIED) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_steps: the force stack cannot ride in one pass over this layout");
+            if (rc != REBXAMD_OK) return rc;
+        }
+        return REBXAMD_OK;
+    }
     double* const x[3] = {const_cast<double*>(view->x), const_cast<double*>(view->y), const_cast<double*>(view->z)};
     double* const v[3] = {const_cast<double*>(view->vx), const_cast<double*>(view->vy), const_cast<double*>(view->vz)};
     double* const a[3] = {view->ax, view->ay, view->az};

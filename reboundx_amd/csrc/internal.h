@@ -104,7 +104,11 @@ struct StepArgs { double h, dtk; const double* star; int epi; double c0, c1, c2;
                   // pass of its own (head_ready: this step's tables were filled that way)
                   HeadConsts* next_hc; double* next_star; double next_h; int head_ready;
                   const unsigned* stop;                // EPI_IM with rounds queued ahead of the host: the pass returns at once when *stop is set
-                  int lead_in_head; };                 // EPI_WH: this step's head pass also records star0 and drifts body 0 over h0 (no pass of its own)
+                  int lead_in_head;                    // EPI_WH: this step's head pass also records star0 and drifts body 0 over h0 (no pass of its own)
+                  // EPI_WH behind a head of several massive bodies (star + planets): `star` and `star0` then describe the head's
+                  // centre of mass instead of body 0 -- the origin of every massless body's Jacobi coordinates -- and the pass adds
+                  // the pull of the head bodies (the tables' list of massive bodies) and the Jacobi term G M q/|q|^3 of the kick
+                  int wh_head; };
 
 enum { WARN_GR_ITER = 1u, WARN_GRFULL_SWEEPS = 2u, WARN_IM_ITER = 4u };
 
@@ -152,6 +156,13 @@ hipError_t launch_rk4_final(double* const v[3], const double* const a1[3], const
 hipError_t launch_wh_star(double* const x[3], double* const v[3], const double* m, double G, double h, double* star, hipStream_t st);
 hipError_t launch_wh_drift(double* const x[3], double* const v[3], double* const a[3], const double* m, double G, double h, double dtk, long long n,
                            double* star, bool exact, hipStream_t st);
+// Wisdom-Holman steps of a head of K <= 64 massive bodies in Jacobi coordinates (one wavefront; state between steps in `jac`,
+// 8*64 doubles).  begin: inertial -> Jacobi, record of the centre of mass in `lead`, drift over h0, Jacobi -> inertial columns.
+// step (after the head pass has left the additional accelerations of the head bodies in their columns): gravity among the head
+// bodies without the pair (0,1), Jacobi kick over dtk, record of the centre of mass and its acceleration in `rec`, drift over h,
+// Jacobi -> inertial columns, acceleration columns of the head cleared.
+hipError_t launch_wh_head_begin(const View& v, long long K, double G, double h0, double* jac, double* lead, bool exact, hipStream_t st);
+hipError_t launch_wh_head_step(const View& v, long long K, double G, double dtk, double h, double* jac, double* rec, bool exact, hipStream_t st);
 long long im_partial_count(long long n);
 hipError_t launch_im_update(double* const fin[3], const double* const orig[3], double* const avgv[3], double* const avga[3], double dt,
                             long long n, double* partials, double* sums, bool exact, hipStream_t st, const unsigned* stop = nullptr);

@@ -637,6 +637,38 @@ __device__ __forceinline__ void integrate_tail(const Program& prog, const HeadCo
     }
 }
 
+// Wisdom-Holman kick of a massless body behind a head of several massive bodies: the pull of every
+// head body (direct gravity; with one head body it cancels against the Jacobi term and neither is
+// formed) and the Jacobi term + G M q / |q|^3, q = position from the head's centre of mass (`frame`).
+template <bool EXACT>
+__device__ __forceinline__ void wh_head_pull(const HeadConsts* __restrict__ tab, double G, const double* __restrict__ frame, const Part& p, V3& acc) {
+    const int nh = tab->nheadm;
+    if (EXACT) {
+#pragma clang fp contract(off)
+        for (int c = 0; c < nh; c++) {
+            const double dx = p.x - tab->head[c][0], dy = p.y - tab->head[c][1], dz = p.z - tab->head[c][2];
+            const double r = sqrt(dx * dx + dy * dy + dz * dz);
+            const double pre = -G * tab->head[c][3] / (r * r * r);
+            acc.x += pre * dx; acc.y += pre * dy; acc.z += pre * dz;
+        }
+        const double qx = p.x - frame[0], qy = p.y - frame[1], qz = p.z - frame[2];
+        const double r2i = 1. / (qx * qx + qy * qy + qz * qz);
+        const double pre3 = sqrt(r2i) * r2i * frame[12];
+        acc.x += pre3 * qx; acc.y += pre3 * qy; acc.z += pre3 * qz;
+    } else {
+        for (int c = 0; c < nh; c++) {
+            const double dx = p.x - tab->head[c][0], dy = p.y - tab->head[c][1], dz = p.z - tab->head[c][2];
+            const double ri = fast_rsqrt(dx * dx + dy * dy + dz * dz);
+            const double pre = -(G * tab->head[c][3]) * (ri * ri * ri);
+            acc.x = fma(pre, dx, acc.x); acc.y = fma(pre, dy, acc.y); acc.z = fma(pre, dz, acc.z);
+        }
+        const double qx = p.x - frame[0], qy = p.y - frame[1], qz = p.z - frame[2];
+        const double ri = fast_rsqrt(qx * qx + qy * qy + qz * qz);
+        const double pre3 = frame[12] * (ri * ri * ri);
+        acc.x = fma(pre3, qx, acc.x); acc.y = fma(pre3, qy, acc.y); acc.z = fma(pre3, qz, acc.z);
+    }
+}
+
 // EPI (tail pass only; see StepArgs).  EPI_WH: the pass carries a whole Wisdom-Holman step of the
 // massless bodies -- the forces start from zero instead of the acceleration columns, the body is
 // kicked with them and drifted on its Kepler orbit about body 0, and positions and velocities are
@@ -818,6 +850,7 @@ __global__ __launch_bounds__(BLOCK, (BACKREACT && SIG == 0ull) ? 2 : (!EXACT && 
         for (int k = 0; k < 2; k++) {
             if (!(k ? act1 : act0)) continue;
             s[k][0] = p[k].x; s[k][1] = p[k].y; s[k][2] = p[k].z; s[k][3] = p[k].vx; s[k][4] = p[k].vy; s[k][5] = p[k].vz;
+            if (step.wh_head > 1) wh_head_pull<EXACT>(tab, prog.G, step.star, p[k], acc[k]);
             wh_kick_drift<EXACT, true>(s[k], acc[k].x, acc[k].y, acc[k].z, step.h, step.dtk, step.star);
         }
         if (full) {

@@ -177,11 +177,78 @@ def test_kepler_drift_default_arithmetic_agrees_with_reference_order(ctx):
     assert np.isfinite(out[1]).all() and r.min() > 0
 
 
-def test_layouts_with_more_than_one_massive_body_are_refused(ctx):
-    from reboundx_amd.device import RebxAmdError
-    cols, pp, _ = synthetic.disk(100, 2)
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("forces", [[], C5_STACK, C2_STACK, [("gr", {"c": C})], [("modify_orbits_forces", {"coordinates": 1}), ("gr_potential", {"c": C})]],
+                         ids=["force-free", "five-effects", "rad+harmonics+gr", "gr", "barycentric-drag+gr_potential"])
+@pytest.mark.parametrize("n,n_planets", [(3, 2), (1500, 2), (700, 6)])
+def test_steps_of_star_planets_and_dust_match_the_checker(ctx, n, n_planets, forces, mode):
+    """BASELINE configuration 1's shape (star + planets + massless dust) stepped on the device: the massive head in Jacobi
+    coordinates in one wavefront (Kepler drifts about G*eta_i, gravity among the planets without the star-planet-1 pair,
+    Jacobi kick), the dust behind it in one pass per step about the head's centre of mass, pulled by every head body.
+    Against the checker's Wisdom-Holman restatement (which reproduces the reference's two-planet archives), 40 steps.
+    The two sides round differently (whole drifts between kicks here, two half drifts with a change of coordinates in
+    between there; the star's pull on a dust grain and the Jacobi term cancel to 1e-3 of either): bar 1e-11 of the state."""
+    dt, steps = 0.05, 40
+    cols, pp, _ = synthetic.disk(n, n_planets)
+    cols["vx"][0], cols["vy"][0] = 1e-3, -2e-3
+    ref = oracle.Sim(cols)
+    oracle.whfast_steps(ref, dt, steps, forces, pp)
+    want = np.array([ref.cols[k] for k in ("x", "y", "z", "vx", "vy", "vz")])
     host = dict(cols)
-    dp = DeviceParticles.from_host(host, device="cuda:0")
+    for k in ("beta", "R_tides", "k1", "tau_a", "tau_e", "tau_inc"):
+        host[k] = pp[k]
+    dp = DeviceParticles.from_host(host, device="cuda:0", n_head=n_planets + 1, tail_massless=True)
+    ctx.wh_steps(dp.view(), build_ops(forces, pp), dt, steps, mode)
+    got = state_of(dp)
+    assert np.isfinite(got).all()
+    start = np.array([cols[k] for k in ("x", "y", "z", "vx", "vy", "vz")])
+    assert np.abs(want - start).max() > 0.1
+    err = np.abs(got - want).max(axis=0)
+    scale = np.abs(want).max()
+    from gpu_common import record
+    record("wh_steps:star+%d planets:n=%d:%s:mode=%d" % (n_planets, n, "+".join(f[0] for f in forces) or "force-free", mode), unfloored=err.max() / scale)
+    assert err.max() <= 1e-11 * scale, (int(err.argmax()), err.max() / scale)
+    assert float(np.abs(np.array(dp.acc_host())[:, :n_planets + 1]).max()) == 0.0
+
+
+def test_star_and_planets_conserve_energy_and_momentum_over_a_long_run(ctx):
+    """Independent of the checker: force-free, 2000 steps of star + 4 planets: total momentum to rounding (the centre of
+    mass is never kicked), energy error bounded and oscillating as for any Wisdom-Holman map (< 1e-7 relative here, with
+    no secular drift between the two halves of the run), massless grains keep their Jacobi constant to the same level."""
+    n, n_planets, dt = 300, 4, 0.02
+    cols, pp, _ = synthetic.disk(n, n_planets)
+
+    def diagnostics(s):
+        m = cols["m"][:n_planets + 1]
+        x, v = s[:3, :n_planets + 1], s[3:, :n_planets + 1]
+        kinetic = 0.5 * (m * (v ** 2).sum(axis=0)).sum()
+        pot = 0.
+        for i in range(n_planets + 1):
+            for j in range(i):
+                pot -= m[i] * m[j] / np.sqrt(((x[:, i] - x[:, j]) ** 2).sum())
+        return kinetic + pot, (m * v).sum(axis=1)
+
+    dp = DeviceParticles.from_host(dict(cols), device="cuda:0", n_head=n_planets + 1, tail_massless=True)
+    e0, p0 = diagnostics(state_of(dp))
+    errs = []
+    for _ in range(2):
+        ctx.wh_steps(dp.view(), [], dt, 1000, 0)
+        e, p = diagnostics(state_of(dp))
+        errs.append(abs((e - e0) / e0))
+        assert np.abs(p - p0).max() <= 1e-15
+    assert max(errs) <= 1e-7 and errs[1] <= 10 * errs[0] + 1e-9
+    assert np.isfinite(state_of(dp)).all()
+
+
+def test_layouts_the_stepping_run_cannot_take_are_refused(ctx):
+    from reboundx_amd.device import RebxAmdError
+    cols, pp, _ = synthetic.disk(100, 2, dust_mass=1e-9)         # every body massive: more than 64 in the head
+    dp = DeviceParticles.from_host(dict(cols), device="cuda:0")
     with pytest.raises(RebxAmdError) as ei:
         ctx.wh_steps(dp.view(), [], 0.01, 1)
+    assert ei.value.code == 3
+    cols, pp, _ = synthetic.disk(100, 2)
+    dp = DeviceParticles.from_host(dict(cols), device="cuda:0", n_head=3, tail_massless=True)
+    with pytest.raises(RebxAmdError) as ei:                      # gr_full is not a streaming force
+        ctx.wh_steps(dp.view(), build_ops([("gr_full", {"c": C})], pp), 0.01, 1)
     assert ei.value.code == 3
