@@ -316,7 +316,8 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
     if (need_m && !v.m) return fail(ctx, REBXAMD_ERR_ARG, "mass column missing");
 
     const bool exact = (mode == REBXAMD_MODE_EXACT);
-    const bool vec2 = all_aligned(v);
+    // (a pass that carries an integrator's round also makes 16-byte accesses to the caller's columns in step->aux)
+    const bool vec2 = all_aligned(v) && (!step || (aligned16(step->aux[0]) && aligned16(step->aux[1]) && aligned16(step->aux[2])));
     const long long K = v.n_head < v.n ? v.n_head : v.n;
     const bool sparse = target_lo < 0 && (u->tail_massless != 0 || K == v.n) && K >= 1 && K <= REBXAMD_MAX_HEAD && max_src < K;
 

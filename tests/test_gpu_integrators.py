@@ -116,6 +116,37 @@ def test_update_carried_by_one_pass_equals_separate_passes(ctx, n, planets, forc
         assert (np.abs(a1 - a2) / np.where(big == 0., 1., big)[None, :]).max() <= TOL
 
 
+@pytest.mark.parametrize("integrator", ["euler", "rk4", "implicit_midpoint"])
+@pytest.mark.parametrize("odd", [("vx",), ("vy", "vz"), ("x", "vx", "ax")])
+def test_columns_at_odd_offsets_take_the_eight_byte_accesses(ctx, integrator, odd):
+    """Columns that start 8 bytes off a 16-byte boundary (a slice of a larger array) must not be touched with 16-byte
+    accesses: also the caller's velocity columns, which the carried implicit-midpoint rounds read and write through
+    the integrator's own pointers.  Same result as with aligned columns, bit for bit."""
+    import torch
+    n = 4099
+    cols, pp, _ = synthetic.disk(n, 2)
+    ops = build_ops(C5_STACK, pp)
+    out = []
+    for shifted in (False, True):
+        dp = device_state(cols, pp)
+        if shifted:
+            for k in odd:
+                room = torch.zeros(n + 3, dtype=torch.float64, device="cuda:0")
+                start = 1 if room.data_ptr() % 16 == 0 else 2
+                view = room[start:start + n]
+                assert view.data_ptr() % 16 == 8
+                view.copy_(dp.cols[k])
+                dp.cols[k] = view
+        rounds = ctx.integrate_force(dp.view(), ops, integrator, 0.01, EXACT)
+        out.append((rounds, vel(dp), np.array(dp.acc_host())))
+    assert out[0][0] == out[1][0]
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    ref = oracle.Sim(cols)
+    oracle.integrate_force(ref, integrator, 0.01, C5_STACK, pp)
+    v0 = np.array([cols[k] for k in ("vx", "vy", "vz")])
+    assert dv_err(v0, np.array([ref.cols[k] for k in ("vx", "vy", "vz")]), out[1][1]) <= TOL
+
+
 @pytest.mark.parametrize("dt", [1e-6, 0.01, 0.5, 2.0])
 def test_implicit_midpoint_rounds_queued_ahead_of_the_host(ctx, dt):
     """The carried implicit-midpoint update tests convergence on the device and queues rounds ahead
