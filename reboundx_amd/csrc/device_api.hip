@@ -1302,8 +1302,10 @@ extern "C" int rebxamd_grfull(rebxamd_ctx* ctx, const rebxamd_view* u, double c,
     if (!u->ax || !u->ay || !u->az) return fail(ctx, REBXAMD_ERR_ARG, "gr_full: acceleration columns missing");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(ctx->device));
-    // workspace: a_newton(3) pot(1) a_const(3) a_old(3) a_new(3) = 13 columns
-    rc = ensure(ctx, &ctx->gf, &ctx->gf_cap, (size_t)13 * (size_t)n * sizeof(double), st);
+    // workspace: a_newton(3) pot(1) a_const(3) a_old(3) a_new(3) = 13 columns; default arithmetic: behind them the partial sums
+    // of the pass that the first sweep and the potential sums share (they outlive the a_const pass, which uses the context's own)
+    const bool fused = mode != REBXAMD_MODE_EXACT;
+    rc = ensure(ctx, &ctx->gf, &ctx->gf_cap, (size_t)13 * (size_t)n * sizeof(double) + (fused ? grfull_partial_bytes(n, n) : 0), st);
     if (rc != REBXAMD_OK) return rc;
     double* w = ctx->gf;
     double *anx = w, *any_ = w + n, *anz = w + 2 * n, *pot = w + 3 * n;
@@ -1312,8 +1314,14 @@ extern "C" int rebxamd_grfull(rebxamd_ctx* ctx, const rebxamd_view* u, double c,
     double *nwx = w + 10 * n, *nwy = w + 11 * n, *nwz = w + 12 * n;
     const View v = make_view(u);
     HIP_TRY(launch_grfull_prepare(v, u->G, gravity_ignore_10, anx, any_, anz, aox, aoy, aoz, st));
-    rc = rebxamd_grfull_pot(ctx, u, c, 0, n, pot, mode, stream);
-    if (rc != REBXAMD_OK) return rc;
+    double* const part4 = w + 13 * n;
+    if (fused) {
+        HIP_TRY(launch_grfull_sweep0_pot(v, u->G, c, 0, n, anx, any_, anz, part4, st));
+        HIP_TRY(launch_grfull_sweep0_pot_combine(false, v, 0, n, part4, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pot, nullptr, nullptr, nullptr, st));
+    } else {
+        rc = rebxamd_grfull_pot(ctx, u, c, 0, n, pot, mode, stream);
+        if (rc != REBXAMD_OK) return rc;
+    }
     rc = rebxamd_grfull_const(ctx, u, c, 0, n, pot, acx, acy, acz, mode, stream);
     if (rc != REBXAMD_OK) return rc;
     // All ten sweeps (reference gr_full.c:173: the bound is the literal 10) are queued at once: the stopping rule is
@@ -1328,7 +1336,11 @@ extern "C" int rebxamd_grfull(rebxamd_ctx* ctx, const rebxamd_view* u, double c,
     for (int k = 0; k < 10 && rc == REBXAMD_OK; k++) {
         double* const* src = (k & 1) ? b1 : b0;
         double* const* dst = (k & 1) ? b0 : b1;
-        rc = rebxamd_grfull_sweep(ctx, u, c, 0, n, anx, any_, anz, src[0], src[1], src[2], acx, acy, acz, dst[0], dst[1], dst[2], ctl + 2, mode, stream);
+        if (k == 0 && fused) {
+            // the first sweep's pair sums are waiting in part4: add a_const, vote
+            if (launch_grfull_sweep0_pot_combine(true, v, 0, n, part4, acx, acy, acz, src[0], src[1], src[2], dst[0], dst[1], dst[2], ctl + 2, st) != hipSuccess)
+                rc = fail(ctx, REBXAMD_ERR_HIP, "gr_full: first sweep");
+        } else rc = rebxamd_grfull_sweep(ctx, u, c, 0, n, anx, any_, anz, src[0], src[1], src[2], acx, acy, acz, dst[0], dst[1], dst[2], ctl + 2, mode, stream);
         if (rc == REBXAMD_OK && launch_grfull_vote(ctl, st) != hipSuccess) rc = fail(ctx, REBXAMD_ERR_HIP, "gr_full: vote kernel");
     }
     ctx->gf_stop = caller_stop;

@@ -23,7 +23,7 @@ namespace rebxamd {
 
 static constexpr int GB = 256;      // rows per workgroup == bodies per LDS tile
 
-enum { PASS_POT = 0, PASS_CONST = 1, PASS_SWEEP = 2 };
+enum { PASS_POT = 0, PASS_CONST = 1, PASS_SWEEP = 2, PASS_SWEEP_POT = 3 };    // the last: the first sweep (a_old = 0) and the potential sums in one pass
 
 struct GrFullArgs {
     long long n, row0, row1;
@@ -38,7 +38,8 @@ struct GrFullArgs {
 
 // ------------------------------------------------------------------ fast passes
 struct __align__(16) TileA { double x, y, z, gm; };     // position and G*m of body j
-struct __align__(16) TileB { double a, b, c, d; };      // const: v_j, phi_j - 2 v_j^2 ; sweep: 3.5 (a_newton_j + a_old_j)
+struct __align__(16) TileB { double a, b, c, d; };      // const: v_j, phi_j - 2 v_j^2 ; sweep: B_j = 3.5 G m_j (a_newton_j + a_old_j), and B_j.x / 7
+struct __align__(16) TileC { double b, c; };            // sweep: B_j.y / 7, B_j.z / 7
 
 __device__ __forceinline__ double rsq_refined(double x) {
     // hardware estimate (~2^-23) + one Newton step: y (1 + e/2) with e = 1 - x y^2 leaves a relative
@@ -50,52 +51,75 @@ __device__ __forceinline__ double rsq_refined(double x) {
     return fma(0.5 * y, e, y);
 }
 
+static constexpr double K_V = 1.224744871391589;       // sqrt(1.5): the const pass stages velocities scaled by it
+static constexpr double INV_K = 0.816496580927726;     // 1 / sqrt(1.5)
+
 // State of one row i while it sweeps over the bodies j.
 struct Row {
-    double xi, yi, zi, vxi, vyi, vzi, p4;
-    double s0, s1, s2;
+    double xi, yi, zi;
+    double ax, ay, az, bx, by, bz, p4;  // const pass: (4/k) v_i, 4 v_i, 4 phi_i c^2 - v_i^2   (k = sqrt(1.5), see grfull_tile)
+    double s0, s1, s2, sp;              // running sums (sp: the potential's; const pass: sum of w2)
+    double t0, t1, t2;                  // const pass: sum of w2 * (k v_j)
     int self;           // index of the row inside the current tile, -1 if it is not in it
 };
 
 // One 256-body tile against this thread's R rows: every body fetched from LDS is used R times.
 // DIAG: the tile contains rows of this workgroup, so the self pair has to be masked (only the
 // tiles that overlap the workgroup's own rows pay for the compare).
-// sweep: the tile holds B = 3.5 (a_newton_j + a_old_j):  term = G m_j/r ( (d.B) d /(7 r^2) + B )
+// sweep: with B_j = 3.5 G m_j (a_newton_j + a_old_j) the pair's term is  (1/r) ( (d.B_j/7) d / r^2 + B_j ):
+// 22 instructions per pair (3 differences, 3 for r^2, 5 for the refined reciprocal square root, 1 for
+// 1/r^2, 3 for the dot product with B_j/7, 1 product, 2 x 3 fused multiply-adds), the mass already inside
+// B_j and both B_j and B_j/7 staged, so that no per-pair scaling is left.
 template <int PASS, bool DIAG, int R>
-__device__ __forceinline__ void grfull_tile(const TileA* __restrict__ ta, const TileB* __restrict__ tb, Row (&row)[R]) {
+__device__ __forceinline__ void grfull_tile(const TileA* __restrict__ ta, const TileB* __restrict__ tb, const TileC* __restrict__ tc, Row (&row)[R]) {
+    constexpr bool SWEEP = PASS == PASS_SWEEP || PASS == PASS_SWEEP_POT;
 #pragma unroll 4
     for (int jj = 0; jj < GB; jj++) {
         const TileA A = ta[jj];
         TileB B;
+        TileC C;
         if (PASS != PASS_POT) B = tb[jj];
+        if (SWEEP) C = tc[jj];
 #pragma unroll
         for (int q = 0; q < R; q++) {
             Row& w = row[q];
             const double dx = w.xi - A.x, dy = w.yi - A.y, dz = w.zi - A.z;
             double r2 = dx * dx + dy * dy + dz * dz;
+            if (SWEEP) {
+                const bool self = DIAG && jj == w.self;
+                if (self) r2 = 1.;
+                double ri = rsq_refined(r2);
+                if (self) ri = 0.;
+                const double h = (ri * ri) * (dx * B.d + dy * C.b + dz * C.c);
+                w.s0 = fma(ri, fma(h, dx, B.a), w.s0);
+                w.s1 = fma(ri, fma(h, dy, B.b), w.s1);
+                w.s2 = fma(ri, fma(h, dz, B.c), w.s2);
+                if (PASS == PASS_SWEEP_POT) w.sp = fma(A.gm, ri, w.sp);
+                continue;
+            }
             double gm = A.gm;
             if (DIAG && jj == w.self) { gm = 0.; r2 = 1.; }
             const double ri = rsq_refined(r2);
             if (PASS == PASS_POT) {
                 w.s0 = fma(gm, ri, w.s0);
-            } else if (PASS == PASS_CONST) {
-                // B = (v_j, phi_j - 2 v_j^2); p4 = 4 phi_i - v_i^2
+            } else {
+                // The pair's term is  g3 ( f1 d + f2 (v_i - v_j) ),  g3 = G m_j / r^3,
+                //   f1 = 4 phi_i + phi_j - v_i^2 - 2 v_j^2 + 4 v_i.v_j + 1.5 (d.v_j)^2 / r^2,   f2 = d.(4 v_i - 3 v_j)     (units of c^2).
+                // Every use of v_j is linear or a square, so the tile holds k v_j with k = sqrt(1.5) (B.a..c; B.d = phi_j c^2 - 2 v_j^2)
+                // and the row the matching multiples of v_i: 1.5 (d.v_j)^2 = (d.k v_j)^2, 4 v_i.v_j = ((4/k) v_i).(k v_j),
+                // 3 d.v_j = (3/k) d.(k v_j).  The part  g3 f2 (v_i - v_j)  is summed as  v_i sum(w2) - (1/k) sum(w2 k v_j)  with
+                // w2 = g3 f2, the factors outside the sums applied once per row: 36 instructions per pair instead of 42.
                 const double ri2 = ri * ri;
                 const double g3 = gm * ri2 * ri;
-                const double vivj = w.vxi * B.a + w.vyi * B.b + w.vzi * B.c;
                 const double dvj = dx * B.a + dy * B.b + dz * B.c;
-                const double dvi = dx * w.vxi + dy * w.vyi + dz * w.vzi;
-                const double f1 = fma(1.5 * ri2, dvj * dvj, fma(4., vivj, w.p4 + B.d));
-                const double f2 = fma(4., dvi, -3. * dvj);
-                w.s0 = fma(g3, fma(f1, dx, f2 * (w.vxi - B.a)), w.s0);
-                w.s1 = fma(g3, fma(f1, dy, f2 * (w.vyi - B.b)), w.s1);
-                w.s2 = fma(g3, fma(f1, dz, f2 * (w.vzi - B.c)), w.s2);
-            } else {
-                const double h = (ri * ri) * ((dx * B.a + dy * B.b + dz * B.c) * (1. / 7.));
-                const double g1 = gm * ri;
-                w.s0 = fma(g1, fma(h, dx, B.a), w.s0);
-                w.s1 = fma(g1, fma(h, dy, B.b), w.s1);
-                w.s2 = fma(g1, fma(h, dz, B.c), w.s2);
+                const double dvi = dx * w.bx + dy * w.by + dz * w.bz;
+                const double vv = fma(w.ax, B.a, fma(w.ay, B.b, fma(w.az, B.c, w.p4 + B.d)));
+                const double f1 = fma(ri2 * dvj, dvj, vv);
+                const double f2 = fma(-2.449489742783178, dvj, dvi);        // 3 / sqrt(1.5) = sqrt(6)
+                const double u = g3 * f1, w2 = g3 * f2;
+                w.s0 = fma(u, dx, w.s0); w.s1 = fma(u, dy, w.s1); w.s2 = fma(u, dz, w.s2);
+                w.t0 = fma(w2, B.a, w.t0); w.t1 = fma(w2, B.b, w.t1); w.t2 = fma(w2, B.c, w.t2);
+                w.sp += w2;
             }
         }
     }
@@ -104,8 +128,10 @@ __device__ __forceinline__ void grfull_tile(const TileA* __restrict__ ta, const 
 // Workgroup = 256 threads, GB*R rows: thread t owns rows t, t + 256, ... of the workgroup's block.
 template <int PASS, int R>
 __global__ __launch_bounds__(GB) void grfull_fast_kernel(GrFullArgs a) {
+    constexpr bool SWEEP = PASS == PASS_SWEEP || PASS == PASS_SWEEP_POT;
     __shared__ TileA ta[GB];
     __shared__ TileB tb[GB];
+    __shared__ TileC tc[SWEEP ? GB : 1];
     const int tid = threadIdx.x;
     if (PASS == PASS_SWEEP && a.stop != nullptr && *a.stop != 0u) return;       // a sweep queued past convergence
     const long long nrows = a.row1 - a.row0;
@@ -122,16 +148,18 @@ __global__ __launch_bounds__(GB) void grfull_fast_kernel(GrFullArgs a) {
         ri_[q] = r;
         live[q] = r < nrows;
         Row& w = row[q];
-        w.xi = w.yi = w.zi = w.vxi = w.vyi = w.vzi = w.p4 = 0.;
-        w.s0 = w.s1 = w.s2 = 0.;
+        w.xi = w.yi = w.zi = w.ax = w.ay = w.az = w.bx = w.by = w.bz = w.p4 = 0.;
+        w.s0 = w.s1 = w.s2 = w.sp = w.t0 = w.t1 = w.t2 = 0.;
         w.self = -1;
         if (live[q]) {
             const long long i = a.row0 + r;
             w.xi = a.x[i]; w.yi = a.y[i]; w.zi = a.z[i];
             if (PASS == PASS_CONST) {
-                w.vxi = a.vx[i]; w.vyi = a.vy[i]; w.vzi = a.vz[i];
-                const double vi2 = w.vxi * w.vxi + w.vyi * w.vyi + w.vzi * w.vzi;
+                const double vxi = a.vx[i], vyi = a.vy[i], vzi = a.vz[i];
+                const double vi2 = vxi * vxi + vyi * vyi + vzi * vzi;
                 w.p4 = 4. * a.pot[i] * a.C2 - vi2;      // work in units where 1/c^2 is applied once at the end
+                w.bx = 4. * vxi; w.by = 4. * vyi; w.bz = 4. * vzi;
+                w.ax = w.bx * INV_K; w.ay = w.by * INV_K; w.az = w.bz * INV_K;
             }
         }
     }
@@ -143,19 +171,27 @@ __global__ __launch_bounds__(GB) void grfull_fast_kernel(GrFullArgs a) {
             TileA A; A.x = a.x[j]; A.y = a.y[j]; A.z = a.z[j]; A.gm = a.G * a.m[j];
             ta[tid] = A;
             if (PASS == PASS_CONST) {
-                TileB B; B.a = a.vx[j]; B.b = a.vy[j]; B.c = a.vz[j];
-                B.d = a.pot[j] * a.C2 - 2. * (B.a * B.a + B.b * B.b + B.c * B.c);
+                const double vxj = a.vx[j], vyj = a.vy[j], vzj = a.vz[j];
+                TileB B; B.a = K_V * vxj; B.b = K_V * vyj; B.c = K_V * vzj;
+                B.d = a.pot[j] * a.C2 - 2. * (vxj * vxj + vyj * vyj + vzj * vzj);
                 tb[tid] = B;
             }
-            if (PASS == PASS_SWEEP) {
-                TileB B; B.a = 3.5 * (a.anx[j] + a.aox[j]); B.b = 3.5 * (a.any_[j] + a.aoy[j]); B.c = 3.5 * (a.anz[j] + a.aoz[j]); B.d = 0.;
-                tb[tid] = B;
+            if (SWEEP) {
+                // (the first sweep starts from a_old = 0 and does not read it)
+                const double tx = PASS == PASS_SWEEP ? a.anx[j] + a.aox[j] : a.anx[j];
+                const double ty = PASS == PASS_SWEEP ? a.any_[j] + a.aoy[j] : a.any_[j];
+                const double tz = PASS == PASS_SWEEP ? a.anz[j] + a.aoz[j] : a.anz[j];
+                const double g35 = 3.5 * A.gm, g05 = 0.5 * A.gm;
+                TileB B; B.a = g35 * tx; B.b = g35 * ty; B.c = g35 * tz; B.d = g05 * tx;
+                TileC C; C.b = g05 * ty; C.c = g05 * tz;
+                tb[tid] = B; tc[tid] = C;
             }
         } else {
             // padding bodies: zero mass far away contributes exactly nothing
             TileA A; A.x = 1.e100; A.y = 1.e100; A.z = 1.e100; A.gm = 0.;
             TileB B; B.a = B.b = B.c = B.d = 0.;
             ta[tid] = A; tb[tid] = B;
+            if (SWEEP) { TileC C; C.b = C.c = 0.; tc[tid] = C; }
         }
         __syncthreads();
         if (jt < blk_hi && jt + GB > blk_lo) {      // workgroup-uniform: this tile overlaps our own rows
@@ -164,9 +200,9 @@ __global__ __launch_bounds__(GB) void grfull_fast_kernel(GrFullArgs a) {
                 const long long i = a.row0 + ri_[q];
                 row[q].self = (live[q] && i >= jt && i < jt + GB) ? (int)(i - jt) : -1;
             }
-            grfull_tile<PASS, true, R>(ta, tb, row);
+            grfull_tile<PASS, true, R>(ta, tb, tc, row);
         } else {
-            grfull_tile<PASS, false, R>(ta, tb, row);
+            grfull_tile<PASS, false, R>(ta, tb, tc, row);
         }
     }
     const double scale = a.invC2;
@@ -175,6 +211,16 @@ __global__ __launch_bounds__(GB) void grfull_fast_kernel(GrFullArgs a) {
         if (!live[q]) continue;
         if (PASS == PASS_POT) {
             a.part[(long long)blockIdx.y * nrows + ri_[q]] = row[q].s0 * scale;
+        } else if (PASS == PASS_SWEEP_POT) {
+            double* o = a.part + ((long long)blockIdx.y * nrows + ri_[q]) * 4;
+            o[0] = row[q].s0 * scale; o[1] = row[q].s1 * scale; o[2] = row[q].s2 * scale; o[3] = row[q].sp * scale;
+        } else if (PASS == PASS_CONST) {
+            // + v_i sum(w2) - (1/k) sum(w2 k v_j);  row.b = 4 v_i
+            const Row& w = row[q];
+            double* o = a.part + ((long long)blockIdx.y * nrows + ri_[q]) * 3;
+            o[0] = fma(0.25 * w.bx, w.sp, fma(-INV_K, w.t0, w.s0)) * scale;
+            o[1] = fma(0.25 * w.by, w.sp, fma(-INV_K, w.t1, w.s1)) * scale;
+            o[2] = fma(0.25 * w.bz, w.sp, fma(-INV_K, w.t2, w.s2)) * scale;
         } else {
             double* o = a.part + ((long long)blockIdx.y * nrows + ri_[q]) * 3;
             o[0] = row[q].s0 * scale; o[1] = row[q].s1 * scale; o[2] = row[q].s2 * scale;
@@ -187,7 +233,9 @@ template <int PASS>
 __global__ __launch_bounds__(256) void grfull_combine_kernel(const double* part, int nchunks, long long row0, long long row1,
                                                              const double* acx, const double* acy, const double* acz,
                                                              const double* aox, const double* aoy, const double* aoz,
-                                                             double* o0, double* o1, double* o2, unsigned* flag, const unsigned* stop) {
+                                                             double* o0, double* o1, double* o2, unsigned* flag, const unsigned* stop, int stride) {
+    // stride: doubles per (chunk, row) entry of `part` (1 for the potential pass, 3 for the others; 4 when the
+    // first sweep and the potential sums shared a pass: the sweep's three sums, then the potential's)
     if (PASS == PASS_SWEEP && stop != nullptr && *stop != 0u) return;
     const long long nrows = row1 - row0;
     const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -196,12 +244,12 @@ __global__ __launch_bounds__(256) void grfull_combine_kernel(const double* part,
         const long long i = row0 + r;
         if (PASS == PASS_POT) {
             double s = 0.;
-            for (int c = 0; c < nchunks; c++) s += part[(long long)c * nrows + r];
+            for (int c = 0; c < nchunks; c++) s += part[((long long)c * nrows + r) * stride + (stride - 1)];
             o0[i] = s;
         } else {
             double s0 = 0., s1 = 0., s2 = 0.;
             for (int c = 0; c < nchunks; c++) {
-                const double* q = part + ((long long)c * nrows + r) * 3;
+                const double* q = part + ((long long)c * nrows + r) * stride;
                 s0 += q[0]; s1 += q[1]; s2 += q[2];
             }
             if (PASS == PASS_SWEEP) {
@@ -512,8 +560,9 @@ static GrFullPlan plan(long long n, long long nrows) {
 }
 
 size_t grfull_partial_bytes(long long n, long long nrows) {
+    // (four doubles per row and chunk: the widest entry any pass writes)
     const GrFullPlan p = plan(n, nrows);
-    return (size_t)p.nchunks * (size_t)nrows * 3 * sizeof(double);
+    return (size_t)p.nchunks * (size_t)nrows * 4 * sizeof(double);
 }
 
 static GrFullArgs base_args(const View& v, double G, double c, long long row0, long long row1) {
@@ -550,16 +599,44 @@ hipError_t launch_grfull_pass(int pass, const View& v, double G, double c, long 
     if (pass == PASS_POT) {
         if (two) hipLaunchKernelGGL((grfull_fast_kernel<PASS_POT, 2>), g, b, 0, st, a);
         else hipLaunchKernelGGL((grfull_fast_kernel<PASS_POT, 1>), g, b, 0, st, a);
-        hipLaunchKernelGGL(grfull_combine_kernel<PASS_POT>, g2, b2, 0, st, part, p.nchunks, row0, row1, acx, acy, acz, aox, aoy, aoz, o0, o1, o2, flag, stop);
+        hipLaunchKernelGGL(grfull_combine_kernel<PASS_POT>, g2, b2, 0, st, part, p.nchunks, row0, row1, acx, acy, acz, aox, aoy, aoz, o0, o1, o2, flag, stop, 1);
     } else if (pass == PASS_CONST) {
         if (two) hipLaunchKernelGGL((grfull_fast_kernel<PASS_CONST, 2>), g, b, 0, st, a);
         else hipLaunchKernelGGL((grfull_fast_kernel<PASS_CONST, 1>), g, b, 0, st, a);
-        hipLaunchKernelGGL(grfull_combine_kernel<PASS_CONST>, g2, b2, 0, st, part, p.nchunks, row0, row1, acx, acy, acz, aox, aoy, aoz, o0, o1, o2, flag, stop);
+        hipLaunchKernelGGL(grfull_combine_kernel<PASS_CONST>, g2, b2, 0, st, part, p.nchunks, row0, row1, acx, acy, acz, aox, aoy, aoz, o0, o1, o2, flag, stop, 3);
     } else {
         if (two) hipLaunchKernelGGL((grfull_fast_kernel<PASS_SWEEP, 2>), g, b, 0, st, a);
         else hipLaunchKernelGGL((grfull_fast_kernel<PASS_SWEEP, 1>), g, b, 0, st, a);
-        hipLaunchKernelGGL(grfull_combine_kernel<PASS_SWEEP>, g2, b2, 0, st, part, p.nchunks, row0, row1, acx, acy, acz, aox, aoy, aoz, o0, o1, o2, flag, stop);
+        hipLaunchKernelGGL(grfull_combine_kernel<PASS_SWEEP>, g2, b2, 0, st, part, p.nchunks, row0, row1, acx, acy, acz, aox, aoy, aoz, o0, o1, o2, flag, stop, 3);
     }
+    return hipGetLastError();
+}
+
+// The first sweep (a_old = 0, so it needs neither the potential sums nor a_const yet) and the potential sums in ONE pass over
+// the pairs: they share the separations and the reciprocal distances.  Leaves the j-chunk partial sums in `part4` (4 per row);
+// combine_pot adds up the potential sums, combine_sweep -- once a_const exists -- the sweep's (with the stopping rule's vote).
+hipError_t launch_grfull_sweep0_pot(const View& v, double G, double c, long long row0, long long row1,
+                                    const double* anx, const double* any_, const double* anz, double* part4, hipStream_t st) {
+    const long long nrows = row1 - row0;
+    if (nrows <= 0) return hipSuccess;
+    GrFullArgs a = base_args(v, G, c, row0, row1);
+    a.anx = anx; a.any_ = any_; a.anz = anz;
+    const GrFullPlan p = plan(v.n, nrows);
+    a.jchunk = p.jchunk; a.part = part4;
+    const dim3 g((unsigned)p.rowblocks, (unsigned)p.nchunks), b(GB);
+    if (p.rows_per_thread == 2) hipLaunchKernelGGL((grfull_fast_kernel<PASS_SWEEP_POT, 2>), g, b, 0, st, a);
+    else hipLaunchKernelGGL((grfull_fast_kernel<PASS_SWEEP_POT, 1>), g, b, 0, st, a);
+    return hipGetLastError();
+}
+hipError_t launch_grfull_sweep0_pot_combine(bool sweep, const View& v, long long row0, long long row1, const double* part4,
+                                            const double* acx, const double* acy, const double* acz, const double* aox, const double* aoy, const double* aoz,
+                                            double* o0, double* o1, double* o2, unsigned* flag, hipStream_t st) {
+    const long long nrows = row1 - row0;
+    if (nrows <= 0) return hipSuccess;
+    const GrFullPlan p = plan(v.n, nrows);
+    const dim3 g2((unsigned)((nrows + 255) / 256)), b2(256);
+    if (sweep) hipLaunchKernelGGL(grfull_combine_kernel<PASS_SWEEP>, g2, b2, 0, st, part4, p.nchunks, row0, row1, acx, acy, acz, aox, aoy, aoz, o0, o1, o2, flag, (const unsigned*)nullptr, 4);
+    else hipLaunchKernelGGL(grfull_combine_kernel<PASS_POT>, g2, b2, 0, st, part4, p.nchunks, row0, row1, acx, acy, acz, aox, aoy, aoz, o0, o1, o2, flag, (const unsigned*)nullptr, 4);
     return hipGetLastError();
 }
 

@@ -197,6 +197,11 @@ hipError_t launch_grfull_pass(int pass, const View& v, double G, double c, long 
                               double* o0, double* o1, double* o2, unsigned* flag, double* part, bool exact, hipStream_t st,
                               const unsigned* stop = nullptr);
 // sweeps queued ahead of the host: ctl = {stop, sweeps run, vote of the sweep just run}
+hipError_t launch_grfull_sweep0_pot(const View& v, double G, double c, long long row0, long long row1,
+                                    const double* anx, const double* any_, const double* anz, double* part4, hipStream_t st);
+hipError_t launch_grfull_sweep0_pot_combine(bool sweep, const View& v, long long row0, long long row1, const double* part4,
+                                            const double* acx, const double* acy, const double* acz, const double* aox, const double* aoy, const double* aoz,
+                                            double* o0, double* o1, double* o2, unsigned* flag, hipStream_t st);
 hipError_t launch_grfull_vote(unsigned* ctl, hipStream_t st);
 hipError_t launch_grfull_finish_select(const View& v, double* const b0[3], double* const b1[3], const unsigned* ctl, unsigned* status, hipStream_t st);
 size_t grfull_hamiltonian_doubles(long long n);
