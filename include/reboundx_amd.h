@@ -593,6 +593,19 @@ int rebxamd_grfull_sweep(rebxamd_ctx* ctx, const rebxamd_view* view, double c, i
                          const double* acx, const double* acy, const double* acz,       /* a_const, rows in range valid */
                          double* outx, double* outy, double* outz,                      /* a_new, rows in range written */
                          uint32_t* dev_flag, int mode, void* stream);
+/* rebxamd_grfull_pot on rows [row0,row1) that ALSO forms the pair sums of the first sweep (gr_full.c:173-199 with
+ * a_old = 0: they need neither the potential sums nor a_const), sharing the separations and reciprocal distances of
+ * the pairs: one all-pairs pass less per evaluation.  The sweep's sums wait inside the context;
+ * rebxamd_grfull_sweep0_finish (same rows, same arguments as rebxamd_grfull_sweep) adds a_const to them, writes the
+ * new iterate and raises the flag like any sweep.  One pair of calls at a time per context.  In reference-order
+ * arithmetic the two calls are rebxamd_grfull_pot and rebxamd_grfull_sweep. */
+int rebxamd_grfull_pot_sweep0(rebxamd_ctx* ctx, const rebxamd_view* view, double c, int64_t row0, int64_t row1,
+                              const double* anx, const double* any_, const double* anz, double* pot, int mode, void* stream);
+int rebxamd_grfull_sweep0_finish(rebxamd_ctx* ctx, const rebxamd_view* view, double c, int64_t row0, int64_t row1,
+                                 const double* anx, const double* any_, const double* anz,
+                                 const double* aox, const double* aoy, const double* aoz,
+                                 const double* acx, const double* acy, const double* acz,
+                                 double* outx, double* outy, double* outz, uint32_t* dev_flag, int mode, void* stream);
 /* Lets a driver queue sweeps ahead of the host (no counterpart in the reference): while stop_dev != NULL,
  * the kernels of every rebxamd_grfull_sweep call on this context return at once, writing nothing, when the
  * device word *stop_dev is non-zero at the time they run.  NULL (default) switches this off. */

@@ -22,6 +22,9 @@ struct rebxamd_ctx {
     size_t partials_cap = 0;
     double* gf = nullptr;               // gr_full workspace
     size_t gf_cap = 0;
+    double* gf4 = nullptr;              // pair sums of a first sweep that shared its pass with the potential sums, until a_const exists
+    size_t gf4_cap = 0;
+    long long gf4_rows[2] = {0, 0}, gf4_n = -1;
     unsigned* gf_flag = nullptr;        // gr_full control words: stop, sweeps run, vote of the sweep just run (+ one spare)
     const unsigned* gf_stop = nullptr;  // caller's stop word for rebxamd_grfull_sweep (rebxamd_grfull_stop_word)
     double* chunk_sums = nullptr;       // second-stage scratch of the back-reaction reduction
@@ -126,6 +129,7 @@ extern "C" void rebxamd_destroy(rebxamd_ctx* ctx) {
     if (ctx->gf_flag) (void)hipFree(ctx->gf_flag);
     if (ctx->star) (void)hipFree(ctx->star);
     if (ctx->whead) (void)hipFree(ctx->whead);
+    if (ctx->gf4) (void)hipFree(ctx->gf4);
     if (ctx->hpin) (void)hipHostFree(ctx->hpin);
     if (ctx->chunk_sums) (void)hipFree(ctx->chunk_sums);
     if (ctx->scan) (void)hipFree(ctx->scan);
@@ -1265,6 +1269,45 @@ extern "C" int rebxamd_grfull_sweep(rebxamd_ctx* ctx, const rebxamd_view* u, dou
     }
     HIP_TRY(launch_grfull_pass(2, make_view(u), u->G, c, row0, row1, nullptr, anx, any_, anz, aox, aoy, aoz, acx, acy, acz,
                                outx, outy, outz, dev_flag, ctx->partials, exact, st, ctx->gf_stop));
+    return REBXAMD_OK;
+}
+
+// The potential sums of rows [row0,row1) together with the pair sums of the FIRST sweep (which starts from a_old = 0 and
+// therefore needs neither the potentials nor a_const): one pass over the pairs instead of two.  The sweep's sums stay in
+// the context until rebxamd_grfull_sweep0_finish adds a_const to them.  Reference-order arithmetic: the potential pass
+// alone; the finish call then runs the sweep itself.
+extern "C" int rebxamd_grfull_pot_sweep0(rebxamd_ctx* ctx, const rebxamd_view* u, double c, int64_t row0, int64_t row1,
+                                         const double* anx, const double* any_, const double* anz, double* pot, int mode, void* stream) {
+    if (mode == REBXAMD_MODE_EXACT) return rebxamd_grfull_pot(ctx, u, c, row0, row1, pot, mode, stream);
+    int rc = grfull_check(ctx, u, row0, row1);
+    if (rc != REBXAMD_OK) return rc;
+    if (!pot || !anx || !any_ || !anz) return fail(ctx, REBXAMD_ERR_ARG, "gr_full: NULL buffer");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    rc = ensure(ctx, &ctx->gf4, &ctx->gf4_cap, grfull_partial_bytes(u->n, row1 - row0), st);
+    if (rc != REBXAMD_OK) return rc;
+    const View v = make_view(u);
+    HIP_TRY(launch_grfull_sweep0_pot(v, u->G, c, row0, row1, anx, any_, anz, ctx->gf4, st));
+    HIP_TRY(launch_grfull_sweep0_pot_combine(false, v, row0, row1, ctx->gf4, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pot, nullptr, nullptr, nullptr, st));
+    ctx->gf4_rows[0] = row0; ctx->gf4_rows[1] = row1; ctx->gf4_n = u->n;
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_grfull_sweep0_finish(rebxamd_ctx* ctx, const rebxamd_view* u, double c, int64_t row0, int64_t row1,
+                                            const double* anx, const double* any_, const double* anz,
+                                            const double* aox, const double* aoy, const double* aoz,
+                                            const double* acx, const double* acy, const double* acz,
+                                            double* outx, double* outy, double* outz, uint32_t* dev_flag, int mode, void* stream) {
+    if (mode == REBXAMD_MODE_EXACT)
+        return rebxamd_grfull_sweep(ctx, u, c, row0, row1, anx, any_, anz, aox, aoy, aoz, acx, acy, acz, outx, outy, outz, dev_flag, mode, stream);
+    int rc = grfull_check(ctx, u, row0, row1);
+    if (rc != REBXAMD_OK) return rc;
+    if (!aox || !aoy || !aoz || !acx || !acy || !acz || !outx || !outy || !outz || !dev_flag) return fail(ctx, REBXAMD_ERR_ARG, "gr_full: NULL buffer");
+    if (!ctx->gf4 || ctx->gf4_rows[0] != row0 || ctx->gf4_rows[1] != row1 || ctx->gf4_n != u->n)
+        return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_grfull_sweep0_finish: no pair sums of rebxamd_grfull_pot_sweep0 for these rows are waiting");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(launch_grfull_sweep0_pot_combine(true, make_view(u), row0, row1, ctx->gf4, acx, acy, acz, aox, aoy, aoz, outx, outy, outz, dev_flag, (hipStream_t)stream));
+    ctx->gf4_n = -1;
     return REBXAMD_OK;
 }
 

@@ -203,6 +203,15 @@ class Context:
         self._check(lib.rebxamd_grfull_const(self._h, ctypes.byref(view), c, row0, row1, pot.data_ptr(),
                                              ac[0].data_ptr(), ac[1].data_ptr(), ac[2].data_ptr(), mode, self._stream()))
 
+    def grfull_pot_sweep0(self, view, c, row0, row1, an, pot, mode=_lib.MODE_FAST):
+        """Potential sums of the rows and, in the same pass, the pair sums of the first sweep (kept in the context)."""
+        self._check(lib.rebxamd_grfull_pot_sweep0(self._h, ctypes.byref(view), c, row0, row1, an[0].data_ptr(), an[1].data_ptr(), an[2].data_ptr(),
+                                                  pot.data_ptr(), mode, self._stream()))
+
+    def grfull_sweep0_finish(self, view, c, row0, row1, an, ao, ac, out, flag, mode=_lib.MODE_FAST):
+        ptrs = [t.data_ptr() for t in (an[0], an[1], an[2], ao[0], ao[1], ao[2], ac[0], ac[1], ac[2], out[0], out[1], out[2])]
+        self._check(lib.rebxamd_grfull_sweep0_finish(self._h, ctypes.byref(view), c, row0, row1, *ptrs, flag.data_ptr(), mode, self._stream()))
+
     def grfull_sweep(self, view, c, row0, row1, an, ao, ac, out, flag, mode=_lib.MODE_FAST):
         ptrs = [t.data_ptr() for t in (an[0], an[1], an[2], ao[0], ao[1], ao[2], ac[0], ac[1], ac[2], out[0], out[1], out[2])]
         self._check(lib.rebxamd_grfull_sweep(self._h, ctypes.byref(view), c, row0, row1, *ptrs, flag.data_ptr(), mode, self._stream()))

@@ -212,6 +212,13 @@ class HipGrFullEngine:
     def sweep(self, c, r0, r1, an, ao, ac, out, flag):
         self.ctx.grfull_sweep(self.view, c, r0, r1, an, ao, ac, out, flag, self.mode)
 
+    def pot_sweep0(self, c, r0, r1, an, pot):
+        """The potential sums and, in the same pass over the pairs, the pair sums of the first sweep."""
+        self.ctx.grfull_pot_sweep0(self.view, c, r0, r1, an, pot, self.mode)
+
+    def sweep0_finish(self, c, r0, r1, an, ao, ac, out, flag):
+        self.ctx.grfull_sweep0_finish(self.view, c, r0, r1, an, ao, ac, out, flag, self.mode)
+
     def finish(self, a):
         self.ctx.grfull_finish(self.view, a)
 
@@ -248,7 +255,13 @@ def grfull_sharded(engine, c, gravity_ignore_10=0, group=None):
         recv_flat = engine.zeros(world * (3 * per + 1))
         recv = recv_flat.view(world, 3 * per + 1)
     engine.newton(gravity_ignore_10, an, [ao3[0], ao3[1], ao3[2]])   # replicated: every rank holds the full incoming field
-    engine.pot(c, r0, r1, pot)
+    # (an engine that can lets the first sweep -- a_old = 0: no potentials, no a_const needed yet -- share the pass of the
+    # potential sums; its pair sums wait in the engine until a_const exists)
+    shared_pass = hasattr(engine, "pot_sweep0")
+    if shared_pass:
+        engine.pot_sweep0(c, r0, r1, an, pot)
+    else:
+        engine.pot(c, r0, r1, pot)
     if use_dist:
         _all_gather_into(pot, pot[rank * per:(rank + 1) * per].clone(), group)
     engine.const(c, r0, r1, pot, ac)
@@ -259,7 +272,8 @@ def grfull_sharded(engine, c, gravity_ignore_10=0, group=None):
         the stopping rule."""
         src, dst = bufs[k % 2], bufs[(k + 1) % 2]
         flag.zero_()
-        engine.sweep(c, r0, r1, an, [src[0], src[1], src[2]], ac, [dst[0], dst[1], dst[2]], flag)
+        run = engine.sweep0_finish if (k == 0 and shared_pass) else engine.sweep
+        run(c, r0, r1, an, [src[0], src[1], src[2]], ac, [dst[0], dst[1], dst[2]], flag)
         if not use_dist:
             return flag
         send[:3 * per].view(3, per).copy_(dst.view(3, world, per)[:, rank, :])
