@@ -95,10 +95,12 @@ def grfull_section(ctx, n, mode=0, dist=None, device="cuda:0"):
 
     grfull_sharded(eng, 1.0e4, 0)                  # warm-up (allocates workspaces, sets up RCCL rings)
     sync()
+    reps = 3
     t0 = time.perf_counter()
-    sweeps = grfull_sharded(eng, 1.0e4, 0)
+    for _ in range(reps):
+        sweeps = grfull_sharded(eng, 1.0e4, 0)
     sync()
-    dt = time.perf_counter() - t0
+    dt = (time.perf_counter() - t0) / reps
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
