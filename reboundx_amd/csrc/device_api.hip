@@ -343,9 +343,12 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
         if (wh && step->wh_head > 1) {
             // star + planets: the head pass leaves the additional accelerations of the head bodies in their columns and the
             // tables of this step; the head's own Wisdom-Holman step (gravity among its bodies, Jacobi kick, drift to the
-            // next force evaluation) follows and records the frame of the massless bodies for the pass below
-            HIP_TRY(launch_head(v, prog, hc, ctx->status, exact, st));
-            HIP_TRY(launch_wh_head_step(v, K, prog.G, step->dtk, step->h, ctx->whead, const_cast<double*>(step->star), exact, st));
+            // next force evaluation) follows and records the frame of the massless bodies for the pass below -- unless the
+            // pass of the step before has already done both in its extra workgroup
+            if (!step->head_ready) {
+                HIP_TRY(launch_head(v, prog, hc, ctx->status, exact, st));
+                HIP_TRY(launch_wh_head_step(v, K, prog.G, step->dtk, step->h, ctx->whead, const_cast<double*>(step->star), exact, st));
+            }
         } else if (!(wh && step->head_ready))
             HIP_TRY(launch_head(v, prog, hc, ctx->status, exact, st, wh ? const_cast<double*>(step->star) : nullptr, wh ? step->h : 0.,
                                 (wh && step->lead_in_head) ? const_cast<double*>(step->star0) : nullptr, wh ? step->h0 : 0.));
@@ -872,11 +875,19 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
         double* const lead = ctx->star + 32;
         HIP_TRY(launch_wh_head_begin(v, K, view->G, 0.5 * dt, ctx->whead, lead, exact, st));
         struct StageReset { rebxamd_ctx* c; ~StageReset() { c->hc_stage = 0; } } stage_reset{ctx};
-        ctx->hc_stage = 0;
+        // With massless bodies behind the head, the pass of step k also runs, in one extra workgroup, the head pass and the head
+        // step of step k + 1 (they never read a massless body) into the other copy of the tables and of the record: one launch
+        // per step after the first.
+        const bool chain = ctx->carried_steps && view->n > K;
         for (int64_t k = 0; k < nsteps; k++) {
             const double h = k + 1 < nsteps ? dt : 0.5 * dt;
-            StepArgs sa = {h, dt, ctx->star + 16 * (int)(k & 1), EPI_WH, 0., 0., 0., {nullptr, nullptr, nullptr}, nullptr, k == 0 ? lead : nullptr, 0.5 * dt, {}};
+            const int cur = chain ? (int)(k & 1) : 0, nxt = cur ^ 1;
+            ctx->hc_stage = cur;
+            StepArgs sa = {h, dt, ctx->star + 16 * cur, EPI_WH, 0., 0., 0., {nullptr, nullptr, nullptr}, nullptr, k == 0 ? lead : nullptr, 0.5 * dt, {}};
             sa.wh_head = (int)K;
+            sa.jac = ctx->whead;
+            if (chain && k + 1 < nsteps) { sa.next_hc = ctx->hc + nxt; sa.next_star = ctx->star + 16 * nxt; sa.next_h = k + 2 < nsteps ? dt : 0.5 * dt; }
+            sa.head_ready = (chain && k > 0) ? 1 : 0;
             rc = run_streaming(ctx, view, ops, 0, nops, mode, st, -1, nullptr, false, &sa);
             if (rc == STEP_NOT_CARRIED) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_steps: the force stack cannot ride in one pass over this layout");
             if (rc != REBXAMD_OK) return rc;

@@ -108,7 +108,8 @@ struct StepArgs { double h, dtk; const double* star; int epi; double c0, c1, c2;
                   // EPI_WH behind a head of several massive bodies (star + planets): `star` and `star0` then describe the head's
                   // centre of mass instead of body 0 -- the origin of every massless body's Jacobi coordinates -- and the pass adds
                   // the pull of the head bodies (the tables' list of massive bodies) and the Jacobi term G M q/|q|^3 of the kick
-                  int wh_head; };
+                  int wh_head;
+                  double* jac; };                      // wh_head > 1 with the next step's head pass chained in: the head's Jacobi state between steps
 
 enum { WARN_GR_ITER = 1u, WARN_GRFULL_SWEEPS = 2u, WARN_IM_ITER = 4u };
 

@@ -23,6 +23,7 @@
 #include "kepler.h"
 #include "updates.h"
 #include "wave_ops.h"
+#include "wh_head.h"
 
 namespace rebxamd {
 
@@ -151,10 +152,10 @@ struct HeadShared {
 // pass records body 0 for the stepping pass that follows -- star[0..5] its state, star[9..11] its
 // acceleration (the column is cleared), star[12] its mass parameter G*m_0 -- drifts it linearly
 // over h and records the new position in star[6..8].
+// (a device function of one wavefront, t = lane: the kernel below calls it, and so does the extra workgroup of a stepping pass
+// behind a head of several massive bodies, which runs the head pass of the next step)
 template <bool EXACT>
-__global__ __launch_bounds__(64) void head_kernel(View v, Program prog, HeadConsts* hc, unsigned* status, double* star, double h) {
-    __shared__ HeadShared sh;
-    const int t = threadIdx.x;
+__device__ __forceinline__ void head_body(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, double* star, double h, HeadShared& sh, const int t) {
     const int K = (int)(v.n_head < v.n ? v.n_head : v.n);
     const bool valid = t < K;
     const double G = prog.G;
@@ -360,6 +361,11 @@ __global__ __launch_bounds__(64) void head_kernel(View v, Program prog, HeadCons
         return;
     }
     if (valid) { v.ax[t] = acc.x; v.ay[t] = acc.y; v.az[t] = acc.z; }
+}
+template <bool EXACT>
+__global__ __launch_bounds__(64) void head_kernel(View v, Program prog, HeadConsts* hc, unsigned* status, double* star, double h) {
+    __shared__ HeadShared sh;
+    head_body<EXACT>(v, prog, hc, status, star, h, sh, threadIdx.x);
 }
 
 // The head pass when the head is ONE body (a star in front of massless bodies) and no op works in
@@ -686,8 +692,21 @@ __global__ __launch_bounds__(BLOCK, (BACKREACT && SIG == 0ull) ? 2 : (!EXACT && 
     const bool chained = EPI == EPI_WH && step.next_hc != nullptr;
     if (chained && blockIdx.x == 0) {
         // the extra workgroup of a Wisdom-Holman pass: the head pass of the next step (it reads and
-        // writes body 0 and the other copy of the tables, which no workgroup of this pass touches).
+        // writes the head bodies and the other copy of the tables, which no workgroup of this pass touches).
         // It is the first workgroup, so that its latency hides behind the others.
+        if constexpr (EPI == EPI_WH) {
+            if (step.wh_head > 1) {
+                // star + planets: the general head pass (additional forces on the head bodies, tables), then the head's own
+                // step -- gravity among its bodies, Jacobi kick, drift to the force evaluation after the next -- by the same
+                // wavefront; the other wavefronts of the workgroup leave first, so its barriers count one wavefront
+                __shared__ HeadShared hsh;
+                __shared__ WhHeadShared wsh;
+                if (tid >= 64) return;
+                head_body<EXACT>(v, prog, step.next_hc, status, nullptr, 0., hsh, tid);
+                wh_head_step_body<EXACT>(v, step.wh_head, prog.G, step.dtk, step.next_h, step.jac, step.next_star, wsh, tid);
+                return;
+            }
+        }
         if (tid < 64) head_one_body(v, prog, step.next_hc, step.next_star, step.next_h, tid);
         return;
     }
