@@ -211,6 +211,31 @@ def test_steps_of_star_planets_and_dust_match_the_checker(ctx, n, n_planets, for
     assert float(np.abs(np.array(dp.acc_host())[:, :n_planets + 1]).max()) == 0.0
 
 
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("n,n_planets", [(20_011, 3), (9, 7), (2500, 1)])
+def test_head_step_riding_in_the_pass_changes_nothing(ctx, n, n_planets, mode):
+    """After the first step, the head pass and the head's own step of step k + 1 run in an extra workgroup of the pass
+    over the massless bodies of step k (they never read a massless body), into a second copy of the tables and of the
+    record.  Switched off, every step launches them ahead of its pass.  Same code, same inputs: the same bits."""
+    dt, steps = 0.05, 9
+    cols, pp, _ = synthetic.disk(n, n_planets)
+    host = dict(cols)
+    for k in ("beta", "R_tides", "k1", "tau_a", "tau_e", "tau_inc"):
+        host[k] = pp[k]
+    ops = build_ops(C5_STACK, pp)
+    out = []
+    for riding in (True, False):
+        dp = DeviceParticles.from_host(host, device="cuda:0", n_head=n_planets + 1, tail_massless=True)
+        try:
+            ctx.carried_steps(riding)
+            ctx.wh_steps(dp.view(), ops, dt, steps, mode)
+        finally:
+            ctx.carried_steps(True)
+        out.append(state_of(dp))
+    assert np.isfinite(out[0]).all()
+    assert np.array_equal(out[0], out[1])
+
+
 def test_star_and_planets_conserve_energy_and_momentum_over_a_long_run(ctx):
     """Independent of the checker: force-free, 2000 steps of star + 4 planets: total momentum to rounding (the centre of
     mass is never kicked), energy error bounded and oscillating as for any Wisdom-Holman map (< 1e-7 relative here, with
