@@ -196,8 +196,8 @@ double rebx_gr_full_hamiltonian(struct rebx_extras* const rebx, const struct reb
 
 /* Operators on the additional-force path: the "integrate a force across a timestep" operator and
  * the kick/drift steppers.  src/reboundx.h:331, :329, :327, :280; src/core.c:279-368, :411-510,
- * :637-648, :697-728.  rebx_load_operator knows "integrate_force", "kick", "drift", "modify_mass" and
- * "modify_orbits_direct"; the reference's other operators (track_min_distance, and kepler, jump,
+ * :637-648, :697-728.  rebx_load_operator knows "integrate_force", "kick", "drift", "modify_mass",
+ * "modify_orbits_direct" and "track_min_distance"; the reference's other operators (kepler, jump,
  * interaction, ias15, which wrap REBOUND internals) are not part of this library and report
  * "not found". */
 struct rebx_operator* rebx_create_operator(struct rebx_extras* const rebx, const char* name);
@@ -224,6 +224,13 @@ void rebx_drift_step(struct reb_simulation* const sim, struct rebx_operator* con
 void rebx_modify_mass(struct reb_simulation* const sim, struct rebx_operator* const op, const double dt);
 void rebx_modify_orbits_direct(struct reb_simulation* const sim, struct rebx_operator* const op, const double dt);
 void rebx_kick_step(struct reb_simulation* const sim, struct rebx_operator* const op, const double dt);
+/* src/track_min_distance.c:66-96 (a recorder: per-particle "min_distance", "min_distance_from", "min_distance_orbit").
+ * Leaves the state alone and touches only the particles that carry "min_distance": runs on the host, on the particle
+ * array the simulation holds.  "min_distance_from" names a particle by its hash; one that is not found is reported
+ * (the reference dereferences the NULL that reb_get_particle_by_hash returns).  "min_distance_orbit" is REBOUND's
+ * struct reb_orbit: it is filled when the library is built against REBOUND (REBXAMD_WITH_REBOUND) and left alone, with a
+ * warning, otherwise. */
+void rebx_track_min_distance(struct reb_simulation* const sim, struct rebx_operator* const op, const double dt);
 /* src/core.h:61, src/core.c:860-866 */
 void rebx_reset_accelerations(struct reb_particle* const ps, const int N);
 

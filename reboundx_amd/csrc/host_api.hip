@@ -1081,6 +1081,7 @@ extern "C" struct rebx_operator* rebx_load_operator(struct rebx_extras* const re
     if (strcmp(name, "integrate_force") == 0) op->step_function = rebx_integrate_force;
     else if (strcmp(name, "modify_mass") == 0) op->step_function = rebx_modify_mass;
     else if (strcmp(name, "modify_orbits_direct") == 0) op->step_function = rebx_modify_orbits_direct;
+    else if (strcmp(name, "track_min_distance") == 0) { op->step_function = rebx_track_min_distance; op->operator_type = REBX_OPERATOR_RECORDER; return op; }
     else if (strcmp(name, "drift") == 0) op->step_function = rebx_drift_step;
     else if (strcmp(name, "kick") == 0) op->step_function = rebx_kick_step;
     else {
@@ -1499,6 +1500,41 @@ extern "C" void rebx_modify_orbits_direct(struct reb_simulation* const sim, stru
         return;
     }
     state_back(rebx, b, sim->particles, N, false);
+}
+
+// reference src/track_min_distance.c:66-96.  Host code on the simulation's own particle array: a recorder reads a handful of
+// particles and changes none.
+extern "C" void rebx_track_min_distance(struct reb_simulation* const sim, struct rebx_operator* const, const double) {
+    struct rebx_extras* rebx = (struct rebx_extras*)sim->extras;
+    const int N = sim->N - sim->N_var;
+    if (!rebx) return;
+    for (int i = 0; i < N; i++) {
+        struct reb_particle* const p = &sim->particles[i];
+        if (!p->ap) continue;
+        double* const min_distance = (double*)rebx_get_param(rebx, (struct rebx_node*)p->ap, "min_distance");
+        if (!min_distance) continue;
+        const uint32_t* const target = (const uint32_t*)rebx_get_param(rebx, (struct rebx_node*)p->ap, "min_distance_from");
+        const struct reb_particle* source = &sim->particles[0];
+        if (target) {
+            source = nullptr;
+            for (int j = 0; j < sim->N && !source; j++)
+                if (sim->particles[j].hash == *target) source = &sim->particles[j];
+            if (!source) { reb_error(sim, "REBOUNDx Error: min_distance_from names a particle hash that is not in the simulation.\n"); continue; }
+        }
+        const double dx = p->x - source->x, dy = p->y - source->y, dz = p->z - source->z;
+        const double r2 = dx * dx + dy * dy + dz * dz;
+        if (r2 < *min_distance * (*min_distance)) {
+            *min_distance = sqrt(r2);
+            void* const orbit = rebx_get_param(rebx, (struct rebx_node*)p->ap, "min_distance_orbit");
+            if (orbit) {
+#ifdef REBXAMD_WITH_REBOUND
+                *(struct reb_orbit*)orbit = reb_tools_particle_to_orbit(sim->G, *p, *source);
+#else
+                reb_warning(sim, "REBOUNDx (MI355X): min_distance_orbit is REBOUND's struct reb_orbit and is recorded only by a library built against REBOUND; min_distance was updated.");
+#endif
+            }
+        }
+    }
 }
 
 extern "C" double rebx_gr_full_hamiltonian(struct rebx_extras* const rebx, const struct rebx_force* const force) {      // src/gr_full.c:251-377

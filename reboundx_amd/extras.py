@@ -545,7 +545,7 @@ PLUGIN_API_SYMBOLS = (
     "rebx_create_operator", "rebx_load_operator", "rebx_add_operator", "rebx_add_operator_step", "rebx_remove_operator",
     "rebx_get_operator", "rebx_pre_timestep_modifications", "rebx_post_timestep_modifications", "rebx_integrate_force",
     "rebx_output_binary", "rebx_init_extras_from_binary", "rebx_create_extras_from_binary",
-    "rebx_drift_step", "rebx_kick_step", "rebx_modify_mass", "rebx_modify_orbits_direct", "rebx_gravitational_harmonics_potential", "rebx_central_force_potential",
+    "rebx_drift_step", "rebx_kick_step", "rebx_modify_mass", "rebx_modify_orbits_direct", "rebx_track_min_distance", "rebx_gravitational_harmonics_potential", "rebx_central_force_potential",
     "rebx_tides_precession_potential", "rebx_gr_potential_potential", "rebx_gr_hamiltonian", "rebx_gr_full_hamiltonian",
     "rebx_attach", "rebx_detach", "rebx_extras_cleanup", "rebx_free", "rebx_initialize", "rebx_register_default_params",
     "rebx_free_pointers", "rebx_free_particle_ap", "rebx_create_force", "rebx_load_force", "rebx_add_force", "rebx_remove_force",

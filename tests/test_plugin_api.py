@@ -233,8 +233,8 @@ def test_operator_factory_and_step_lists():
     sim.add(m=1e-3, x=1., vy=1.)
     sim.dt = 0.5
     rebx = Extras(sim)
-    with pytest.raises(RuntimeError, match="Operator 'track_min_distance' not found"):
-        rebx.load_operator("track_min_distance")
+    with pytest.raises(RuntimeError, match="Operator 'kepler' not found"):
+        rebx.load_operator("kepler")
     assert lib.rebx_len(rebx._allocated_operators) == 0
     drift = rebx.load_operator("drift")
     assert isinstance(drift, Operator) and drift.name == b"drift" and drift.operator_type == 1
@@ -259,6 +259,45 @@ def test_operator_factory_and_step_lists():
     assert lib.rebx_len(rebx2._pre_timestep_modifications) == 0 and lib.rebx_len(rebx2._post_timestep_modifications) == 1
     rebx2.add_operator(kick, dtfraction=0.25, timing="pre")
     assert lib.rebx_len(rebx2._pre_timestep_modifications) == 1
+
+
+def test_track_min_distance_records_the_closest_approach():
+    """src/track_min_distance.c:66-96: a recorder (one whole step after the timestep, core.c:474-479) that lowers a
+    particle's "min_distance" to its distance from particle 0, or from the particle whose hash "min_distance_from" holds,
+    whenever that is smaller, and never raises it."""
+    sim = Simulation(integrator="whfast")
+    sim.add(m=1.)
+    sim.add(m=1e-3, x=3., y=4.)
+    sim.add(m=1e-3, x=3., y=4., z=12.)
+    sim.particles[2].hash = 777
+    rebx = Extras(sim)
+    op = rebx.load_operator("track_min_distance")
+    assert op.operator_type == 2                                  # REBX_OPERATOR_RECORDER
+    rebx.add_operator(op)
+    assert lib.rebx_len(rebx._pre_timestep_modifications) == 0 and lib.rebx_len(rebx._post_timestep_modifications) == 1
+    ps = sim.particles
+    ps[1].params["min_distance"] = 100.
+    sim.post_timestep_modifications(ctypes.byref(sim))
+    sim.process_messages()
+    assert ps[1].params["min_distance"] == 5.0                   # from particle 0
+    ps[1].x = 6.; ps[1].y = 8.
+    sim.post_timestep_modifications(ctypes.byref(sim))
+    assert ps[1].params["min_distance"] == 5.0                   # further away: kept
+    ps[1].x = 0.3; ps[1].y = 0.4
+    sim.post_timestep_modifications(ctypes.byref(sim))
+    assert ps[1].params["min_distance"] == 0.5
+    ps[1].params["min_distance"] = 100.
+    ps[1].params["min_distance_from"] = 777
+    sim.post_timestep_modifications(ctypes.byref(sim))
+    want = ((3. - .3) ** 2 + (4. - .4) ** 2 + 144.) ** 0.5
+    assert ps[1].params["min_distance"] == pytest.approx(want, rel=1e-15)
+    ps[1].params["min_distance_from"] = 12345                   # nobody carries that hash
+    ps[1].params["min_distance"] = 100.
+    sim.post_timestep_modifications(ctypes.byref(sim))
+    with pytest.raises(RuntimeError, match="not in the simulation"):
+        sim.process_messages()
+    assert ps[1].params["min_distance"] == 100.
+    sim.free_particle_params()
 
 
 def test_custom_operator_needs_type_and_step_function():
