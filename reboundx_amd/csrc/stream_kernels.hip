@@ -1084,6 +1084,7 @@ static void launch_stream_cols(dim3 g, dim3 b, hipStream_t st, bool vec2, bool f
 #define EPILOGUE(E) \
     { FIXED_EPI(E, REBXAMD_OP_RADIATION, REBXAMD_OP_J2, REBXAMD_OP_J4, REBXAMD_OP_GR) \
       FIXED_EPI(E, REBXAMD_OP_RADIATION, REBXAMD_OP_J2, REBXAMD_OP_J4, REBXAMD_OP_GR_POTENTIAL, REBXAMD_OP_TIDES, REBXAMD_OP_MOF) \
+      FIXED_EPI(E, REBXAMD_OP_RADIATION) \
       if (vec2) hipLaunchKernelGGL((stream_kernel<EXACT, false, true, COL_ALL, 0ull, E>), g, b, 0, st, v, prog, lo, base, hc, partials, status, sa); \
       else hipLaunchKernelGGL((stream_kernel<EXACT, false, false, COL_ALL, 0ull, E>), g, b, 0, st, v, prog, lo, base, hc, partials, status, sa); \
       return; }
