@@ -462,7 +462,13 @@ int rebxamd_reset_accelerations(rebxamd_ctx* ctx, const rebxamd_view* view, void
  * drift dt/2 }, with the two half drifts between consecutive steps merged into one Kepler drift of
  * dt (the state is synchronised when the call returns, not in between).  Positions and velocities
  * are updated in place.  The acceleration columns are scratch: on return body 0's is zero and the others'
- * are either untouched (the forces never left registers) or zero.  Asynchronous (G*m0 is formed on the device). */
+ * are either untouched (the forces never left registers) or zero.  Asynchronous (G*m0 is formed on the device).
+ * rebxamd_wh_steps also takes a head of several massive bodies (star + planets: 2 <= view->n_head <= 64,
+ * view->tail_massless = 1): the head then steps in Jacobi coordinates as REBOUND's WHFast does with its defaults
+ * (Rein & Tamayo 2015: body i on a Kepler orbit about G*(m_0 + ... + m_i), the centre of mass drifting linearly,
+ * direct gravity among the head bodies without the pair (0,1), Jacobi term on bodies i >= 2), and every massless body
+ * about the head's centre of mass, pulled by every head body.  The force stack must then be one streaming run (no
+ * gr_full, at most one gr and one Jacobi/barycentric modify_orbits_forces) whose sources are head bodies. */
 int rebxamd_wh_drift(rebxamd_ctx* ctx, const rebxamd_view* view, double dt, int mode, void* stream);
 int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, double dt, int64_t nsteps,
                      int mode, void* stream);
