@@ -245,6 +245,10 @@ void rebx_tides_precession(struct reb_simulation* const sim, struct rebx_force* 
 void rebx_central_force(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N);
 void rebx_gravitational_harmonics(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N);
 
+/* src/core.h:74.  Not implemented (src/ephemeris_forces.c needs the JPL ephemeris files): reports through the
+ * simulation's message channel and leaves the accelerations alone; rebx_load_force does not know the name. */
+void rebx_ephemeris_forces(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N);
+
 /* src/reboundx.h:436,448, src/radiation_forces.c:119-124 */
 double rebx_rad_calc_beta(const double G, const double c, const double source_mass, const double source_luminosity, const double radius, const double density, const double Q_pr);
 double rebx_rad_calc_particle_radius(const double G, const double c, const double source_mass, const double source_luminosity, const double beta, const double density, const double Q_pr);

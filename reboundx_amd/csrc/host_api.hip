@@ -1502,6 +1502,12 @@ extern "C" void rebx_modify_orbits_direct(struct reb_simulation* const sim, stru
     state_back(rebx, b, sim->particles, N, false);
 }
 
+// reference src/core.h:74, src/ephemeris_forces.c: needs the JPL ephemeris readers and their data files, which are not on this
+// path.  Exported so that bindings which resolve every force callback by name still load; it reports and changes nothing.
+extern "C" void rebx_ephemeris_forces(struct reb_simulation* const sim, struct rebx_force* const, struct reb_particle* const, const int) {
+    reb_error(sim, "REBOUNDx (MI355X) Error: ephemeris_forces is not part of this library (it needs the JPL ephemeris files). Accelerations were not updated.\n");
+}
+
 // reference src/track_min_distance.c:66-96.  Host code on the simulation's own particle array: a recorder reads a handful of
 // particles and changes none.
 extern "C" void rebx_track_min_distance(struct reb_simulation* const sim, struct rebx_operator* const, const double) {

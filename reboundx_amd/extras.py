@@ -553,7 +553,7 @@ PLUGIN_API_SYMBOLS = (
     "rebx_set_param_int", "rebx_set_param_uint32", "rebx_register_param", "rebx_get_type", "rebx_len", "rebx_error",
     "rebx_additional_forces", "rebx_reset_accelerations", "rebx_gr", "rebx_gr_full", "rebx_gr_potential",
     "rebx_radiation_forces", "rebx_modify_orbits_forces", "rebx_tides_precession", "rebx_central_force",
-    "rebx_gravitational_harmonics", "rebx_rad_calc_beta", "rebx_rad_calc_particle_radius",
+    "rebx_gravitational_harmonics", "rebx_ephemeris_forces", "rebx_rad_calc_beta", "rebx_rad_calc_particle_radius",
     "rebxamd_invalidate_params", "rebxamd_set_mode", "rebxamd_last_timings", "rebxamd_set_param_column", "rebxamd_get_param_column",
     "rebx_build_str", "rebx_version_str", "rebx_githash_str",
 )
