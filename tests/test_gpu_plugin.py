@@ -510,6 +510,41 @@ def test_gr_and_jacobi_drag_with_massive_bodies_anywhere_through_the_hook():
     sim.free_particle_params()
 
 
+def test_parameter_columns_feed_the_operators_too():
+    """tau_mass (modify_mass) and tau_a / tau_e / tau_omega (modify_orbits_direct) given as columns: the operators' step
+    functions must do what they do with the same values in the particles' lists."""
+    n = 3000
+    cols, pp, _ = synthetic.disk(n, 2)
+    rng = np.random.default_rng(4)
+    tau_mass = np.where(rng.random(n) < 0.5, -1e3 * (1 + rng.random(n)), np.nan)
+    tau_omega = np.where(rng.random(n) < 0.3, 100. * (1 + rng.random(n)), np.nan)
+    given = {"tau_mass": tau_mass, "tau_a": pp["tau_a"], "tau_e": pp["tau_e"], "tau_omega": tau_omega}
+    states = []
+    for how in ("lists", "columns"):
+        sim, arr, view = big_array_sim(cols)
+        sim.integrator = 1
+        sim.dt = 0.1
+        rebx = Extras(sim)
+        mm = rebx.load_operator("modify_mass")
+        mod = rebx.load_operator("modify_orbits_direct")
+        if how == "columns":
+            for k, v in given.items():
+                assert rebx.set_param_column(k, v)
+        else:
+            for k, v in given.items():
+                key = k.encode("ascii")
+                for i in np.nonzero(~np.isnan(v))[0]:
+                    lib.rebx_set_param_double(ctypes.byref(rebx), ctypes.byref(ctypes.c_void_p.from_buffer(arr[i], Particle.ap.offset)), key, float(v[i]))
+        mm.step(sim, 0.05)
+        mod.step(sim, 0.05)
+        sim.process_messages()
+        states.append(view[:, [0, 1, 2, 3, 4, 5, 9]].copy())
+        sim.free_particle_params()
+    start = np.array([cols[k] for k in ("x", "y", "z", "vx", "vy", "vz", "m")]).T
+    assert np.abs(states[0] - start).max() > 1e-7
+    assert np.array_equal(states[0].view(np.uint64), states[1].view(np.uint64))
+
+
 @pytest.mark.parametrize("integrator", ["euler", "rk2", "rk4", "implicit_midpoint"])
 def test_integrate_force_operator_with_a_builtin_force_runs_on_the_device(integrator):
     """The reference's IntegrateForce setup (ipython_examples/IntegrateForce.ipynb: a
