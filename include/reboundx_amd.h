@@ -272,7 +272,8 @@ void rebxamd_invalidate_params(struct rebx_extras* rebx);
  * values == NULL or N == 0 removes the column.  The linked lists stay authoritative: where a particle's
  * own list holds `name` (rebx_set_param_double), that value is used and the column's entry ignored.
  * The column is seen by this library's effects and operators only: rebx_get_param on a particle does
- * not find it (there is no list node), and rebx_output_binary does not save it.  Indices follow the
+ * not find it (there is no list node).  rebx_output_binary writes its entries as ordinary parameters of the
+ * particles, so a file that is read back (by this library or by the reference) holds them in the lists.  Indices follow the
  * particle array at the time of each call; after removing or reordering particles set the column again.
  * Returns 1, or 0 after reporting through the simulation's message channel (unknown or unregistered
  * name, negative N). */

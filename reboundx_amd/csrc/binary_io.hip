@@ -67,8 +67,39 @@ template <class Fn> void for_each_oldest_first(struct rebx_node* head, Fn fn) {
     for (size_t k = nodes.size(); k-- > 0;) fn(nodes[k]->object);
 }
 
-void write_param_list(Writer& w, struct rebx_node* ap) {
+// Per-particle double parameters that were given as whole columns (rebxamd_set_param_column) have no list node; a file
+// holds them as what they stand for, a parameter of the particle, so that the reference (and this library) reads them back
+// as list entries.
+struct ColumnEntries {
+    static constexpr int NCOL = 9;
+    const char* name[NCOL] = {"beta", "R_tides", "k1", "tau_a", "tau_e", "tau_inc", "tau_mass", "tau_omega", "tau_Omega"};
+    const double* col[NCOL] = {};
+    int len[NCOL] = {};
+    bool any = false;
+    explicit ColumnEntries(struct rebx_extras* rebx) {
+        for (int k = 0; k < NCOL; k++) {
+            col[k] = rebxamd_get_param_column(rebx, name[k], &len[k]);
+            any = any || col[k] != nullptr;
+        }
+    }
+};
+
+void write_param_list(Writer& w, struct rebx_extras* rebx, struct rebx_node* ap, const ColumnEntries* columns = nullptr, int particle = -1) {
     const size_t list = w.open(F_PARAM_LIST);
+    if (columns != nullptr && columns->any) {
+        // (written first = oldest: entries of the particle's own list end up in front of them when the file is read)
+        for (int k = 0; k < ColumnEntries::NCOL; k++) {
+            if (!columns->col[k] || particle >= columns->len[k]) continue;
+            const double value = columns->col[k][particle];
+            if (value != value || rebx_get_param(rebx, ap, columns->name[k]) != NULL) continue;     // not set here / the list's own entry wins
+            const enum rebx_param_type type = REBX_TYPE_DOUBLE;
+            const size_t rec = w.open(F_PARAM);
+            w.record(F_PARAM_TYPE, &type, sizeof(type));
+            w.text(F_NAME, columns->name[k]);
+            w.record(F_PARAM_VALUE, &value, sizeof(value));
+            w.close(rec);
+        }
+    }
     for_each_oldest_first(ap, [&](void* obj) {
         const struct rebx_param* p = (const struct rebx_param*)obj;
         if (p->type == REBX_TYPE_POINTER) return;        // cannot be restored (output.c:120-122)
@@ -82,10 +113,10 @@ void write_param_list(Writer& w, struct rebx_node* ap) {
     w.close(list);
 }
 
-void write_named_with_params(Writer& w, int32_t type, const char* name, struct rebx_node* ap) {
+void write_named_with_params(Writer& w, struct rebx_extras* rebx, int32_t type, const char* name, struct rebx_node* ap) {
     const size_t rec = w.open(type);
     w.text(F_NAME, name);
-    write_param_list(w, ap);
+    write_param_list(w, rebx, ap);
     w.close(rec);
 }
 
@@ -381,12 +412,12 @@ extern "C" void rebx_output_binary(struct rebx_extras* rebx, char* filename) {  
     }
     {
         const size_t list = w.open(F_ALLOCATED_FORCES);
-        for_each_oldest_first(rebx->allocated_forces, [&](void* obj) { const struct rebx_force* f = (const struct rebx_force*)obj; write_named_with_params(w, F_FORCE, f->name, f->ap); });
+        for_each_oldest_first(rebx->allocated_forces, [&](void* obj) { const struct rebx_force* f = (const struct rebx_force*)obj; write_named_with_params(w, rebx, F_FORCE, f->name, f->ap); });
         w.close(list);
     }
     {
         const size_t list = w.open(F_ALLOCATED_OPERATORS);
-        for_each_oldest_first(rebx->allocated_operators, [&](void* obj) { const struct rebx_operator* o = (const struct rebx_operator*)obj; write_named_with_params(w, F_OPERATOR, o->name, o->ap); });
+        for_each_oldest_first(rebx->allocated_operators, [&](void* obj) { const struct rebx_operator* o = (const struct rebx_operator*)obj; write_named_with_params(w, rebx, F_OPERATOR, o->name, o->ap); });
         w.close(list);
     }
     {
@@ -404,11 +435,12 @@ extern "C" void rebx_output_binary(struct rebx_extras* rebx, char* filename) {  
     {
         const size_t list = w.open(F_PARTICLES);
         struct reb_simulation* sim = rebx->sim;
+        const ColumnEntries columns(rebx);
         for (int i = 0; i < sim->N; i++) {
             const size_t rec = w.open(F_PARTICLE);
             const int32_t index = i;
             w.record(F_PARTICLE_INDEX, &index, sizeof(index));
-            write_param_list(w, (struct rebx_node*)sim->particles[i].ap);
+            write_param_list(w, rebx, (struct rebx_node*)sim->particles[i].ap, &columns, i);
             w.close(rec);
         }
         w.close(list);

@@ -157,3 +157,29 @@ def test_round_trip_of_forces_operators_steps_and_every_value_type(tmp_path):
     assert open(path, "rb").read() == open(again, "rb").read()
     sim.free_particle_params()
     sim2.free_particle_params()
+
+
+def test_parameter_columns_are_saved_as_the_particle_parameters_they_stand_for(tmp_path):
+    """A per-particle parameter given as a whole column (rebxamd_set_param_column) has no list node; the file stores its
+    entries as ordinary parameters of the particles (output.c:209-256 layout), so whoever reads the file -- this library or
+    the reference -- finds them in the particles' lists.  Unset entries are not written; a list entry of the same name wins."""
+    import numpy as np
+    sim = three_body()
+    rebx = Extras(sim)
+    rebx.add_force(rebx.load_force("modify_orbits_forces"))
+    assert rebx.set_param_column("tau_a", np.array([np.nan, -1e4, -2e4]))
+    assert rebx.set_param_column("beta", np.array([np.nan, np.nan, 0.25]))
+    sim.particles[2].params["tau_a"] = -7e4                           # the list's own entry wins over the column's
+    sim.particles[1].params["tau_e"] = -1e3
+    path = str(tmp_path / "columns.rebx")
+    rebx.save(path)
+
+    sim2 = three_body()
+    rebx2 = Extras(sim2, path)
+    assert rebx2.get_param_column("tau_a") is None                   # they come back as list entries
+    ps = sim2.particles
+    assert len(ps[0].params) == 0
+    assert ps[1].params["tau_a"] == -1e4 and ps[1].params["tau_e"] == -1e3 and len(ps[1].params) == 2
+    assert ps[2].params["tau_a"] == -7e4 and ps[2].params["beta"] == 0.25 and len(ps[2].params) == 2
+    sim.free_particle_params()
+    sim2.free_particle_params()
