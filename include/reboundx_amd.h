@@ -624,6 +624,17 @@ int rebxamd_grfull_sweep0_finish(rebxamd_ctx* ctx, const rebxamd_view* view, dou
                                  const double* aox, const double* aoy, const double* aoz,
                                  const double* acx, const double* acy, const double* acz,
                                  double* outx, double* outy, double* outz, uint32_t* dev_flag, int mode, void* stream);
+/* The per-sweep exchange of a row-sharded driver in two small kernels around its all-gather (no counterpart in the reference).
+ * rebxamd_grfull_pack: send <- [ outx rows | outy rows | outz rows | vote ] of rows [row0, row0 + per) (rows >= n travel as
+ * zeros), 3*per + 1 doubles; the vote is dev_flag (as raised by the sweep), which is cleared for the next sweep.
+ * rebxamd_grfull_unpack: recv = `world` such messages in rank order -> every rank's rows into the full columns
+ * (world*per doubles each); *stop_dev is set once no rank's rows fail the stopping rule (the word handed to
+ * rebxamd_grfull_stop_word: sweeps queued behind it then return at once); *vote_dev <- 1 while some rank's do.  With
+ * recv == NULL (all rows on this device) only the vote is handled, taken from dev_flag. */
+int rebxamd_grfull_pack(rebxamd_ctx* ctx, const double* outx, const double* outy, const double* outz, int64_t row0, int64_t per, int64_t n,
+                        uint32_t* dev_flag, double* send, void* stream);
+int rebxamd_grfull_unpack(rebxamd_ctx* ctx, const double* recv, int world, int64_t per, double* outx, double* outy, double* outz,
+                          uint32_t* dev_flag, uint32_t* stop_dev, int32_t* vote_dev, void* stream);
 /* Lets a driver queue sweeps ahead of the host (no counterpart in the reference): while stop_dev != NULL,
  * the kernels of every rebxamd_grfull_sweep call on this context return at once, writing nothing, when the
  * device word *stop_dev is non-zero at the time they run.  NULL (default) switches this off. */

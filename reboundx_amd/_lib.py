@@ -82,6 +82,8 @@ _sig = {
     "rebxamd_grfull_sweep": (c_int, [c_void_p, POINTER(View), c_double, c_int64, c_int64] + [c_void_p] * 13 + [c_int, c_void_p]),
     "rebxamd_grfull_pot_sweep0": (c_int, [c_void_p, POINTER(View), c_double, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "rebxamd_grfull_sweep0_finish": (c_int, [c_void_p, POINTER(View), c_double, c_int64, c_int64] + [c_void_p] * 13 + [c_int, c_void_p]),
+    "rebxamd_grfull_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "rebxamd_grfull_unpack": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rebxamd_grfull_stop_word": (c_int, [c_void_p, c_void_p]),
     "rebxamd_grfull": (c_int, [c_void_p, POINTER(View), c_double, c_int, c_int, POINTER(c_int), c_void_p]),
 }

@@ -1322,6 +1322,25 @@ extern "C" int rebxamd_grfull_sweep0_finish(rebxamd_ctx* ctx, const rebxamd_view
     return REBXAMD_OK;
 }
 
+// The exchange of a row-sharded sweep in two small kernels around the driver's all-gather (see grfull_kernels.hip).
+extern "C" int rebxamd_grfull_pack(rebxamd_ctx* ctx, const double* outx, const double* outy, const double* outz, int64_t row0, int64_t per, int64_t n,
+                                   uint32_t* dev_flag, double* send, void* stream) {
+    if (!ctx) return REBXAMD_ERR_ARG;
+    if (!outx || !outy || !outz || !dev_flag || !send || row0 < 0 || per < 0 || n < 0) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_grfull_pack: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(launch_grfull_pack(outx, outy, outz, row0, per, n, dev_flag, send, (hipStream_t)stream));
+    return REBXAMD_OK;
+}
+extern "C" int rebxamd_grfull_unpack(rebxamd_ctx* ctx, const double* recv, int world, int64_t per, double* outx, double* outy, double* outz,
+                                     uint32_t* dev_flag, uint32_t* stop_dev, int32_t* vote_dev, void* stream) {
+    if (!ctx) return REBXAMD_ERR_ARG;
+    if (!stop_dev || !vote_dev || (recv ? (world < 1 || per < 1 || !outx || !outy || !outz) : !dev_flag))
+        return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_grfull_unpack: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(launch_grfull_unpack(recv, world, per, outx, outy, outz, dev_flag, stop_dev, vote_dev, (hipStream_t)stream));
+    return REBXAMD_OK;
+}
+
 extern "C" int rebxamd_grfull_stop_word(rebxamd_ctx* ctx, const uint32_t* stop_dev) {
     if (!ctx) return REBXAMD_ERR_ARG;
     ctx->gf_stop = stop_dev;

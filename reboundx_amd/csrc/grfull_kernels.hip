@@ -648,6 +648,48 @@ hipError_t launch_grfull_prepare(const View& v, double G, int gravity_ignore_10,
     return hipGetLastError();
 }
 
+// ---- the exchange of a row-sharded sweep (one process per GPU): every rank sends its rows of the new iterate and its vote in
+// ONE message, [x rows | y rows | z rows | vote], `per` rows each (rows behind n are padding and travel as zeros).
+__global__ __launch_bounds__(256) void grfull_pack_kernel(const double* ox, const double* oy, const double* oz, long long row0, long long per, long long n,
+                                                          unsigned* flag, double* send) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < per) {
+        const long long r = row0 + i;
+        const bool in = r < n;
+        send[i] = in ? ox[r] : 0.; send[per + i] = in ? oy[r] : 0.; send[2 * per + i] = in ? oz[r] : 0.;
+    }
+    if (i == 0) { send[3 * per] = *flag ? 1. : 0.; *flag = 0u; }        // (the flag is ready for the next sweep)
+}
+// recv: `world` such messages in rank order.  Puts every rank's rows in their place in the full columns, and turns the votes into
+// the stop word of the queued sweeps: set (for good) once no rank's rows fail the stopping rule.  vote_out <- 1 if some rank's do.
+// recv == nullptr (all rows on this device): only the vote, taken from `flag`, which is cleared.
+__global__ __launch_bounds__(256) void grfull_unpack_kernel(const double* recv, int world, long long per, long long npad, double* ox, double* oy, double* oz,
+                                                            unsigned* flag, unsigned* stop, int* vote_out) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (recv != nullptr && idx < npad) {
+        const long long r = idx / per, i = idx - r * per;
+        const double* msg = recv + r * (3 * per + 1);
+        ox[idx] = msg[i]; oy[idx] = msg[per + i]; oz[idx] = msg[2 * per + i];
+    }
+    if (idx == 0) {
+        bool any = false;
+        if (recv != nullptr) { for (int r = 0; r < world; r++) any = any || recv[(long long)r * (3 * per + 1) + 3 * per] != 0.; }
+        else { any = *flag != 0u; *flag = 0u; }
+        if (!any) *stop = 1u;
+        *vote_out = any ? 1 : 0;
+    }
+}
+hipError_t launch_grfull_pack(const double* ox, const double* oy, const double* oz, long long row0, long long per, long long n, unsigned* flag, double* send, hipStream_t st) {
+    const long long nb = per > 0 ? (per + 255) / 256 : 1;
+    hipLaunchKernelGGL(grfull_pack_kernel, dim3((unsigned)nb), dim3(256), 0, st, ox, oy, oz, row0, per, n, flag, send);
+    return hipGetLastError();
+}
+hipError_t launch_grfull_unpack(const double* recv, int world, long long per, double* ox, double* oy, double* oz, unsigned* flag, unsigned* stop, int* vote_out, hipStream_t st) {
+    const long long npad = recv ? per * world : 1;
+    hipLaunchKernelGGL(grfull_unpack_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, st, recv, world, per, npad, ox, oy, oz, flag, stop, vote_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_grfull_vote(unsigned* ctl, hipStream_t st) {
     hipLaunchKernelGGL(grfull_vote_kernel, dim3(1), dim3(64), 0, st, ctl);
     return hipGetLastError();

@@ -203,6 +203,8 @@ hipError_t launch_grfull_sweep0_pot(const View& v, double G, double c, long long
 hipError_t launch_grfull_sweep0_pot_combine(bool sweep, const View& v, long long row0, long long row1, const double* part4,
                                             const double* acx, const double* acy, const double* acz, const double* aox, const double* aoy, const double* aoz,
                                             double* o0, double* o1, double* o2, unsigned* flag, hipStream_t st);
+hipError_t launch_grfull_pack(const double* ox, const double* oy, const double* oz, long long row0, long long per, long long n, unsigned* flag, double* send, hipStream_t st);
+hipError_t launch_grfull_unpack(const double* recv, int world, long long per, double* ox, double* oy, double* oz, unsigned* flag, unsigned* stop, int* vote_out, hipStream_t st);
 hipError_t launch_grfull_vote(unsigned* ctl, hipStream_t st);
 hipError_t launch_grfull_finish_select(const View& v, double* const b0[3], double* const b1[3], const unsigned* ctl, unsigned* status, hipStream_t st);
 size_t grfull_hamiltonian_doubles(long long n);

@@ -212,6 +212,14 @@ class Context:
         ptrs = [t.data_ptr() for t in (an[0], an[1], an[2], ao[0], ao[1], ao[2], ac[0], ac[1], ac[2], out[0], out[1], out[2])]
         self._check(lib.rebxamd_grfull_sweep0_finish(self._h, ctypes.byref(view), c, row0, row1, *ptrs, flag.data_ptr(), mode, self._stream()))
 
+    def grfull_pack(self, out, row0, per, n, flag, send):
+        self._check(lib.rebxamd_grfull_pack(self._h, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), row0, per, n, flag.data_ptr(), send.data_ptr(), self._stream()))
+
+    def grfull_unpack(self, recv, world, per, out, flag, stop, vote):
+        self._check(lib.rebxamd_grfull_unpack(self._h, recv.data_ptr() if recv is not None else None, world, per,
+                                              out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), flag.data_ptr() if flag is not None else None,
+                                              stop.data_ptr(), vote.data_ptr(), self._stream()))
+
     def grfull_sweep(self, view, c, row0, row1, an, ao, ac, out, flag, mode=_lib.MODE_FAST):
         ptrs = [t.data_ptr() for t in (an[0], an[1], an[2], ao[0], ao[1], ao[2], ac[0], ac[1], ac[2], out[0], out[1], out[2])]
         self._check(lib.rebxamd_grfull_sweep(self._h, ctypes.byref(view), c, row0, row1, *ptrs, flag.data_ptr(), mode, self._stream()))

@@ -222,6 +222,14 @@ class HipGrFullEngine:
     def finish(self, a):
         self.ctx.grfull_finish(self.view, a)
 
+    def pack(self, out, r0, per, flag, send):
+        """send <- this rank's rows of the new iterate and its vote (one message); the flag is cleared."""
+        self.ctx.grfull_pack(out, r0, per, self.n, flag, send)
+
+    def unpack(self, recv, world, per, out, flag, stop, vote):
+        """All ranks' messages -> the full columns; the votes -> the stop word and `vote` (recv None: the vote of `flag` alone)."""
+        self.ctx.grfull_unpack(recv, world, per, out, flag, stop, vote)
+
     def set_stop(self, word):
         """word: int32 device tensor; while set, sweeps queued behind a non-zero word return at once."""
         self.ctx.grfull_stop_word(word)
@@ -274,13 +282,23 @@ def grfull_sharded(engine, c, gravity_ignore_10=0, group=None):
     engine.const(c, r0, r1, pot, ac)
     bufs = [ao3, out3]                              # sweep k reads the iterate in bufs[k % 2] and writes bufs[(k + 1) % 2]
 
-    def one_sweep(k):
+    def one_sweep(k, stop=None, vote=None):
         """Queues sweep k and its exchange; returns the device tensor that is non-zero while any rank's rows fail
-        the stopping rule."""
+        the stopping rule.  stop, vote (engines with pack/unpack kernels): the exchange is two small kernels around the
+        all-gather, which also turn the votes into the stop word of the queued sweeps and into `vote`."""
         src, dst = bufs[k % 2], bufs[(k + 1) % 2]
-        flag.zero_()
+        if stop is None:
+            flag.zero_()
         run = engine.sweep0_finish if (k == 0 and shared_pass) else engine.sweep
         run(c, r0, r1, an, [src[0], src[1], src[2]], ac, [dst[0], dst[1], dst[2]], flag)
+        if stop is not None:
+            if use_dist:
+                engine.pack([dst[0], dst[1], dst[2]], r0, per, flag, send)
+                _all_gather_into(recv_flat, send, group)
+                engine.unpack(recv_flat, world, per, [dst[0], dst[1], dst[2]], None, stop, vote)
+            else:
+                engine.unpack(None, 1, per, [dst[0], dst[1], dst[2]], flag, stop, vote)
+            return vote
         if not use_dist:
             return flag
         send[:3 * per].view(3, per).copy_(dst.view(3, world, per)[:, rank, :])
@@ -294,16 +312,25 @@ def grfull_sharded(engine, c, gravity_ignore_10=0, group=None):
         # Sweeps are queued one ahead of the host: the vote of sweep k is turned into a stop word on the device
         # (the kernels of a sweep queued behind a set word return at once, writing nothing) and copied to pinned
         # memory without waiting; the host looks at the vote of sweep k - 1 after it has queued sweep k.
-        stop = engine.flag()
-        votes = torch.ones(10, dtype=torch.int32).pin_memory()
+        if "votes" not in ws:
+            ws["votes"], ws["stop"], ws["vote"] = torch.ones(10, dtype=torch.int32).pin_memory(), engine.flag(), engine.flag()
+        votes, stop, vote_dev = ws["votes"], ws["stop"], ws["vote"]
+        votes.fill_(1)
+        stop.zero_()
         events = []
+        fused = hasattr(engine, "unpack")
+        if fused:
+            flag.zero_()                            # (the exchange kernels clear it after every sweep)
         engine.set_stop(stop)
         try:
             for k in range(10):                     # reference loop bound (gr_full.c:173)
-                vote = one_sweep(k)
-                unconv = (vote != 0).to(torch.int32).reshape(1)
-                torch.maximum(stop, 1 - unconv, out=stop)
-                votes[k:k + 1].copy_(unconv, non_blocking=True)
+                if fused:
+                    votes[k:k + 1].copy_(one_sweep(k, stop, vote_dev), non_blocking=True)
+                else:
+                    vote = one_sweep(k)
+                    unconv = (vote != 0).to(torch.int32).reshape(1)
+                    torch.maximum(stop, 1 - unconv, out=stop)
+                    votes[k:k + 1].copy_(unconv, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
                 events.append(ev)
