@@ -123,6 +123,7 @@ struct Bridge {
     std::vector<SourceC> central;
     double timings[4] = {0, 0, 0, 0};
     std::vector<hipEvent_t> block_done;     // one per block of the download/unpack pipeline
+    size_t mass_synced = 0;                 // leading entries of the mass column that the device already holds
 };
 
 std::mutex g_mu;
@@ -159,6 +160,7 @@ void release_buffers(Bridge* b) {
     }
     b->cap = 0;
     b->built_n = -1;
+    b->mass_synced = 0;
 }
 
 void drop_bridge(const rebx_extras* rebx) {
@@ -181,12 +183,12 @@ double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// Host threads for the array-of-structs <-> column conversions (REBXAMD_HOST_THREADS, default 8,
-// at most 64).  Below ~100k particles one thread is faster than starting helpers.
+// Host threads for the array-of-structs <-> column conversions (REBXAMD_HOST_THREADS, default 16,
+// at most 64; never more than the machine has).  Below ~100k particles one thread is faster than starting helpers.
 int host_threads(int N) {
     static const int configured = [] {
         const char* e = getenv("REBXAMD_HOST_THREADS");
-        int t = e ? atoi(e) : 8;
+        int t = e ? atoi(e) : 16;
         const int hw = (int)std::thread::hardware_concurrency();
         if (hw > 0 && t > hw) t = hw;
         return t < 1 ? 1 : (t > 64 ? 64 : t);
@@ -849,9 +851,11 @@ bool ops_of_force(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* 
 
 // Host array-of-structs -> device columns: packs, re-flattens the parameter lists if they changed,
 // uploads.  On success `v` describes the device copy; t[0..2] = times at start, after packing,
-// after the upload.
+// after the upload.  A block of masses travels only when one of them differs from what the device
+// holds.  with_acc = false: the accelerations stay on the host and the device columns start from
+// zero (the caller adds what comes back), which saves their 24 bytes per particle on the way up.
 bool stage_in(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* b, const struct reb_particle* particles, const int N,
-              rebxamd_view& v, double t[3]) {
+              rebxamd_view& v, double t[3], const bool with_acc = true) {
     if (!ensure_capacity(rebx, b, (size_t)N)) return false;
     t[0] = now_ms();
     double* const* h = b->h_dyn;
@@ -869,31 +873,44 @@ bool stage_in(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* b, c
         const int nt = host_threads(b1 - b0);
         unsigned long long chunk_sum[64];
         long long chunk_last[64];
+        bool chunk_mass[64];
+        const size_t synced = b->mass_synced;
         parallel_chunks(b1 - b0, nt, [&](int lo, int hi, int k) {
             unsigned long long cs = 1469598103934665603ull;
             long long lm = -1;
+            bool moved = false;
             for (int i = b0 + lo; i < b0 + hi; i++) {
                 const struct reb_particle& p = particles[i];
-                h[H_X][i] = p.x; h[H_Y][i] = p.y; h[H_Z][i] = p.z;
-                h[H_VX][i] = p.vx; h[H_VY][i] = p.vy; h[H_VZ][i] = p.vz;
+                // (streaming stores: the staging columns are written once and read by the copy engine, not by this core)
+                __builtin_nontemporal_store(p.x, &h[H_X][i]); __builtin_nontemporal_store(p.y, &h[H_Y][i]); __builtin_nontemporal_store(p.z, &h[H_Z][i]);
+                __builtin_nontemporal_store(p.vx, &h[H_VX][i]); __builtin_nontemporal_store(p.vy, &h[H_VY][i]); __builtin_nontemporal_store(p.vz, &h[H_VZ][i]);
+                moved |= (size_t)i >= synced || bits_of(h[H_M][i]) != bits_of(p.m);
                 h[H_M][i] = p.m;
-                h[H_AX][i] = p.ax; h[H_AY][i] = p.ay; h[H_AZ][i] = p.az;
+                if (with_acc) { h[H_AX][i] = p.ax; h[H_AY][i] = p.ay; h[H_AZ][i] = p.az; }
                 if (p.m != 0.) lm = i;
                 cs = (cs ^ (unsigned long long)(uintptr_t)p.ap) * 1099511628211ull;
             }
-            chunk_sum[k] = cs; chunk_last[k] = lm;
+            chunk_sum[k] = cs; chunk_last[k] = lm; chunk_mass[k] = moved;
         });
         // fold of the per-chunk folds, in order: changes whenever any list head changes
         sum = (sum ^ (unsigned long long)nt) * 1099511628211ull;
+        bool mass_moved = false;
         for (int k = 0; k < nt; k++) {
             sum = (sum ^ chunk_sum[k]) * 1099511628211ull;
             if (chunk_last[k] > last_massive) last_massive = chunk_last[k];
+            mass_moved |= chunk_mass[k];
         }
         pack_ms += now_ms() - tp;
         if (small_system(b, N)) ok = hipMemcpyAsync(b->d_slab, b->h_slab, H_NDYN * b->cap * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess;
-        else for (int k = 0; k < H_NDYN && ok; k++)
+        else for (int k = 0; k < H_NDYN && ok; k++) {
+            if (k == H_M && !mass_moved) continue;
+            if (k >= H_AX && !with_acc) continue;
             ok = hipMemcpyAsync(b->d_dyn[k] + b0, b->h_dyn[k] + b0, (size_t)(b1 - b0) * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess;
+        }
     }
+    if (!with_acc && !small_system(b, N))
+        for (int k = H_AX; k <= H_AZ && ok; k++) ok = hipMemsetAsync(b->d_dyn[k], 0, (size_t)N * sizeof(double), st) == hipSuccess;
+    b->mass_synced = ok ? (size_t)N : 0;
     const bool rebuild = b->built_generation != b->generation || b->built_n != N || b->built_checksum != sum;
     const double tf = now_ms();
     bool changed[P_NPAR];
@@ -949,7 +966,14 @@ void run_builtin(struct reb_simulation* sim, struct rebx_extras* rebx, const std
     Bridge* b = bridge_of(rebx, true);
     rebxamd_view v;
     double t[3];
-    if (!stage_in(sim, rebx, b, particles, N, v, t)) return;
+    // Large systems in the fast arithmetic leave the accelerations on the host: the device sums the forces from zero
+    // and the sum is added here (one rounding of the total instead of one per force: below the fast mode's own bar).
+    // The exact arithmetic adds force after force onto the uploaded values, as the reference does.
+    // (gr_full reads the incoming accelerations -- src/gr_full.c:70-74 -- so a batch that holds it uploads them.)
+    bool reads_acc = false;
+    for (const Pending& pf : batch) reads_acc |= pf.force->update_accelerations == rebx_gr_full;
+    const bool delta = b->mode == REBXAMD_MODE_FAST && !reads_acc && !(N <= 16384 && b->cap <= 32768);
+    if (!stage_in(sim, rebx, b, particles, N, v, t, !delta)) return;
 
     // ---- ops (effect parameters are read on every call: they are a handful of list walks)
     std::vector<rebxamd_op> ops;
@@ -998,7 +1022,8 @@ void run_builtin(struct reb_simulation* sim, struct rebx_extras* rebx, const std
             ok = hipEventSynchronize(b->block_done[blk]) == hipSuccess;
             if (!ok) break;
             parallel_chunks(b1 - b0, host_threads(b1 - b0), [&](int lo, int hi, int) {
-                for (int i = b0 + lo; i < b0 + hi; i++) { particles[i].ax = h[H_AX][i]; particles[i].ay = h[H_AY][i]; particles[i].az = h[H_AZ][i]; }
+                if (delta) for (int i = b0 + lo; i < b0 + hi; i++) { particles[i].ax += h[H_AX][i]; particles[i].ay += h[H_AY][i]; particles[i].az += h[H_AZ][i]; }
+                else for (int i = b0 + lo; i < b0 + hi; i++) { particles[i].ax = h[H_AX][i]; particles[i].ay = h[H_AY][i]; particles[i].az = h[H_AZ][i]; }
             });
         }
         ok = ok && rebxamd_fetch_warnings(b->ctx, &bits, st) == REBXAMD_OK;     // synchronises the stream

@@ -61,5 +61,5 @@ for k in range(4):
     t = rebx.last_timings()
     # pack and upload overlap block by block, as do download and unpack: "h2d" is what remains of the upload after
     # the last block is packed
-    print("call %d  n=%d  wall %8.2f ms | pack %7.2f  h2d wait %7.2f  kernels %6.3f  d2h+unpack %7.2f ms | %.3e evals/s end to end (80 B in, 24 B out per particle)" % (
+    print("call %d  n=%d  wall %8.2f ms | pack %7.2f  h2d wait %7.2f  kernels %6.3f  d2h+unpack %7.2f ms | %.3e evals/s end to end (48 B in once the masses are there, 24 B out per particle; 80 B in with the exact arithmetic)" % (
         k, n, wall * 1e3, t["pack_ms"], t["h2d_ms"], t["kernel_ms"], t["d2h_unpack_ms"], n / wall), flush=True)

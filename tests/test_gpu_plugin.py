@@ -434,6 +434,53 @@ def test_larger_host_array_round_trip_and_timings():
     sim.free_particle_params()
 
 
+def test_large_array_in_fast_mode_adds_onto_host_accelerations_and_follows_mass_changes():
+    """Fast mode on a large array: the accelerations are not uploaded (the device sums from zero, the host adds) and a
+    block of masses travels only when it changed.  Incoming accelerations (gravity here) must survive, and a changed
+    star mass, a changed array length and a changed mass far down the array must each show in the next call."""
+    n = 1_200_000                                   # more than one block of the upload pipeline
+    cols, pp, _ = synthetic.disk(n, 1)
+    synthetic.add_newtonian(cols, n_head=1)
+    sim, arr, view = big_array_sim(cols)
+    rebx = Extras(sim)
+    f = rebx.load_force("radiation_forces"); f.params["c"] = C
+    rebx.add_force(f)
+    g = rebx.load_force("gr_potential"); g.params["c"] = C
+    rebx.add_force(g)
+    arr[0]._sim = ctypes.pointer(sim)
+    arr[0].params["radiation_source"] = 1
+    rebx.set_param_column("beta", pp["beta"])
+    src = np.zeros(n, dtype=np.uint8); src[0] = 1
+
+    def check(count):
+        for j, k in enumerate(("ax", "ay", "az")):      # what REBOUND does before every evaluation: gravity, afresh
+            view[:, 6 + j] = cols[k]
+        untouched = view[:, 6:9].copy()
+        start = {k: view[:count, 6 + j].copy() for j, k in enumerate(("ax", "ay", "az"))}
+        now = {k: view[:count, j].copy() for j, k in enumerate(("x", "y", "z", "vx", "vy", "vz"))}
+        now.update(start); now["m"] = view[:count, 9].copy()
+        sim.N = count
+        sim.call_additional_forces()
+        ref = oracle.Sim(now)
+        oracle.apply_forces(ref, [("gr_potential", {"c": C}), ("radiation_forces", {"c": C})],
+                            {"beta": pp["beta"][:count], "radiation_source": src[:count]})
+        got, want = np.array([view[:count, 6], view[:count, 7], view[:count, 8]]), np.array(ref.acc)
+        # 1e-12 of the body's total or of what was added to it, whichever is larger (radiation pressure cancels
+        # most of gravity where beta is near one: the sum then amplifies the rounding of both)
+        before = np.array([start["ax"], start["ay"], start["az"]])
+        scale = np.maximum(np.abs(want).max(axis=0), np.abs(want - before).max(axis=0))
+        assert (np.abs(got - want) / scale[None, :]).max() <= TOL
+        assert np.array_equal(view[count:, 6:9], untouched[count:])
+
+    check(n)
+    view[0, 9] *= 1.5                               # the star's mass: first block only
+    check(n)
+    check(n - 100_000)                              # a shorter array ...
+    view[n - 5, 9] = 2e-9                           # ... and a longer one again whose new end holds a changed mass
+    check(n)
+    sim.free_particle_params()
+
+
 def test_parameter_lists_spread_over_a_large_array_are_flattened_by_several_host_threads():
     """Above 1e5 particles the host side converts arrays and walks the parameter lists on several
     threads, each over its own range of particles.  Parameters set on particles of every range, a
