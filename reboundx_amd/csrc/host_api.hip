@@ -854,8 +854,10 @@ bool ops_of_force(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* 
 // after the upload.  A block of masses travels only when one of them differs from what the device
 // holds.  with_acc = false: the accelerations stay on the host and the device columns start from
 // zero (the caller adds what comes back), which saves their 24 bytes per particle on the way up.
+// with_vel = false: the velocities stay behind too (the device columns keep whatever they held:
+// for callers whose kernels do not read them).
 bool stage_in(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* b, const struct reb_particle* particles, const int N,
-              rebxamd_view& v, double t[3], const bool with_acc = true) {
+              rebxamd_view& v, double t[3], const bool with_acc = true, const bool with_vel = true) {
     if (!ensure_capacity(rebx, b, (size_t)N)) return false;
     t[0] = now_ms();
     double* const* h = b->h_dyn;
@@ -883,7 +885,7 @@ bool stage_in(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* b, c
                 const struct reb_particle& p = particles[i];
                 // (streaming stores: the staging columns are written once and read by the copy engine, not by this core)
                 __builtin_nontemporal_store(p.x, &h[H_X][i]); __builtin_nontemporal_store(p.y, &h[H_Y][i]); __builtin_nontemporal_store(p.z, &h[H_Z][i]);
-                __builtin_nontemporal_store(p.vx, &h[H_VX][i]); __builtin_nontemporal_store(p.vy, &h[H_VY][i]); __builtin_nontemporal_store(p.vz, &h[H_VZ][i]);
+                if (with_vel) { __builtin_nontemporal_store(p.vx, &h[H_VX][i]); __builtin_nontemporal_store(p.vy, &h[H_VY][i]); __builtin_nontemporal_store(p.vz, &h[H_VZ][i]); }
                 moved |= (size_t)i >= synced || bits_of(h[H_M][i]) != bits_of(p.m);
                 h[H_M][i] = p.m;
                 if (with_acc) { h[H_AX][i] = p.ax; h[H_AY][i] = p.ay; h[H_AZ][i] = p.az; }
@@ -905,6 +907,7 @@ bool stage_in(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* b, c
         else for (int k = 0; k < H_NDYN && ok; k++) {
             if (k == H_M && !mass_moved) continue;
             if (k >= H_AX && !with_acc) continue;
+            if (k >= H_VX && k <= H_VZ && !with_vel) continue;
             ok = hipMemcpyAsync(b->d_dyn[k] + b0, b->h_dyn[k] + b0, (size_t)(b1 - b0) * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess;
         }
     }
@@ -970,10 +973,15 @@ void run_builtin(struct reb_simulation* sim, struct rebx_extras* rebx, const std
     // and the sum is added here (one rounding of the total instead of one per force: below the fast mode's own bar).
     // The exact arithmetic adds force after force onto the uploaded values, as the reference does.
     // (gr_full reads the incoming accelerations -- src/gr_full.c:70-74 -- so a batch that holds it uploads them.)
-    bool reads_acc = false;
-    for (const Pending& pf : batch) reads_acc |= pf.force->update_accelerations == rebx_gr_full;
-    const bool delta = b->mode == REBXAMD_MODE_FAST && !reads_acc && !(N <= 16384 && b->cap <= 32768);
-    if (!stage_in(sim, rebx, b, particles, N, v, t, !delta)) return;
+    // A batch of position-only forces (the reference's REBX_FORCE_POS, src/core.c:232-263) leaves the velocities behind too.
+    const bool large = !(N <= 16384 && b->cap <= 32768);
+    bool reads_acc = false, reads_vel = false;
+    for (const Pending& pf : batch) {
+        reads_acc |= pf.force->update_accelerations == rebx_gr_full;
+        reads_vel |= pf.builtin->type != REBX_FORCE_POS;
+    }
+    const bool delta = b->mode == REBXAMD_MODE_FAST && !reads_acc && large;
+    if (!stage_in(sim, rebx, b, particles, N, v, t, !delta, reads_vel || !large)) return;
 
     // ---- ops (effect parameters are read on every call: they are a handful of list walks)
     std::vector<rebxamd_op> ops;

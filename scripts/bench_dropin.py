@@ -1,7 +1,8 @@
 """Times the drop-in path (host array-of-structs in and out through sim->additional_forces):
 pack, host-to-device, kernels, device-to-host + unpack, as reported by rebxamd_last_timings.
-usage: python scripts/bench_dropin.py [n] [gr | beta-lists | beta-column]
+usage: python scripts/bench_dropin.py [n] [gr | j2 | beta-lists | beta-column]
   gr           gr + gravitational_harmonics: no per-particle parameters beyond the star's
+  j2           gravitational_harmonics alone: a position-only batch, which uploads no velocities
   beta-lists   radiation_forces with beta set on every particle by rebx_set_param_double (one list per particle:
                every call reads n values again through the cached pointers)
   beta-column  the same beta given whole by rebxamd_set_param_column (no lists)"""
@@ -31,8 +32,8 @@ sim.N = n
 arr[0]._sim = ctypes.pointer(sim)
 rebx = Extras(sim)
 what = sys.argv[2] if len(sys.argv) > 2 else "gr"
-if what == "gr":
-    for name in ("gr", "gravitational_harmonics"):          # executed: harmonics, then gr
+if what in ("gr", "j2"):
+    for name in ("gr", "gravitational_harmonics") if what == "gr" else ("gravitational_harmonics",):          # executed: harmonics, then gr
         f = rebx.load_force(name)
         if name == "gr":
             f.params["c"] = C

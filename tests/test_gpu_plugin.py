@@ -481,6 +481,34 @@ def test_large_array_in_fast_mode_adds_onto_host_accelerations_and_follows_mass_
     sim.free_particle_params()
 
 
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_position_only_forces_on_a_large_array_never_look_at_the_velocities(mode):
+    """A batch of forces the reference types REBX_FORCE_POS (core.c:232-263) uploads no velocities: the result must be the
+    checker's whatever the host velocities hold (NaN here), on a fresh device buffer."""
+    n = 300_000
+    cols, pp, _ = synthetic.disk(n, 1)
+    synthetic.add_newtonian(cols, n_head=1)
+    sim, arr, view = big_array_sim(cols)
+    view[:, 3:6] = np.nan
+    rebx = Extras(sim)
+    rebx.set_mode(mode)
+    g = rebx.load_force("gr_potential"); g.params["c"] = C
+    rebx.add_force(g)
+    rebx.add_force(rebx.load_force("gravitational_harmonics"))
+    arr[0]._sim = ctypes.pointer(sim)
+    arr[0].params["J2"] = 1e-3; arr[0].params["J4"] = -3e-5; arr[0].params["R_eq"] = 2e-3
+    sim.call_additional_forces()
+    ref = oracle.Sim(cols)
+    col = lambda v: np.concatenate([[v], np.full(n - 1, np.nan)])
+    oracle.apply_forces(ref, [("gravitational_harmonics", {}), ("gr_potential", {"c": C})], {"J2": col(1e-3), "J4": col(-3e-5), "R_eq": col(2e-3)})
+    got, want = np.array([view[:, 6], view[:, 7], view[:, 8]]), np.array(ref.acc)
+    assert np.isfinite(got).all()
+    if mode == "exact":
+        assert ulp_diff(got[:, 1:], want[:, 1:]).max() == 0
+    assert rel_err(got, want).max() <= TOL
+    sim.free_particle_params()
+
+
 def test_parameter_lists_spread_over_a_large_array_are_flattened_by_several_host_threads():
     """Above 1e5 particles the host side converts arrays and walks the parameter lists on several
     threads, each over its own range of particles.  Parameters set on particles of every range, a
