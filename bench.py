@@ -148,13 +148,26 @@ def c5_section(ctx, n, steps, mode, device):
     ctx.wh_steps(view, ops, dt, steps, mode)
     torch.cuda.synchronize()
     queued = (time.perf_counter() - t0) / steps
+    # the same with the run left open between the host's waits (rebxamd_wh_run_*: the trailing half drift of a step is merged
+    # with the next step's leading one, as REBOUND's WHFast does with safe_mode = 0): one launch and one wait per step
+    rc = lib.rebxamd_wh_run_begin(ctx._h, vref, arr, len(ops), dt, mode, stream)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rc = rc or lib.rebxamd_wh_run_steps(ctx._h, 1, stream)
+        torch.cuda.current_stream().synchronize()
+    synced_open = (time.perf_counter() - t0) / steps
+    rc = rc or lib.rebxamd_wh_run_end(ctx._h, stream)
+    torch.cuda.synchronize()
+    if rc != 0:
+        raise RuntimeError("rebxamd_wh_run_*: %d" % rc)
     x = dp.cols["x"]
     finite = bool(torch.isfinite(x).all().item())
-    # per queued step one pass over the grains carries forces, kick and drift: positions, velocities,
-    # mass and the six parameters read (104 B), positions and velocities written (48 B); the
-    # accelerations stay in registers
-    bytes_per_step = 152 * n
-    out = {"n": n, "steps": steps, "effects": 5, "us_per_step_host_synced": synced * 1e6, "us_per_step_queued": queued * 1e6,
+    # per queued step one pass over the grains carries forces, kick and drift: positions, velocities, beta and the three
+    # timescales read (80 B), positions and velocities written (48 B); the accelerations stay in registers.  (R_tides, k1
+    # and the mass of a massless grain are not needed: tides_precession skips massless bodies, src/tides_precession.c:84-87.)
+    bytes_per_step = 128 * n
+    out = {"n": n, "steps": steps, "effects": 5, "us_per_step_host_synced": synced * 1e6, "us_per_step_host_synced_open_run": synced_open * 1e6,
+           "us_per_step_queued": queued * 1e6,
            "particle_steps_per_s": n / queued, "state_finite": finite,
            "roofline": {"bound": "hbm", "achieved": bytes_per_step / queued / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": bytes_per_step / queued / 1e9 / HBM_PEAK_GBS}}

@@ -478,6 +478,24 @@ int rebxamd_wh_drift(rebxamd_ctx* ctx, const rebxamd_view* view, double dt, int 
 int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, double dt, int64_t nsteps,
                      int mode, void* stream);
 
+/* The same run left unsynchronised between calls, for a host that looks in after every step (or every few) and still
+ * wants one launch and one Kepler drift per step -- what REBOUND's WHFast does with safe_mode = 0 and
+ * reb_integrator_synchronize.  No counterpart in the reference.  One massive body followed by massless ones
+ * (view->n_head = 1, view->tail_massless = 1), a force stack of at least one op that is one streaming run whose source
+ * is body 0 (no gr_full, no barycentric modify_orbits_forces); anything else: REBXAMD_ERR_UNSUPPORTED, use rebxamd_wh_steps.
+ *   rebxamd_wh_run_begin   opens the run (launches nothing; keeps copies of *view and of the ops).  Until the run is
+ *                          closed the caller must leave the columns where they are and must not write positions,
+ *                          velocities, masses or parameters.
+ *   rebxamd_wh_run_steps   nsteps more steps, each ONE pass: { drift dt (dt/2 in the first step of the run) ; forces ;
+ *                          kick }.  Between calls the massless bodies sit at the middle of the last step, kicked; body 0's
+ *                          row is one drift further (the next step's head pass has already run).
+ *   rebxamd_wh_run_end     the closing half drift: the columns hold the synchronised state, bit for bit what
+ *                          rebxamd_wh_steps(view, ops, dt, <steps taken>) would have left.  Closes the run.
+ * All three are asynchronous on `stream` (the same stream for the whole run). */
+int rebxamd_wh_run_begin(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, double dt, int mode, void* stream);
+int rebxamd_wh_run_steps(rebxamd_ctx* ctx, int64_t nsteps, void* stream);
+int rebxamd_wh_run_end(rebxamd_ctx* ctx, void* stream);
+
 /* Operators on device columns.  Positions, velocities (and masses) of `view` are UPDATED IN PLACE.
  * rebxamd_modify_mass: m_i += m_i*dt/tau_mass_i where tau_mass_i is set (device column, NaN = not
  * set), then positions and velocities are shifted to the centre-of-mass frame

@@ -60,6 +60,9 @@ _sig = {
     "rebxamd_reset_accelerations": (c_int, [c_void_p, POINTER(View), c_void_p]),
     "rebxamd_wh_drift": (c_int, [c_void_p, POINTER(View), c_double, c_int, c_void_p]),
     "rebxamd_wh_steps": (c_int, [c_void_p, POINTER(View), POINTER(Op), c_int, c_double, c_int64, c_int, c_void_p]),
+    "rebxamd_wh_run_begin": (c_int, [c_void_p, POINTER(View), POINTER(Op), c_int, c_double, c_int, c_void_p]),
+    "rebxamd_wh_run_steps": (c_int, [c_void_p, c_int64, c_void_p]),
+    "rebxamd_wh_run_end": (c_int, [c_void_p, c_void_p]),
     "rebxamd_modify_mass": (c_int, [c_void_p, POINTER(View), c_void_p, c_double, c_void_p]),
     "rebxamd_modify_orbits_direct": (c_int, [c_void_p, POINTER(View), c_int, c_int, POINTER(c_double), c_void_p, c_void_p, c_double, c_void_p]),
     "rebxamd_potentials": (c_int, [c_void_p, POINTER(View), POINTER(Op), c_int, POINTER(c_double), c_void_p]),

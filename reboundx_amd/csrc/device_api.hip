@@ -30,7 +30,10 @@ struct rebxamd_ctx {
     double* chunk_sums = nullptr;       // second-stage scratch of the back-reaction reduction
     void* hpin = nullptr;               // 512 B of pinned host memory: small results come back through it (no staging copy inside the runtime)
     double* whead = nullptr;            // Jacobi state of a head of several massive bodies between Wisdom-Holman steps (8 x 64 doubles)
-    double* star = nullptr;             // 3 x 16 doubles: records of body 0 around Wisdom-Holman drifts (two alternate between steps, one for the leading half drift)
+    double* star = nullptr;             // 6 x 16 doubles: records of body 0 around Wisdom-Holman drifts (two alternate between steps, one for the leading
+                                        // half drift; an open run: two more for the leading drifts of alternate steps, one for the closing half drift)
+    // a Wisdom-Holman run left unsynchronised between calls (rebxamd_wh_run_begin .. rebxamd_wh_run_end)
+    struct WhRun { bool open = false; int64_t k = 0; double dt = 0.; int mode = 0; rebxamd_view view; std::vector<rebxamd_op> ops; } run;
     double* integ = nullptr;            // stage columns of the force integrators
     size_t integ_cap = 0;
     double* shard = nullptr;            // per-range forces and reactions of the sharded Jacobi/barycentric modify_orbits_forces
@@ -104,7 +107,7 @@ extern "C" int rebxamd_create(int device, rebxamd_ctx** out) {
         hipMalloc((void**)&ctx->status, sizeof(unsigned)) != hipSuccess ||
         hipMalloc((void**)&ctx->ll, sizeof(long long)) != hipSuccess ||
         hipMalloc((void**)&ctx->gf_flag, 4 * sizeof(unsigned)) != hipSuccess ||
-        hipMalloc((void**)&ctx->star, 48 * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&ctx->star, 96 * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&ctx->whead, 8 * REBXAMD_MAX_HEAD * sizeof(double)) != hipSuccess ||
         hipHostMalloc(&ctx->hpin, 512, hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void**)&ctx->chunk_sums, sizeof(double) * REBXAMD_MAX_OPS * 64 * 3) != hipSuccess ||
@@ -950,6 +953,76 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
         }
         HIP_TRY(launch_wh_drift(x, v, a, view->m, view->G, h, dt, view->n, ctx->star, exact, st));
     }
+    return REBXAMD_OK;
+}
+
+// ------------------------------------------------------------------ Wisdom-Holman run left unsynchronised between calls
+// Step k of such a run is ONE pass: { drift dt (dt/2 in step 0) about body 0; forces; kick } -- the trailing half drift of
+// a step and the leading one of the next are one Kepler drift, carried at the head of the next pass, and the head pass of
+// step k + 1 (tables, record and leading drift of body 0) rides in the extra workgroup of pass k.  Body 0's row therefore
+// runs one leading drift ahead of the others while the run is open; its records keep what the end of the run needs.
+
+extern "C" int rebxamd_wh_run_begin(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, double dt, int mode, void* stream) {
+    (void)stream;
+    int rc = check_step_view(ctx, view, "rebxamd_wh_run_begin: bad argument", true, true);
+    if (rc != REBXAMD_OK) return rc;
+    if (ctx->run.open) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_run_begin: a run is already open on this context (close it with rebxamd_wh_run_end)");
+    if (nops < 0 || nops > REBXAMD_MAX_OPS || (nops > 0 && !ops)) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_run_begin: bad argument");
+    if (!view->m || !view->x || !view->vx) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_run_begin: position/velocity/mass columns missing");
+    bool ok = ctx->carried_steps && view->n_head == 1 && view->tail_massless && view->n > 1 && one_streaming_run(ops, nops);
+    for (int k = 0; k < nops && ok; k++) {
+        const bool com = ops[k].kind == REBXAMD_OP_MOF && ops[k].iarg != REBX_COORDINATES_PARTICLE;
+        const int src = (ops[k].kind == REBXAMD_OP_GR || ops[k].kind == REBXAMD_OP_GR_POTENTIAL) ? 0 : ops[k].src;
+        if ((!com && src != 0) || (ops[k].kind == REBXAMD_OP_MOF && ops[k].iarg == REBX_COORDINATES_BARYCENTRIC)) ok = false;
+    }
+    if (!ok)
+        return fail(ctx, REBXAMD_ERR_UNSUPPORTED, "rebxamd_wh_run_begin handles one massive body followed by massless ones (n_head = 1, tail_massless = 1) under a non-empty stack that is one streaming run of forces whose source is body 0 (no gr_full, no barycentric modify_orbits_forces); use rebxamd_wh_steps otherwise");
+    ctx->run.open = true; ctx->run.k = 0; ctx->run.dt = dt; ctx->run.mode = mode;
+    ctx->run.view = *view;
+    ctx->run.ops.assign(ops, ops + nops);
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_wh_run_steps(rebxamd_ctx* ctx, int64_t nsteps, void* stream) {
+    if (!ctx) return REBXAMD_ERR_ARG;
+    if (!ctx->run.open) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_run_steps: no open run");
+    if (nsteps < 0) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_run_steps: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const double dt = ctx->run.dt;
+    struct StageReset { rebxamd_ctx* c; ~StageReset() { c->hc_stage = 0; } } stage_reset{ctx};
+    for (int64_t j = 0; j < nsteps; j++) {
+        const int64_t k = ctx->run.k;
+        const int cur = (int)(k & 1), nxt = cur ^ 1;
+        ctx->hc_stage = cur;
+        StepArgs sa = {0., dt, ctx->star + 16 * cur, EPI_WH, 0., 0., 0., {nullptr, nullptr, nullptr}, nullptr, ctx->star + 48 + 16 * cur, k == 0 ? 0.5 * dt : dt, {}};
+        sa.next_hc = ctx->hc + nxt; sa.next_star = ctx->star + 16 * nxt; sa.next_h = 0.;
+        sa.next_lead = ctx->star + 48 + 16 * nxt; sa.next_h_lead = dt;
+        sa.head_ready = k > 0 ? 1 : 0;
+        sa.lead_in_head = k == 0 ? 1 : 0;
+        const int rc = run_streaming(ctx, &ctx->run.view, ctx->run.ops.data(), 0, (int)ctx->run.ops.size(), ctx->run.mode, st, -1, nullptr, false, &sa);
+        if (rc == STEP_NOT_CARRIED) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_run_steps: the force stack cannot ride in one pass over this layout");
+        if (rc != REBXAMD_OK) return rc;
+        ctx->run.k = k + 1;
+    }
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_wh_run_end(rebxamd_ctx* ctx, void* stream) {
+    if (!ctx) return REBXAMD_ERR_ARG;
+    if (!ctx->run.open) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_run_end: no open run");
+    ctx->run.open = false;
+    if (ctx->run.k == 0) return REBXAMD_OK;            // nothing was launched: the columns are as they were
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const rebxamd_view* view = &ctx->run.view;
+    double* const x[3] = {const_cast<double*>(view->x), const_cast<double*>(view->y), const_cast<double*>(view->z)};
+    double* const v[3] = {const_cast<double*>(view->vx), const_cast<double*>(view->vy), const_cast<double*>(view->vz)};
+    // body 0 back to where the last pass's forces saw it (its row ran ahead by the leading drift of a step that never came),
+    // then the closing half drift of everything
+    const int last = (int)((ctx->run.k - 1) & 1);
+    HIP_TRY(launch_wh_star_restore(x, ctx->star + 16 * last, st));
+    HIP_TRY(launch_wh_drift(x, v, nullptr, view->m, view->G, 0.5 * ctx->run.dt, 0., view->n, ctx->star + 80, ctx->run.mode == REBXAMD_MODE_EXACT, st));
     return REBXAMD_OK;
 }
 

@@ -109,7 +109,10 @@ struct StepArgs { double h, dtk; const double* star; int epi; double c0, c1, c2;
                   // centre of mass instead of body 0 -- the origin of every massless body's Jacobi coordinates -- and the pass adds
                   // the pull of the head bodies (the tables' list of massive bodies) and the Jacobi term G M q/|q|^3 of the kick
                   int wh_head;
-                  double* jac; };                      // wh_head > 1 with the next step's head pass chained in: the head's Jacobi state between steps
+                  double* jac;                         // wh_head > 1 with the next step's head pass chained in: the head's Jacobi state between steps
+                  // EPI_WH, one-body head, run left unsynchronised between steps: the chained head pass of the next step first records
+                  // body 0 in next_lead and drifts it over next_h_lead (that step's leading drift); h == 0 then means "no trailing drift"
+                  double* next_lead; double next_h_lead; };
 
 enum { WARN_GR_ITER = 1u, WARN_GRFULL_SWEEPS = 2u, WARN_IM_ITER = 4u };
 
@@ -154,6 +157,7 @@ hipError_t launch_rk2_final(double* const v[3], const double* const a1[3], const
 hipError_t launch_rk4_mid(double* const sv[3], const double* const v[3], double* const k2a[3], double* const k3a[3], double dt, long long n, bool exact, hipStream_t st);
 hipError_t launch_rk4_final(double* const v[3], const double* const a1[3], const double* const a4[3], const double* const k23[3], double dt6, long long n, bool exact, hipStream_t st);
 // body 0 alone: records it in `star` and drifts it over h
+hipError_t launch_wh_star_restore(double* const x[3], const double* star, hipStream_t st);
 hipError_t launch_wh_star(double* const x[3], double* const v[3], const double* m, double G, double h, double* star, hipStream_t st);
 hipError_t launch_wh_drift(double* const x[3], double* const v[3], double* const a[3], const double* m, double G, double h, double dtk, long long n,
                            double* star, bool exact, hipStream_t st);

@@ -145,6 +145,17 @@ __device__ __forceinline__ void kepler_dev(double (&q)[6], double M, double dt) 
 // its mass parameter G*m_0 [12].
 // KICK: v += dtk*(a - a_0) first (Jacobi kick of a massless body), then the Kepler drift over h
 // relative to body 0.
+// v += dtk*(a - a_0): the Jacobi kick of a massless body (a_0 = star[9..11])
+template <bool EXACT>
+__device__ __forceinline__ void wh_kick(double& vx, double& vy, double& vz, double ax, double ay, double az, double dtk, const double* __restrict__ star) {
+#pragma clang fp contract(off)
+    if (EXACT) {
+        vx += dtk * (ax - star[9]); vy += dtk * (ay - star[10]); vz += dtk * (az - star[11]);
+    } else {
+        vx = fma(dtk, ax - star[9], vx); vy = fma(dtk, ay - star[10], vy); vz = fma(dtk, az - star[11], vz);
+    }
+}
+
 template <bool EXACT, bool KICK>
 __device__ __forceinline__ void wh_kick_drift(double (&s)[6], double ax, double ay, double az, double h, double dtk,
                                               const double* __restrict__ star) {
@@ -152,13 +163,7 @@ __device__ __forceinline__ void wh_kick_drift(double (&s)[6], double ax, double 
     {
 #pragma clang fp contract(off)
         double vx = s[3], vy = s[4], vz = s[5];
-        if (KICK) {
-            if (EXACT) {
-                vx += dtk * (ax - star[9]); vy += dtk * (ay - star[10]); vz += dtk * (az - star[11]);
-            } else {
-                vx = fma(dtk, ax - star[9], vx); vy = fma(dtk, ay - star[10], vy); vz = fma(dtk, az - star[11], vz);
-            }
-        }
+        if (KICK) wh_kick<EXACT>(vx, vy, vz, ax, ay, az, dtk, star);
         q[0] = s[0] - star[0]; q[1] = s[1] - star[1]; q[2] = s[2] - star[2];
         q[3] = vx - star[3]; q[4] = vy - star[4]; q[5] = vz - star[5];
     }

@@ -284,6 +284,17 @@ hipError_t launch_wh_star(double* const x[3], double* const v[3], const double* 
     return hipGetLastError();
 }
 
+// body 0 back to the position its record holds (star[0..2]: where it was before the drift the record describes)
+__global__ void wh_star_restore_kernel(Cols3 x, const double* __restrict__ star) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    x.x[0] = star[0]; x.y[0] = star[1]; x.z[0] = star[2];
+}
+hipError_t launch_wh_star_restore(double* const x[3], const double* star, hipStream_t st) {
+    const Cols3 cx = {x[0], x[1], x[2]};
+    hipLaunchKernelGGL(wh_star_restore_kernel, dim3(1), dim3(64), 0, st, cx, star);
+    return hipGetLastError();
+}
+
 // a == nullptr: drift only.  Otherwise kick by dtk with the accelerations in `a` (which are cleared), then drift.
 hipError_t launch_wh_drift(double* const x[3], double* const v[3], double* const a[3], const double* m, double G, double h, double dtk, long long n,
                            double* star, bool exact, hipStream_t st) {

@@ -707,7 +707,7 @@ __global__ __launch_bounds__(BLOCK, (BACKREACT && SIG == 0ull) ? 2 : (!EXACT && 
                 return;
             }
         }
-        if (tid < 64) head_one_body(v, prog, step.next_hc, step.next_star, step.next_h, tid);
+        if (tid < 64) head_one_body(v, prog, step.next_hc, step.next_star, step.next_h, tid, step.next_lead, step.next_h_lead);
         return;
     }
     const unsigned blk = blockIdx.x - (chained ? 1u : 0u);
@@ -870,7 +870,9 @@ __global__ __launch_bounds__(BLOCK, (BACKREACT && SIG == 0ull) ? 2 : (!EXACT && 
             if (!(k ? act1 : act0)) continue;
             s[k][0] = p[k].x; s[k][1] = p[k].y; s[k][2] = p[k].z; s[k][3] = p[k].vx; s[k][4] = p[k].vy; s[k][5] = p[k].vz;
             if (step.wh_head > 1) wh_head_pull<EXACT>(tab, prog.G, step.star, p[k], acc[k]);
-            wh_kick_drift<EXACT, true>(s[k], acc[k].x, acc[k].y, acc[k].z, step.h, step.dtk, step.star);
+            // (h == 0: a run left unsynchronised between steps -- the drift waits for the next pass, or for the end of the run)
+            if (step.h == 0.) wh_kick<EXACT>(s[k][3], s[k][4], s[k][5], acc[k].x, acc[k].y, acc[k].z, step.dtk, step.star);
+            else wh_kick_drift<EXACT, true>(s[k], acc[k].x, acc[k].y, acc[k].z, step.h, step.dtk, step.star);
         }
         if (full) {
             d2v t;

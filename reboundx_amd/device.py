@@ -79,6 +79,18 @@ class Context:
         arr = (Op * max(len(ops), 1))(*ops)
         self._check(lib.rebxamd_wh_steps(self._h, ctypes.byref(view), arr, len(ops), float(dt), int(nsteps), mode, self._stream()))
 
+    def wh_run_begin(self, view, ops, dt, mode=_lib.MODE_FAST):
+        """Opens a Wisdom-Holman run that stays unsynchronised between calls (one pass and one Kepler drift per step)."""
+        arr = (Op * max(len(ops), 1))(*ops)
+        self._check(lib.rebxamd_wh_run_begin(self._h, ctypes.byref(view), arr, len(ops), float(dt), mode, self._stream()))
+
+    def wh_run_steps(self, nsteps):
+        self._check(lib.rebxamd_wh_run_steps(self._h, int(nsteps), self._stream()))
+
+    def wh_run_end(self):
+        """Closing half drift: the columns hold the synchronised state."""
+        self._check(lib.rebxamd_wh_run_end(self._h, self._stream()))
+
     def modify_mass(self, view, tau_mass, dt):
         """tau_mass: float64 device tensor, NaN = not set.  Masses, positions, velocities change in place."""
         self._check(lib.rebxamd_modify_mass(self._h, ctypes.byref(view), tau_mass.data_ptr(), float(dt), self._stream()))

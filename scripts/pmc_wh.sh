@@ -1,0 +1,27 @@
+#!/bin/bash
+# Instruction mix of the pass that carries a Wisdom-Holman step (one PMC pass; GPU box, repository root).
+# usage: bash scripts/pmc_wh.sh [grains]
+set -e
+ROOT="$(pwd)"
+OUT="$ROOT/gpurun_out"
+N=${1:-10000000}
+cd /tmp && export TMPDIR=/tmp
+timeout -s KILL 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d "$OUT/prof_wh" -o wh -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu --grfull-n 0 --c3-n 0 --c3-big-n 0 --ooc-n 0 --c5-n $N --c5-steps 40 > "$OUT/prof_wh.log" 2>&1
+python3 - "$OUT" <<'P'
+import collections, csv, glob, sys
+out = sys.argv[1]
+cc = glob.glob(out + "/prof_wh/**/*counter_collection.csv", recursive=True)[0]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(cc)):
+    k = r["Kernel_Name"]
+    if "stream_kernel" not in k: continue
+    acc[k[:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if r["Counter_Name"] == "SQ_WAVES": acc[k[:70]]["dur"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+for k, d in acc.items():
+    m = {c: sum(v) / len(v) for c, v in d.items()}
+    print(k, "n=%d dur %.1f us" % (len(d["SQ_WAVES"]), m["dur"] / 1e3))
+    print("   waves %.0f  VALU/wave %.0f  SALU/wave %.0f  clock %.2f GHz  VALU-active/busy %.3f  wait_any/wave_cycles %.3f" % (
+        m["SQ_WAVES"], m["SQ_INSTS_VALU"] / m["SQ_WAVES"], m["SQ_INSTS_SALU"] / m["SQ_WAVES"], m["GRBM_GUI_ACTIVE"] / 8 / m["dur"],
+        m["SQ_ACTIVE_INST_VALU"] / m["SQ_BUSY_CYCLES"], m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]))
+    print("   raw", {c: v for c, v in m.items()})
+P

@@ -46,3 +46,56 @@ for label, wait in (("torch stream.synchronize", stream.synchronize), ("hipStrea
         lib.rebxamd_wh_steps(ctx._h, vref, arr, len(ops), dt, 1, 0, sp)
         wait()
     print("%-28s %s: %.2f us per synchronised step" % (label, "spin" if spin else "default", (time.perf_counter() - t0) / steps * 1e6))
+
+# where a synchronised step goes: the call (host work + launch), the wait, and the same with 1000 grains (kernel ~3 us:
+# what remains is the launch-to-completion latency of the runtime)
+def split(view_, label):
+    vr = ctypes.byref(view_)
+    tc = tw = 0.
+    steps = 3000
+    for _ in range(steps):
+        a = time.perf_counter()
+        lib.rebxamd_wh_steps(ctx._h, vr, arr, len(ops), dt, 1, 0, sp)
+        b = time.perf_counter()
+        hipc.hipStreamSynchronize(sp)
+        c = time.perf_counter()
+        tc += b - a; tw += c - b
+    print("%-14s call %.2f us  wait %.2f us  total %.2f us" % (label, tc / steps * 1e6, tw / steps * 1e6, (tc + tw) / steps * 1e6))
+
+
+split(view, "1e6 grains")
+small = {k: v[:1001] for k, v in host.items()}
+dps = DeviceParticles.from_host(small, device="cuda:0", n_head=1, tail_massless=True)
+split(dps.view(), "1000 grains")
+t0 = time.perf_counter()
+for _ in range(3000):
+    lib.rebxamd_wh_steps(ctx._h, ctypes.byref(dps.view()) if False else vref, arr, len(ops), dt, 1, 0, sp)
+hipc.hipStreamSynchronize(sp)
+print("queued single-step calls, 1e6 grains: %.2f us per call" % ((time.perf_counter() - t0) / 3000 * 1e6))
+vs = dps.view(); vsr = ctypes.byref(vs)
+t0 = time.perf_counter()
+for _ in range(3000):
+    lib.rebxamd_wh_steps(ctx._h, vsr, arr, len(ops), dt, 1, 0, sp)
+hipc.hipStreamSynchronize(sp)
+print("queued single-step calls, 1000 grains: %.2f us per call (host cost of a call when the device keeps up)" % ((time.perf_counter() - t0) / 3000 * 1e6))
+
+
+def split_open(view_, label):
+    vr = ctypes.byref(view_)
+    lib.rebxamd_wh_run_begin(ctx._h, vr, arr, len(ops), dt, 0, sp)
+    tc = tw = 0.
+    steps = 3000
+    for _ in range(steps):
+        a = time.perf_counter()
+        lib.rebxamd_wh_run_steps(ctx._h, 1, sp)
+        b = time.perf_counter()
+        hipc.hipStreamSynchronize(sp)
+        c = time.perf_counter()
+        tc += b - a; tw += c - b
+    lib.rebxamd_wh_run_end(ctx._h, sp)
+    hipc.hipStreamSynchronize(sp)
+    print("open run, %-14s call %.2f us  wait %.2f us  total %.2f us" % (label, tc / steps * 1e6, tw / steps * 1e6, (tc + tw) / steps * 1e6))
+
+
+split_open(view, "1e6 grains")
+split_open(vs, "1000 grains")

@@ -8,6 +8,7 @@ Jacobi correction, which cancel to rounding; the device never forms them), so ag
 rounding accumulated over the steps, not bitwise: bar 1e-12 of the state after 40 steps."""
 import numpy as np
 import pytest
+import torch
 
 import oracle
 from reboundx_amd import synthetic
@@ -277,3 +278,60 @@ def test_layouts_the_stepping_run_cannot_take_are_refused(ctx):
     with pytest.raises(RebxAmdError) as ei:                      # gr_full is not a streaming force
         ctx.wh_steps(dp.view(), build_ops([("gr_full", {"c": C})], pp), 0.01, 1)
     assert ei.value.code == 3
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("forces", [C5_STACK, C2_STACK, [("radiation_forces", {"c": C})]],
+                         ids=["five-effects", "rad+harmonics+gr", "radiation"])
+@pytest.mark.parametrize("n", [2, 3, 1500, 4099])
+def test_run_left_open_between_calls_ends_bit_for_bit_where_the_closed_run_ends(ctx, n, forces, mode):
+    """rebxamd_wh_run_begin / _steps / _end: the trailing half drift of a step waits for the next pass (or for the end of the
+    run).  The operations on every body are those of rebxamd_wh_steps in the same order, so after the closing call the states
+    are equal to the bit in both arithmetic modes, however the steps were split over calls; the host may wait after any call."""
+    dt = 0.05
+    cols, pp, _ = synthetic.disk(n, 0)
+    cols["vx"][0], cols["vy"][0] = 1e-3, -2e-3
+    ops = build_ops(forces, pp)
+    closed = device_particles(cols, pp)
+    ctx.wh_steps(closed.view(), ops, dt, 7, mode)
+    want = state_of(closed)
+    for split in ([7], [1] * 7, [3, 0, 4], [1, 5, 1]):
+        dp = device_particles(cols, pp)
+        ctx.wh_run_begin(dp.view(), ops, dt, mode)
+        for k in split:
+            ctx.wh_run_steps(k)
+            torch.cuda.synchronize()
+        ctx.wh_run_end()
+        got = state_of(dp)
+        assert np.isfinite(got).all()
+        assert np.array_equal(got, want), split
+
+
+def test_open_run_contract(ctx):
+    """A run that took no step leaves the columns untouched; a second begin, steps or end without a run, and layouts or
+    stacks the open run does not take are refused; after the end the context steps as before."""
+    from reboundx_amd.device import RebxAmdError
+    cols, pp, _ = synthetic.disk(500, 0)
+    ops = build_ops(C5_STACK, pp)
+    dp = device_particles(cols, pp)
+    before = state_of(dp)
+    ctx.wh_run_begin(dp.view(), ops, 0.05)
+    with pytest.raises(RebxAmdError) as ei:
+        ctx.wh_run_begin(dp.view(), ops, 0.05)
+    assert ei.value.code == 1
+    ctx.wh_run_steps(0)
+    ctx.wh_run_end()
+    assert np.array_equal(state_of(dp), before)
+    for call in (lambda: ctx.wh_run_steps(1), ctx.wh_run_end):
+        with pytest.raises(RebxAmdError) as ei:
+            call()
+        assert ei.value.code == 1
+    planets, ppp, _ = synthetic.disk(100, 2)
+    dq = DeviceParticles.from_host(dict(planets), device="cuda:0", n_head=3, tail_massless=True)
+    for view, stack, par in ((dq.view(), C5_STACK, ppp), (dp.view(), [], pp), (dp.view(), [("modify_orbits_forces", {"coordinates": 1})], pp),
+                             (dp.view(), [("gr_full", {"c": C})], pp)):
+        with pytest.raises(RebxAmdError) as ei:
+            ctx.wh_run_begin(view, build_ops(stack, par), 0.05)
+        assert ei.value.code == 3
+    ctx.wh_steps(dp.view(), ops, 0.05, 2)                        # no run is left open by a refused begin
+    assert np.isfinite(state_of(dp)).all()
