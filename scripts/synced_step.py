@@ -99,3 +99,23 @@ def split_open(view_, label):
 
 split_open(view, "1e6 grains")
 split_open(vs, "1000 grains")
+
+
+def split_open_query(view_, label):
+    """the same, waiting by polling hipStreamQuery instead of hipStreamSynchronize"""
+    vr = ctypes.byref(view_)
+    lib.rebxamd_wh_run_begin(ctx._h, vr, arr, len(ops), dt, 0, sp)
+    steps = 3000
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        lib.rebxamd_wh_run_steps(ctx._h, 1, sp)
+        while hipc.hipStreamQuery(sp) != 0:
+            pass
+    tot = time.perf_counter() - t0
+    lib.rebxamd_wh_run_end(ctx._h, sp)
+    hipc.hipStreamSynchronize(sp)
+    print("open run, %-14s polling hipStreamQuery: total %.2f us" % (label, tot / steps * 1e6))
+
+
+split_open_query(view, "1e6 grains")
+split_open_query(vs, "1000 grains")
