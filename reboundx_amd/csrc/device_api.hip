@@ -32,6 +32,10 @@ struct rebxamd_ctx {
     double* whead = nullptr;            // Jacobi state of a head of several massive bodies between Wisdom-Holman steps (8 x 64 doubles)
     double* star = nullptr;             // 6 x 16 doubles: records of body 0 around Wisdom-Holman drifts (two alternate between steps, one for the leading
                                         // half drift; an open run: two more for the leading drifts of alternate steps, one for the closing half drift)
+    // batches of Wisdom-Holman steps carried by one pass (star + massless bodies): tables and records of body 0, one per step
+    HeadConsts* hc_batch = nullptr;
+    double* star_batch = nullptr;
+    int wh_batch = 32;                  // steps per pass (1: one pass per step)
     // a Wisdom-Holman run left unsynchronised between calls (rebxamd_wh_run_begin .. rebxamd_wh_run_end)
     struct WhRun { bool open = false; int64_t k = 0; double dt = 0.; int mode = 0; rebxamd_view view; std::vector<rebxamd_op> ops; } run;
     double* integ = nullptr;            // stage columns of the force integrators
@@ -132,6 +136,8 @@ extern "C" void rebxamd_destroy(rebxamd_ctx* ctx) {
     if (ctx->gf_flag) (void)hipFree(ctx->gf_flag);
     if (ctx->star) (void)hipFree(ctx->star);
     if (ctx->whead) (void)hipFree(ctx->whead);
+    if (ctx->hc_batch) (void)hipFree(ctx->hc_batch);
+    if (ctx->star_batch) (void)hipFree(ctx->star_batch);
     if (ctx->gf4) (void)hipFree(ctx->gf4);
     if (ctx->hpin) (void)hipHostFree(ctx->hpin);
     if (ctx->chunk_sums) (void)hipFree(ctx->chunk_sums);
@@ -328,7 +334,7 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
     const long long K = v.n_head < v.n ? v.n_head : v.n;
     const bool sparse = target_lo < 0 && (u->tail_massless != 0 || K == v.n) && K >= 1 && K <= REBXAMD_MAX_HEAD && max_src < K;
 
-    const bool wh = step && step->epi == EPI_WH;
+    const bool wh = step && (step->epi == EPI_WH || step->epi == EPI_WHB);
     const bool applies = step && step->epi == EPI_APPLY;      // the pass also applies a prefix-sum force (any-mass-layout pass only)
     if (step && !applies && !(sparse && (wh ? (K == 1 || step->wh_head == (int)K) : v.n > K))) return STEP_NOT_CARRIED;
     if (applies && (sparse || prog.gr_op >= 0 || prog.mofcom_op >= 0 || target_lo >= 0 || pushes_only)) return STEP_NOT_CARRIED;
@@ -352,12 +358,16 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
                 HIP_TRY(launch_head(v, prog, hc, ctx->status, exact, st));
                 HIP_TRY(launch_wh_head_step(v, K, prog.G, step->dtk, step->h, ctx->whead, const_cast<double*>(step->star), exact, st));
             }
+        } else if (wh && step->nsub > 1) {
+            // a batch of steps in one pass: the head passes of all of them first, one after the other in one wavefront
+            HIP_TRY(launch_head_batch(v, prog, const_cast<HeadConsts*>(step->tabs), const_cast<double*>(step->star), step->nsub, step->h_sub, step->h,
+                                      step->lead_in_head ? const_cast<double*>(step->star0) : nullptr, step->h0, st));
         } else if (!(wh && step->head_ready))
             HIP_TRY(launch_head(v, prog, hc, ctx->status, exact, st, wh ? const_cast<double*>(step->star) : nullptr, wh ? step->h : 0.,
                                 (wh && step->lead_in_head) ? const_cast<double*>(step->star0) : nullptr, wh ? step->h0 : 0.));
         if (v.n > K) {
             TimedLaunch tl(ctx, st);
-            HIP_TRY(launch_stream(v, prog, K, hc, nullptr, nullptr, false, exact, vec2, ctx->fixed_stacks, ctx->status, st, step));
+            HIP_TRY(launch_stream(v, prog, K, (wh && step->nsub > 1) ? step->tabs : hc, nullptr, nullptr, false, exact, vec2, ctx->fixed_stacks, ctx->status, st, step));
         }
         return REBXAMD_OK;
     }
@@ -850,6 +860,15 @@ extern "C" int rebxamd_wh_drift(rebxamd_ctx* ctx, const rebxamd_view* view, doub
     return REBXAMD_OK;
 }
 
+constexpr int kMaxWhBatch = 64;
+
+extern "C" int rebxamd_wh_batch(rebxamd_ctx* ctx, int steps_per_pass) {
+    if (!ctx) return REBXAMD_ERR_ARG;
+    if (steps_per_pass < 1 || steps_per_pass > kMaxWhBatch) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_batch: between 1 and 64 steps per pass");
+    ctx->wh_batch = steps_per_pass;
+    return REBXAMD_OK;
+}
+
 extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, double dt, int64_t nsteps,
                                 int mode, void* stream) {
     int rc = check_step_view(ctx, view, "rebxamd_wh_steps: bad argument", true, true);
@@ -928,6 +947,32 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
             HIP_TRY(launch_wh_star(x, v, view->m, view->G, 0.5 * dt, star0, st));   // body 0 to mid-step; the others follow inside the pass
         }
         struct StageReset { rebxamd_ctx* c; ~StageReset() { c->hc_stage = 0; } } stage_reset{ctx};
+        // The massless bodies are independent of one another and body 0 of them: one pass can take every body through a batch
+        // of steps in registers -- positions and velocities make one round trip per batch instead of one per step -- once the
+        // head passes of those steps (tables, records of body 0) have been made, one after the other in one wavefront.
+        const int batch = (chain && ctx->wh_batch > 1 && !ctx->fixed_scratch) ? ctx->wh_batch : 1;
+        if (batch > 1 && nsteps > 1) {
+            if (!ctx->hc_batch) {
+                HIP_TRY(hipMalloc((void**)&ctx->hc_batch, (size_t)kMaxWhBatch * sizeof(HeadConsts)));
+                HIP_TRY(hipMalloc((void**)&ctx->star_batch, (size_t)kMaxWhBatch * 16 * sizeof(double)));
+            }
+            for (int64_t k = 0; k < nsteps;) {
+                const int nsub = (int)(nsteps - k < batch ? nsteps - k : batch);
+                const bool ends = k + nsub == nsteps;
+                StepArgs sa = {ends ? 0.5 * dt : dt, dt, ctx->star_batch, EPI_WHB, 0., 0., 0., {nullptr, nullptr, nullptr}, nullptr, k == 0 ? star0 : nullptr, 0.5 * dt, {}};
+                sa.lead_in_head = k == 0 ? 1 : 0;
+                sa.nsub = nsub; sa.h_sub = dt; sa.tabs = ctx->hc_batch;
+                if (nsub == 1) {            // a last batch of one step is an ordinary pass; its head pass goes through the same launcher
+                    sa.nsub = 0; sa.tabs = nullptr; sa.star = ctx->star; sa.epi = EPI_WH;
+                    ctx->hc_stage = 0;
+                }
+                rc = run_streaming(ctx, view, ops, 0, nops, mode, st, -1, nullptr, false, &sa);
+                if (rc == STEP_NOT_CARRIED) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_steps: the force stack cannot ride in one pass over this layout");
+                if (rc != REBXAMD_OK) return rc;
+                k += nsub;
+            }
+            return REBXAMD_OK;
+        }
         for (int64_t k = 0; k < nsteps; k++) {
             const double h = k + 1 < nsteps ? dt : 0.5 * dt;
             const int cur = chain ? (int)(k & 1) : 0, nxt = cur ^ 1;

@@ -88,7 +88,9 @@ struct HeadConsts {
 //   EPI_APPLY (any-mass-layout pass, default arithmetic) the last pass of a prefix-sum force rides along:
 //             a_i also receives aJ_i minus the reactions of the bodies k >= i (scan_kernels.hip, pass 5),
 //             so the accelerations make one round trip for the streaming forces and that force together
-enum { EPI_NONE = 0, EPI_WH = 1, EPI_EULER = 2, EPI_RK2 = 3, EPI_RK4 = 4, EPI_IM = 5, EPI_APPLY = 6 };
+//   EPI_WHB   (one-body head) nsub consecutive Wisdom-Holman steps of every body, which stays in registers in between;
+//             an instance of its own so that the one-step pass keeps its register allocation
+enum { EPI_NONE = 0, EPI_WH = 1, EPI_EULER = 2, EPI_RK2 = 3, EPI_RK4 = 4, EPI_IM = 5, EPI_APPLY = 6, EPI_WHB = 7 };
 // What the per-body pass of a prefix-sum force leaves for the pass that applies it: the force in the body's
 // own frame (aj), the share of it that falls back on the bodies before (share), the reactions summed over
 // the workgroups behind each workgroup of that pass (behind_blocks, 3 per workgroup) and per wavefront
@@ -112,7 +114,12 @@ struct StepArgs { double h, dtk; const double* star; int epi; double c0, c1, c2;
                   double* jac;                         // wh_head > 1 with the next step's head pass chained in: the head's Jacobi state between steps
                   // EPI_WH, one-body head, run left unsynchronised between steps: the chained head pass of the next step first records
                   // body 0 in next_lead and drifts it over next_h_lead (that step's leading drift); h == 0 then means "no trailing drift"
-                  double* next_lead; double next_h_lead; };
+                  double* next_lead; double next_h_lead;
+                  // EPI_WHB: the pass carries nsub (> 1) consecutive steps of every massless body, which stays in
+                  // registers in between -- the bodies are independent of one another and body 0 of them, so only the tables
+                  // (tabs[j]) and records (star + 16 j) change from step to step; the trailing drift is h_sub after every step
+                  // but the last of the batch, h after that one
+                  int nsub; double h_sub; const HeadConsts* tabs; };
 
 enum { WARN_GR_ITER = 1u, WARN_GRFULL_SWEEPS = 2u, WARN_IM_ITER = 4u };
 
@@ -121,6 +128,9 @@ enum { WARN_GR_ITER = 1u, WARN_GRFULL_SWEEPS = 2u, WARN_IM_ITER = 4u };
 // lead != nullptr (one-body head only): body 0 is first recorded in `lead` and drifted over h_lead (the leading half drift of a run)
 hipError_t launch_head(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, bool exact, hipStream_t st,
                        double* star = nullptr, double h = 0., double* lead = nullptr, double h_lead = 0.);
+// the one-body head passes of nsub consecutive Wisdom-Holman steps (tables hc[j], records star + 16 j); see head_one_batch_kernel
+hipError_t launch_head_batch(const View& v, const Program& prog, HeadConsts* hc, double* star, int nsub, double h, double h_last, double* lead,
+                             double h_lead, hipStream_t st);
 hipError_t launch_stream(const View& v, const Program& prog, long long lo, const HeadConsts* hc, double* partials,
                          int* nblocks_out, bool backreact, bool exact, bool vec2, bool fixed, unsigned* status, hipStream_t st,
                          const StepArgs* step = nullptr);

@@ -42,7 +42,22 @@ __device__ __forceinline__ void stumpff_dev(double z, double (&c)[4]) {
 #pragma clang fp contract(off)
         REBXAMD_STUMPFF_BODY
     } else {
-        REBXAMD_STUMPFF_BODY
+        // seven terms: the first one left out is below |z|^7/16! = 5e-21 for |z| <= 0.1
+        c3 = 1. / 1307674368000.;            c2 = 1. / 87178291200.;
+        c3 = 1. / 6227020800. - z * c3;      c2 = 1. / 479001600. - z * c2;
+        c3 = 1. / 39916800. - z * c3;        c2 = 1. / 3628800. - z * c2;
+        c3 = 1. / 362880. - z * c3;          c2 = 1. / 40320. - z * c2;
+        c3 = 1. / 5040. - z * c3;            c2 = 1. / 720. - z * c2;
+        c3 = 1. / 120. - z * c3;             c2 = 1. / 24. - z * c2;
+        c3 = 1. / 6. - z * c3;               c2 = 1. / 2. - z * c2;
+        c1 = 1. - z * c3; c0 = 1. - z * c2;
+        for (; n > 0; n--) {
+            z *= 4.;
+            c3 = 0.25 * (c2 + c0 * c3);
+            c2 = 0.5 * c1 * c1;
+            c1 = c0 * c1;
+            c0 = 2. * c0 * c0 - 1.;
+        }
     }
     c[0] = c0; c[1] = c1; c[2] = c2; c[3] = c3;
 }
@@ -95,8 +110,10 @@ __device__ __forceinline__ void kepler_exact(double (&q)[6], double M, double dt
 
 // Default arithmetic: refined hardware reciprocals, third-order starting guess and Halley's
 // method (cubic convergence): a step shorter than 4e-6 of X leaves an error below rounding, so
-// the usual cost is two evaluations of the G functions plus the final one.  The bracket of the
-// root (the residual is monotonic in X: its derivative is r > 0) guards every step.
+// the usual cost is two evaluations of the G functions.  The bracket of the root (the residual is
+// monotonic in X: its derivative is r > 0) guards every step.  The G functions at the accepted X come
+// from those at the last iterate by their Taylor series to second order in the step (G0' = -beta G1,
+// G1' = G0, G2' = G1, G3' = G2; the cubic term is below (4e-6)^3 of the value), not from a third evaluation.
 __device__ __forceinline__ void kepler_fast(double (&q)[6], double M, double dt) {
     const double x0 = q[0], y0 = q[1], z0 = q[2], vx0 = q[3], vy0 = q[4], vz0 = q[5];
     const double r2 = x0 * x0 + y0 * y0 + z0 * z0;
@@ -111,23 +128,37 @@ __device__ __forceinline__ void kepler_fast(double (&q)[6], double M, double dt)
     double X = u * (1. - u * (a - u * (2. * a * a - b)));
     double G[4];
     double lo = -HUGE_VAL, hi = HUGE_VAL, prev = __builtin_nan("");
+    bool fresh = false;                     // G holds the functions at X
     for (int it = 0; it < 60; it++) {
         gfuncs_dev<false>(beta, X, G);
         const double s = r0 * X + eta0 * G[2] + zeta0 * G[3] - dt;
         const double sp = r0 + eta0 * G[1] + zeta0 * G[2];
         const double spp = eta0 * G[0] + zeta0 * G[1];
         if (s > 0.) hi = X; else lo = X;
-        // Halley: dX = -s / (s' - s s'' / (2 s'))
-        const double spi = fast_rcp(sp);
-        const double dX = -s * fast_rcp(sp - 0.5 * s * spp * spi);
+        // Halley: dX = -s / (s' - s s'' / (2 s')) = -s s' / (s'^2 - s s''/2); the step is a correction, so one
+        // Newton refinement of the hardware reciprocal (relative error ~2e-16 of the step) is enough
+        const double den = fma(sp, sp, -0.5 * s * spp);
+        double y = __builtin_amdgcn_rcp(den);
+        y = fma(y, fma(-den, y, 1.0), y);
+        const double dX = -(s * sp) * y;
         double Xn = X + dX;
         const bool inside = Xn > lo && Xn < hi;
-        if (!inside) Xn = (isfinite(lo) && isfinite(hi)) ? 0.5 * (lo + hi) : X - s * spi;
-        const bool done = (inside && fabs(dX) <= 4e-6 * fabs(Xn)) || Xn == X || Xn == prev;
+        if (!inside) Xn = (isfinite(lo) && isfinite(hi)) ? 0.5 * (lo + hi) : X - s * fast_rcp(sp);
+        const bool small = inside && fabs(dX) <= 4e-6 * fabs(Xn);
+        if (small) {
+            const double d = Xn - X, hd = 0.5 * d;
+            const double g1 = fma(d, fma(-beta * hd, G[1], G[0]), G[1]);
+            const double g2 = fma(d, fma(hd, G[0], G[1]), G[2]);
+            const double g3 = fma(d, fma(hd, G[1], G[2]), G[3]);
+            G[1] = g1; G[2] = g2; G[3] = g3;
+            X = Xn; fresh = true;
+            break;
+        }
+        if (Xn == X) { fresh = true; break; }
+        if (Xn == prev) { X = Xn; break; }
         prev = X; X = Xn;
-        if (done) break;
     }
-    gfuncs_dev<false>(beta, X, G);
+    if (!fresh) gfuncs_dev<false>(beta, X, G);
     const double r = r0 + eta0 * G[1] + zeta0 * G[2];
     const double ri = fast_rcp(r);
     const double fm1 = -M * G[2] * r0i, g = dt - M * G[3], fd = -M * G[1] * r0i * ri, gdm1 = -M * G[2] * ri;

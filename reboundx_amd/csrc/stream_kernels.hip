@@ -375,10 +375,10 @@ __global__ __launch_bounds__(64) void head_kernel(View v, Program prog, HeadCons
 // fraction of head_kernel's latency: no loops over ops with barriers, no LDS.
 // lead != nullptr (first step of a Wisdom-Holman run): body 0 is first recorded in `lead` and drifted over h_lead
 // -- the record the tail pass needs for its leading half drift -- and the tables are then filled for the drifted body.
-__device__ __forceinline__ void head_one_body(const View& v, const Program& prog, HeadConsts* hc, double* star, double h, const int t,
-                                              double* lead = nullptr, double h_lead = 0.) {
-    Src S;
-    load_src(v, 0, S);                                  // every lane reads the same body
+// S: body 0 (the same in every lane), taken as it stands and left as the pass leaves it (drifted, in a stepping run), so that a
+// wavefront can make one head pass after the other without going through memory; write_row: also store the new position.
+__device__ __forceinline__ void head_one_core(const View& v, const Program& prog, HeadConsts* hc, double* star, double h, const int t,
+                                              double* lead, double h_lead, Src& S, bool write_row) {
     if (lead != nullptr) {
 #pragma clang fp contract(off)
         const double nx = S.x + h_lead * S.vx, ny = S.y + h_lead * S.vy, nz = S.z + h_lead * S.vz;
@@ -393,44 +393,68 @@ __device__ __forceinline__ void head_one_body(const View& v, const Program& prog
         if (prog.ops[t].kind == REBXAMD_OP_GR) s = 0;
         if (s >= 0) hc->src[t] = S;
     }
-    if (t != 0) return;
-    if (S.m != 0.) { hc->head[0][0] = S.x; hc->head[0][1] = S.y; hc->head[0][2] = S.z; hc->head[0][3] = S.m; }
-    hc->nheadm = S.m != 0. ? 1 : 0;
-    hc->head0 = S.m != 0. ? 0 : -1;
-    // In a stepping run the acceleration of body 0 starts from zero whatever the column holds (the columns of
-    // the bodies behind it are neither read nor written there).
-    double a0x = star != nullptr ? 0. : v.ax[0], a0y = star != nullptr ? 0. : v.ay[0], a0z = star != nullptr ? 0. : v.az[0];
-    if (prog.gr_op >= 0) {
+    if (t == 0) {
+        if (S.m != 0.) { hc->head[0][0] = S.x; hc->head[0][1] = S.y; hc->head[0][2] = S.z; hc->head[0][3] = S.m; }
+        hc->nheadm = S.m != 0. ? 1 : 0;
+        hc->head0 = S.m != 0. ? 0 : -1;
+        // In a stepping run the acceleration of body 0 starts from zero whatever the column holds (the columns of
+        // the bodies behind it are neither read nor written there).
+        double a0x = star != nullptr ? 0. : v.ax[0], a0y = star != nullptr ? 0. : v.ay[0], a0z = star != nullptr ? 0. : v.az[0];
+        if (prog.gr_op >= 0) {
 #pragma clang fp contract(off)
-        const double eta = S.m, ei = 1. / eta;
-        hc->gr_c[0] = (eta * S.x) * ei;  hc->gr_c[1] = (eta * S.y) * ei;  hc->gr_c[2] = (eta * S.z) * ei;
-        hc->gr_c[3] = (eta * S.vx) * ei; hc->gr_c[4] = (eta * S.vy) * ei; hc->gr_c[5] = (eta * S.vz) * ei;
-        hc->gr_c[6] = (eta * 0.) * ei;   hc->gr_c[7] = (eta * 0.) * ei;   hc->gr_c[8] = (eta * 0.) * ei;
-        hc->gr_mu = prog.G * S.m;
-        // what the back-transformation of an empty Jacobi chain leaves on the body: zero (NaN for a massless one)
-        const double na0 = ((0. * eta) * ei);
-        a0x += na0; a0y += na0; a0z += na0;
-        if (star == nullptr) { v.ax[0] = a0x; v.ay[0] = a0y; v.az[0] = a0z; }
-    }
-    if (prog.mofcom_op >= 0) {
-        Com c = {0., 0., 0., 0., 0., 0., 0.};
-        com_add(c, S);
-        hc->com[0] = c.x; hc->com[1] = c.y; hc->com[2] = c.z;
-        hc->com[3] = c.vx; hc->com[4] = c.vy; hc->com[5] = c.vz; hc->com[6] = c.m;
-        hc->nbary = 0;
+            const double eta = S.m, ei = 1. / eta;
+            hc->gr_c[0] = (eta * S.x) * ei;  hc->gr_c[1] = (eta * S.y) * ei;  hc->gr_c[2] = (eta * S.z) * ei;
+            hc->gr_c[3] = (eta * S.vx) * ei; hc->gr_c[4] = (eta * S.vy) * ei; hc->gr_c[5] = (eta * S.vz) * ei;
+            hc->gr_c[6] = (eta * 0.) * ei;   hc->gr_c[7] = (eta * 0.) * ei;   hc->gr_c[8] = (eta * 0.) * ei;
+            hc->gr_mu = prog.G * S.m;
+            // what the back-transformation of an empty Jacobi chain leaves on the body: zero (NaN for a massless one)
+            const double na0 = ((0. * eta) * ei);
+            a0x += na0; a0y += na0; a0z += na0;
+            if (star == nullptr) { v.ax[0] = a0x; v.ay[0] = a0y; v.az[0] = a0z; }
+        }
+        if (prog.mofcom_op >= 0) {
+            Com c = {0., 0., 0., 0., 0., 0., 0.};
+            com_add(c, S);
+            hc->com[0] = c.x; hc->com[1] = c.y; hc->com[2] = c.z;
+            hc->com[3] = c.vx; hc->com[4] = c.vy; hc->com[5] = c.vz; hc->com[6] = c.m;
+            hc->nbary = 0;
+        }
+        if (star != nullptr) {
+            star[0] = S.x; star[1] = S.y; star[2] = S.z; star[3] = S.vx; star[4] = S.vy; star[5] = S.vz;
+            star[9] = a0x; star[10] = a0y; star[11] = a0z; star[12] = prog.G * S.m;
+        }
     }
     if (star != nullptr) {
 #pragma clang fp contract(off)
-        star[0] = S.x; star[1] = S.y; star[2] = S.z; star[3] = S.vx; star[4] = S.vy; star[5] = S.vz;
-        star[9] = a0x; star[10] = a0y; star[11] = a0z; star[12] = prog.G * S.m;
-        v.ax[0] = 0.; v.ay[0] = 0.; v.az[0] = 0.;
         const double nx = S.x + h * S.vx, ny = S.y + h * S.vy, nz = S.z + h * S.vz;
-        const_cast<double*>(v.x)[0] = nx; const_cast<double*>(v.y)[0] = ny; const_cast<double*>(v.z)[0] = nz;
-        star[6] = nx; star[7] = ny; star[8] = nz;
+        if (t == 0) {
+            star[6] = nx; star[7] = ny; star[8] = nz;
+            if (write_row) {
+                v.ax[0] = 0.; v.ay[0] = 0.; v.az[0] = 0.;
+                const_cast<double*>(v.x)[0] = nx; const_cast<double*>(v.y)[0] = ny; const_cast<double*>(v.z)[0] = nz;
+            }
+        }
+        S.x = nx; S.y = ny; S.z = nz;
     }
+}
+__device__ __forceinline__ void head_one_body(const View& v, const Program& prog, HeadConsts* hc, double* star, double h, const int t,
+                                              double* lead = nullptr, double h_lead = 0.) {
+    Src S;
+    load_src(v, 0, S);                                  // every lane reads the same body
+    head_one_core(v, prog, hc, star, h, t, lead, h_lead, S, true);
 }
 __global__ __launch_bounds__(64) void head_one_kernel(View v, Program prog, HeadConsts* hc, double* star, double h, double* lead, double h_lead) {
     head_one_body(v, prog, hc, star, h, threadIdx.x, lead, h_lead);
+}
+// The one-body head passes of nsub consecutive steps of a Wisdom-Holman run, one after the other in one wavefront (body 0
+// carried in registers): tables hc[j] and records star[16 j] for step j; body 0 drifts over h after every step but the
+// last of the batch, over h_last after that one.  What a pass needs to carry nsub steps of every massless body.
+__global__ __launch_bounds__(64) void head_one_batch_kernel(View v, Program prog, HeadConsts* hc, double* star, int nsub, double h, double h_last,
+                                                            double* lead, double h_lead) {
+    Src S;
+    load_src(v, 0, S);
+    for (int j = 0; j < nsub; j++)
+        head_one_core(v, prog, hc + j, star + 16 * j, j + 1 < nsub ? h : h_last, threadIdx.x, j == 0 ? lead : nullptr, h_lead, S, j + 1 == nsub);
 }
 
 // ------------------------------------------------------------------ streaming kernel
@@ -753,7 +777,7 @@ __global__ __launch_bounds__(BLOCK, (BACKREACT && SIG == 0ull) ? 2 : (!EXACT && 
         }
     }
 
-    if (EPI == EPI_WH && step.star0 != nullptr) {
+    if ((EPI == EPI_WH || EPI == EPI_WHB) && step.star0 != nullptr) {
         // first step of a run: the leading half drift, ahead of the forces
 #pragma unroll
         for (int k = 0; k < 2; k++) {
@@ -761,6 +785,44 @@ __global__ __launch_bounds__(BLOCK, (BACKREACT && SIG == 0ull) ? 2 : (!EXACT && 
             double s[6] = {p[k].x, p[k].y, p[k].z, p[k].vx, p[k].vy, p[k].vz};
             wh_kick_drift<EXACT, false>(s, 0., 0., 0., step.h0, 0., step.star0);
             p[k].x = s[0]; p[k].y = s[1]; p[k].z = s[2]; p[k].vx = s[3]; p[k].vy = s[4]; p[k].vz = s[5];
+        }
+    }
+    if constexpr (EPI == EPI_WHB && !BACKREACT) {
+        {
+            // A batch of steps: the bodies of this thread go through all of them in registers.
+            for (int j = 0; j < step.nsub; j++) {
+                const HeadConsts* __restrict__ tj = step.tabs + j;
+                const double* __restrict__ sj = step.star + 16 * j;
+                const double hj = j + 1 < step.nsub ? step.h_sub : step.h;
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    if (!(k ? act1 : act0)) continue;
+                    V3 a = {0., 0., 0.};
+                    tail_particle<EXACT, SIG>(prog, tj, p[k], a, status);
+                    double s[6] = {p[k].x, p[k].y, p[k].z, p[k].vx, p[k].vy, p[k].vz};
+                    wh_kick_drift<EXACT, true>(s, a.x, a.y, a.z, hj, step.dtk, sj);
+                    p[k].x = s[0]; p[k].y = s[1]; p[k].z = s[2]; p[k].vx = s[3]; p[k].vy = s[4]; p[k].vz = s[5];
+                }
+            }
+            double* const px = const_cast<double*>(v.x); double* const py = const_cast<double*>(v.y); double* const pz = const_cast<double*>(v.z);
+            double* const pvx = const_cast<double*>(v.vx); double* const pvy = const_cast<double*>(v.vy); double* const pvz = const_cast<double*>(v.vz);
+            if (full) {
+                d2v t;
+                t.x = p[0].x; t.y = p[1].x; __builtin_nontemporal_store(t, reinterpret_cast<d2v*>(px + i0));
+                t.x = p[0].y; t.y = p[1].y; __builtin_nontemporal_store(t, reinterpret_cast<d2v*>(py + i0));
+                t.x = p[0].z; t.y = p[1].z; __builtin_nontemporal_store(t, reinterpret_cast<d2v*>(pz + i0));
+                t.x = p[0].vx; t.y = p[1].vx; __builtin_nontemporal_store(t, reinterpret_cast<d2v*>(pvx + i0));
+                t.x = p[0].vy; t.y = p[1].vy; __builtin_nontemporal_store(t, reinterpret_cast<d2v*>(pvy + i0));
+                t.x = p[0].vz; t.y = p[1].vz; __builtin_nontemporal_store(t, reinterpret_cast<d2v*>(pvz + i0));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    if (!(k ? act1 : act0)) continue;
+                    const long long i = i0 + k;
+                    px[i] = p[k].x; py[i] = p[k].y; pz[i] = p[k].z; pvx[i] = p[k].vx; pvy[i] = p[k].vy; pvz[i] = p[k].vz;
+                }
+            }
+            return;
         }
     }
     double orig[2][3], fin[2][3];           // implicit midpoint: velocities at the start of the step, current estimate of the final ones
@@ -1074,6 +1136,13 @@ hipError_t launch_head(const View& v, const Program& prog, HeadConsts* hc, unsig
     return hipGetLastError();
 }
 
+hipError_t launch_head_batch(const View& v, const Program& prog, HeadConsts* hc, double* star, int nsub, double h, double h_last, double* lead,
+                             double h_lead, hipStream_t st) {
+    if (nsub < 1 || v.n < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(head_one_batch_kernel, dim3(1), dim3(64), 0, st, v, prog, hc, star, nsub, h, h_last, lead, h_lead);
+    return hipGetLastError();
+}
+
 template <bool EXACT, bool BACKREACT>
 static void launch_stream_cols(dim3 g, dim3 b, hipStream_t st, bool vec2, bool fixed, int cols, const View& v, const Program& prog, long long lo,
                                long long base, const HeadConsts* hc, double* partials, unsigned* status, const StepArgs* step) {
@@ -1095,6 +1164,7 @@ static void launch_stream_cols(dim3 g, dim3 b, hipStream_t st, bool vec2, bool f
       if (sig == S_) { hipLaunchKernelGGL((stream_kernel<EXACT, false, true, sig_cols(S_, true) | COL_VEL, S_, E>), g, b, 0, st, v, prog, lo, base, hc, partials, status, sa); return; } }
             switch (sa.epi) {
             case EPI_WH: EPILOGUE(EPI_WH)
+            case EPI_WHB: EPILOGUE(EPI_WHB)
             case EPI_EULER: EPILOGUE(EPI_EULER)
             case EPI_RK2: EPILOGUE(EPI_RK2)
             case EPI_RK4: EPILOGUE(EPI_RK4)

@@ -187,6 +187,10 @@ class Context:
         integrate_force, the last pass of a prefix-sum force in apply; default) or every pass runs on its own."""
         self._check(lib.rebxamd_carried_steps(self._h, 1 if on else 0))
 
+    def wh_batch(self, steps_per_pass=32):
+        """Steps that one pass of wh_steps carries for every massless body behind a single massive one (1: one pass per step)."""
+        self._check(lib.rebxamd_wh_batch(self._h, int(steps_per_pass)))
+
     def timing_read(self):
         ms, cnt = ctypes.c_double(0), ctypes.c_int(0)
         self._check(lib.rebxamd_timing_read(self._h, ctypes.byref(ms), ctypes.byref(cnt)))

@@ -335,3 +335,31 @@ def test_open_run_contract(ctx):
         assert ei.value.code == 3
     ctx.wh_steps(dp.view(), ops, 0.05, 2)                        # no run is left open by a refused begin
     assert np.isfinite(state_of(dp)).all()
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("forces", [C5_STACK, C2_STACK, [("gr", {"c": C})]], ids=["five-effects", "rad+harmonics+gr", "gr"])
+@pytest.mark.parametrize("n", [2, 3, 1500, 4099])
+def test_batches_of_steps_in_one_pass_equal_one_pass_per_step(ctx, n, forces, mode):
+    """Behind a single massive body every massless body can go through a batch of steps in registers (rebxamd_wh_batch).  The
+    operations on each body are those of one pass per step, in the same order, with the same tables: the states agree to the
+    bit in both arithmetic modes, whatever the batch length and however the run length falls on it."""
+    dt = 0.05
+    cols, pp, _ = synthetic.disk(n, 0)
+    cols["vx"][0], cols["vy"][0] = 1e-3, -2e-3
+    ops = build_ops(forces, pp)
+    try:
+        for steps in (1, 2, 5, 8, 9, 13):
+            ctx.wh_batch(1)
+            one = device_particles(cols, pp)
+            ctx.wh_steps(one.view(), ops, dt, steps, mode)
+            want = state_of(one)
+            for batch in (2, 4, 32):
+                ctx.wh_batch(batch)
+                dp = device_particles(cols, pp)
+                ctx.wh_steps(dp.view(), ops, dt, steps, mode)
+                got = state_of(dp)
+                assert np.isfinite(got).all()
+                assert np.array_equal(got, want), (steps, batch)
+    finally:
+        ctx.wh_batch(32)
