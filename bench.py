@@ -114,6 +114,18 @@ def grfull_section(ctx, n, mode=0, dist=None, device="cuda:0"):
                          "frac": flops / dt / 1e12 / peak}}
 
 
+WH_BATCH = 32                       # the library's default steps per pass of a queued Wisdom-Holman run
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4     # wave64 vector instructions per second: 1024 SIMDs, one instruction per 4 cycles at 2.4 GHz
+
+
+def valu_issue_roofline(instructions_per_wave_step, n, seconds_per_step):
+    """Vector-issue roofline of a stepping pass that keeps its bodies in registers over a batch of steps."""
+    waves = (n + 127) // 128
+    achieved = instructions_per_wave_step * waves / seconds_per_step
+    return {"bound": "fp64-valu-issue", "achieved": achieved / 1e9, "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave-instructions/s",
+            "frac": achieved / VALU_ISSUE_PEAK, "instructions_per_wave_and_step": instructions_per_wave_step}
+
+
 def c5_section(ctx, n, steps, mode, device):
     """Secondary metric: end-to-end device-resident run -- star + n massless grains, five stacked
     effects in the kick of a Wisdom-Holman step, particle and parameter columns resident in HBM.
@@ -162,15 +174,16 @@ def c5_section(ctx, n, steps, mode, device):
         raise RuntimeError("rebxamd_wh_run_*: %d" % rc)
     x = dp.cols["x"]
     finite = bool(torch.isfinite(x).all().item())
-    # per queued step one pass over the grains carries forces, kick and drift: positions, velocities, beta and the three
-    # timescales read (80 B), positions and velocities written (48 B); the accelerations stay in registers.  (R_tides, k1
-    # and the mass of a massless grain are not needed: tides_precession skips massless bodies, src/tides_precession.c:84-87.)
-    bytes_per_step = 128 * n
-    out = {"n": n, "steps": steps, "effects": 5, "us_per_step_host_synced": synced * 1e6, "us_per_step_host_synced_open_run": synced_open * 1e6,
-           "us_per_step_queued": queued * 1e6,
+    # Queued steps run in batches (rebxamd_wh_batch, 32 by default): one pass takes every grain through the steps of a batch in
+    # registers -- positions, velocities, beta and the three timescales read (80 B) and positions and velocities written
+    # (48 B) once per BATCH, i.e. 4 B per grain and step -- so the pass is bound by fp64 vector issue, not by memory.
+    # Instructions per wavefront (128 grains) and step from SQ_INSTS_VALU / SQ_WAVES (scripts/pmc_wh.sh): 729 for this stack.
+    # A wave64 vector instruction occupies its SIMD for 4 cycles (more for the quarter-rate reciprocals and square roots).
+    out = {"n": n, "steps": steps, "effects": 5, "steps_per_pass": WH_BATCH, "us_per_step_host_synced": synced * 1e6,
+           "us_per_step_host_synced_open_run": synced_open * 1e6, "us_per_step_queued": queued * 1e6,
            "particle_steps_per_s": n / queued, "state_finite": finite,
-           "roofline": {"bound": "hbm", "achieved": bytes_per_step / queued / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": bytes_per_step / queued / 1e9 / HBM_PEAK_GBS}}
+           "hbm_bytes_per_particle_step": 128. / WH_BATCH,
+           "roofline": valu_issue_roofline(729, n, queued)}
     # the shape of BASELINE configuration 1 (star + planet + grains under radiation forces) at this size: the massive head steps in
     # Jacobi coordinates in one wavefront (three small launches per step), the grains in the same kind of pass, which also adds the
     # pull of both head bodies; positions, velocities and beta read (56 B), positions and velocities written (48 B)
@@ -190,8 +203,9 @@ def c5_section(ctx, n, steps, mode, device):
     q1 = (time.perf_counter() - t0) / steps1
     out["star_planet_grains"] = {"n": n, "steps": steps1, "effects": 1, "us_per_step_queued": q1 * 1e6, "particle_steps_per_s": n / q1,
                                  "state_finite": bool(torch.isfinite(dq.cols["x"]).all().item()),
-                                 "roofline": {"bound": "hbm", "achieved": 104 * n / q1 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                              "frac": 104 * n / q1 / 1e9 / HBM_PEAK_GBS}}
+                                 "steps_per_pass": WH_BATCH, "hbm_bytes_per_particle_step": 104. / WH_BATCH,
+                                 # (775 instructions per wavefront and step: radiation + the pull of both head bodies + the Jacobi term + the drift)
+                                 "roofline": valu_issue_roofline(775, n, q1)}
     return out
 
 

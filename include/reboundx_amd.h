@@ -601,12 +601,13 @@ int rebxamd_fixed_stacks(rebxamd_ctx* ctx, int on);
  * Both compute the same expressions (the order of the additions into a_i differs at rounding
  * level in the rebxamd_apply case). */
 int rebxamd_carried_steps(rebxamd_ctx* ctx, int on);
-/* Steps per pass of rebxamd_wh_steps for one massive body followed by massless ones (no counterpart in the reference).
- * The massless bodies are independent of one another and body 0 of them, so one pass can take each of them through a
- * batch of steps in registers once the head passes of those steps have been made (one wavefront, one after the other):
- * positions and velocities then make one round trip through memory per batch instead of one per step, and the run is
- * bound by arithmetic instead of memory.  The operations on every body, and so the results, are those of one pass per
- * step.  1 <= steps_per_pass <= 64; default 32; 1 = one pass per step. */
+/* Steps per pass of rebxamd_wh_steps over the massless bodies behind the massive head (no counterpart in the reference).
+ * The massless bodies feel the head but not one another, so one pass can take each of them through a batch of steps in
+ * registers once the head has gone through those steps (one wavefront, one step after the other; the tables and the frame
+ * record of every step are kept): positions and velocities then make one round trip through memory per batch instead of
+ * one per step, and the run is bound by arithmetic instead of memory.  The operations on every body, and so the results,
+ * are those of one pass per step, bit for bit.  Applies to a head of one body and to star + planets alike.
+ * 1 <= steps_per_pass <= 64; default 32; 1 = one pass per step. */
 int rebxamd_wh_batch(rebxamd_ctx* ctx, int steps_per_pass);
 int rebxamd_timing_read(rebxamd_ctx* ctx, double* total_ms, int* launches);
 

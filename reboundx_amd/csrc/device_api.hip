@@ -354,7 +354,11 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
             // tables of this step; the head's own Wisdom-Holman step (gravity among its bodies, Jacobi kick, drift to the
             // next force evaluation) follows and records the frame of the massless bodies for the pass below -- unless the
             // pass of the step before has already done both in its extra workgroup
-            if (!step->head_ready) {
+            if (step->nsub > 1) {
+                // a batch of steps in one pass: the head passes and head steps of all of them first, in one wavefront
+                HIP_TRY(launch_wh_head_batch(v, prog, const_cast<HeadConsts*>(step->tabs), ctx->status, K, step->dtk, ctx->whead, const_cast<double*>(step->star),
+                                             step->nsub, step->h_sub, step->h, exact, st));
+            } else if (!step->head_ready) {
                 HIP_TRY(launch_head(v, prog, hc, ctx->status, exact, st));
                 HIP_TRY(launch_wh_head_step(v, K, prog.G, step->dtk, step->h, ctx->whead, const_cast<double*>(step->star), exact, st));
             }
@@ -862,6 +866,13 @@ extern "C" int rebxamd_wh_drift(rebxamd_ctx* ctx, const rebxamd_view* view, doub
 
 constexpr int kMaxWhBatch = 64;
 
+// tables and records of the steps of a batch
+static int ensure_wh_batch(rebxamd_ctx* ctx) {
+    if (!ctx->hc_batch) HIP_TRY(hipMalloc((void**)&ctx->hc_batch, (size_t)kMaxWhBatch * sizeof(HeadConsts)));
+    if (!ctx->star_batch) HIP_TRY(hipMalloc((void**)&ctx->star_batch, (size_t)kMaxWhBatch * 16 * sizeof(double)));
+    return REBXAMD_OK;
+}
+
 extern "C" int rebxamd_wh_batch(rebxamd_ctx* ctx, int steps_per_pass) {
     if (!ctx) return REBXAMD_ERR_ARG;
     if (steps_per_pass < 1 || steps_per_pass > kMaxWhBatch) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_batch: between 1 and 64 steps per pass");
@@ -901,6 +912,31 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
         // step of step k + 1 (they never read a massless body) into the other copy of the tables and of the record: one launch
         // per step after the first.
         const bool chain = ctx->carried_steps && view->n > K;
+        // The massless bodies feel the head but not one another: once the head has gone through a batch of steps (one
+        // wavefront, tables and frame record of every step kept), one pass takes every massless body through the same steps
+        // in registers, as behind a single massive body.
+        const int batch = (chain && ctx->wh_batch > 1 && !ctx->fixed_scratch) ? ctx->wh_batch : 1;
+        if (batch > 1 && nsteps > 1) {
+            rc = ensure_wh_batch(ctx);
+            if (rc != REBXAMD_OK) return rc;
+            for (int64_t k = 0; k < nsteps;) {
+                const int nsub = (int)(nsteps - k < batch ? nsteps - k : batch);
+                const bool ends = k + nsub == nsteps;
+                StepArgs sa = {ends ? 0.5 * dt : dt, dt, ctx->star_batch, EPI_WHB, 0., 0., 0., {nullptr, nullptr, nullptr}, nullptr, k == 0 ? lead : nullptr, 0.5 * dt, {}};
+                sa.wh_head = (int)K;
+                sa.jac = ctx->whead;
+                sa.nsub = nsub; sa.h_sub = dt; sa.tabs = ctx->hc_batch;
+                if (nsub == 1) {            // a last batch of one step is an ordinary pass behind a head pass and a head step of their own
+                    sa.nsub = 0; sa.tabs = nullptr; sa.star = ctx->star; sa.epi = EPI_WH;
+                    ctx->hc_stage = 0;
+                }
+                rc = run_streaming(ctx, view, ops, 0, nops, mode, st, -1, nullptr, false, &sa);
+                if (rc == STEP_NOT_CARRIED) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_steps: the force stack cannot ride in one pass over this layout");
+                if (rc != REBXAMD_OK) return rc;
+                k += nsub;
+            }
+            return REBXAMD_OK;
+        }
         for (int64_t k = 0; k < nsteps; k++) {
             const double h = k + 1 < nsteps ? dt : 0.5 * dt;
             const int cur = chain ? (int)(k & 1) : 0, nxt = cur ^ 1;
@@ -952,10 +988,8 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
         // head passes of those steps (tables, records of body 0) have been made, one after the other in one wavefront.
         const int batch = (chain && ctx->wh_batch > 1 && !ctx->fixed_scratch) ? ctx->wh_batch : 1;
         if (batch > 1 && nsteps > 1) {
-            if (!ctx->hc_batch) {
-                HIP_TRY(hipMalloc((void**)&ctx->hc_batch, (size_t)kMaxWhBatch * sizeof(HeadConsts)));
-                HIP_TRY(hipMalloc((void**)&ctx->star_batch, (size_t)kMaxWhBatch * 16 * sizeof(double)));
-            }
+            rc = ensure_wh_batch(ctx);
+            if (rc != REBXAMD_OK) return rc;
             for (int64_t k = 0; k < nsteps;) {
                 const int nsub = (int)(nsteps - k < batch ? nsteps - k : batch);
                 const bool ends = k + nsub == nsteps;

@@ -88,7 +88,7 @@ struct HeadConsts {
 //   EPI_APPLY (any-mass-layout pass, default arithmetic) the last pass of a prefix-sum force rides along:
 //             a_i also receives aJ_i minus the reactions of the bodies k >= i (scan_kernels.hip, pass 5),
 //             so the accelerations make one round trip for the streaming forces and that force together
-//   EPI_WHB   (one-body head) nsub consecutive Wisdom-Holman steps of every body, which stays in registers in between;
+//   EPI_WHB   nsub consecutive Wisdom-Holman steps of every body, which stays in registers in between;
 //             an instance of its own so that the one-step pass keeps its register allocation
 enum { EPI_NONE = 0, EPI_WH = 1, EPI_EULER = 2, EPI_RK2 = 3, EPI_RK4 = 4, EPI_IM = 5, EPI_APPLY = 6, EPI_WHB = 7 };
 // What the per-body pass of a prefix-sum force leaves for the pass that applies it: the force in the body's
@@ -131,6 +131,9 @@ hipError_t launch_head(const View& v, const Program& prog, HeadConsts* hc, unsig
 // the one-body head passes of nsub consecutive Wisdom-Holman steps (tables hc[j], records star + 16 j); see head_one_batch_kernel
 hipError_t launch_head_batch(const View& v, const Program& prog, HeadConsts* hc, double* star, int nsub, double h, double h_last, double* lead,
                              double h_lead, hipStream_t st);
+// star + planets: head passes and head steps of nsub consecutive Wisdom-Holman steps (tables hc[j], frame records star + 16 j); see wh_head_batch_kernel
+hipError_t launch_wh_head_batch(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, long long K, double dtk, double* jac, double* star,
+                                int nsub, double h, double h_last, bool exact, hipStream_t st);
 hipError_t launch_stream(const View& v, const Program& prog, long long lo, const HeadConsts* hc, double* partials,
                          int* nblocks_out, bool backreact, bool exact, bool vec2, bool fixed, unsigned* status, hipStream_t st,
                          const StepArgs* step = nullptr);

@@ -799,6 +799,7 @@ __global__ __launch_bounds__(BLOCK, (BACKREACT && SIG == 0ull) ? 2 : (!EXACT && 
                     if (!(k ? act1 : act0)) continue;
                     V3 a = {0., 0., 0.};
                     tail_particle<EXACT, SIG>(prog, tj, p[k], a, status);
+                    if (step.wh_head > 1) wh_head_pull<EXACT>(tj, prog.G, sj, p[k], a);
                     double s[6] = {p[k].x, p[k].y, p[k].z, p[k].vx, p[k].vy, p[k].vz};
                     wh_kick_drift<EXACT, true>(s, a.x, a.y, a.z, hj, step.dtk, sj);
                     p[k].x = s[0]; p[k].y = s[1]; p[k].z = s[2]; p[k].vx = s[3]; p[k].vy = s[4]; p[k].vz = s[5];
@@ -1140,6 +1141,31 @@ hipError_t launch_head_batch(const View& v, const Program& prog, HeadConsts* hc,
                              double h_lead, hipStream_t st) {
     if (nsub < 1 || v.n < 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL(head_one_batch_kernel, dim3(1), dim3(64), 0, st, v, prog, hc, star, nsub, h, h_last, lead, h_lead);
+    return hipGetLastError();
+}
+
+// Star + planets: the head passes and the head's own Wisdom-Holman steps of nsub consecutive steps, one after the other in one
+// wavefront (lane = head body; every lane reads back only what it has stored itself): tables hc[j] and frame records
+// star[16 j] of step j, the head's state after the batch in the columns and in `jac`.  The head drifts over h after every
+// step but the last of the batch, over h_last after that one.
+template <bool EXACT>
+__global__ __launch_bounds__(64) void wh_head_batch_kernel(View v, Program prog, HeadConsts* hc, unsigned* status, int K, double dtk, double* jac,
+                                                           double* star, int nsub, double h, double h_last) {
+    __shared__ HeadShared hsh;
+    __shared__ WhHeadShared wsh;
+    const int t = threadIdx.x;
+    for (int j = 0; j < nsub; j++) {
+        head_body<EXACT>(v, prog, hc + j, status, nullptr, 0., hsh, t);
+        wh_head_step_body<EXACT>(v, K, prog.G, dtk, j + 1 < nsub ? h : h_last, jac, star + 16 * j, wsh, t);
+        __syncthreads();
+    }
+}
+
+hipError_t launch_wh_head_batch(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, long long K, double dtk, double* jac, double* star,
+                                int nsub, double h, double h_last, bool exact, hipStream_t st) {
+    if (nsub < 1 || K < 2 || K > REBXAMD_MAX_HEAD || K > v.n) return hipErrorInvalidValue;
+    if (exact) hipLaunchKernelGGL(wh_head_batch_kernel<true>, dim3(1), dim3(64), 0, st, v, prog, hc, status, (int)K, dtk, jac, star, nsub, h, h_last);
+    else hipLaunchKernelGGL(wh_head_batch_kernel<false>, dim3(1), dim3(64), 0, st, v, prog, hc, status, (int)K, dtk, jac, star, nsub, h, h_last);
     return hipGetLastError();
 }
 

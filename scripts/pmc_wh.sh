@@ -1,22 +1,30 @@
 #!/bin/bash
 # Instruction mix of the pass that carries a Wisdom-Holman step (one PMC pass; GPU box, repository root).
-# usage: bash scripts/pmc_wh.sh [grains]
+# usage: bash scripts/pmc_wh.sh [grains] [steps of the queued run]
+# Dispatches of one kernel are grouped by their instruction count: a pass that carries a batch of steps issues in
+# proportion to the steps of its batch.
 set -e
 ROOT="$(pwd)"
 OUT="$ROOT/gpurun_out"
 N=${1:-10000000}
+STEPS=${2:-40}
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d "$OUT/prof_wh" -o wh -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu --grfull-n 0 --c3-n 0 --c3-big-n 0 --ooc-n 0 --c5-n $N --c5-steps 40 > "$OUT/prof_wh.log" 2>&1
+timeout -s KILL 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d "$OUT/prof_wh" -o wh -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu --grfull-n 0 --c3-n 0 --c3-big-n 0 --ooc-n 0 --c5-n $N --c5-steps $STEPS > "$OUT/prof_wh.log" 2>&1
 python3 - "$OUT" <<'P'
 import collections, csv, glob, sys
 out = sys.argv[1]
 cc = glob.glob(out + "/prof_wh/**/*counter_collection.csv", recursive=True)[0]
-acc = collections.defaultdict(lambda: collections.defaultdict(list))
+per = collections.defaultdict(dict)
 for r in csv.DictReader(open(cc)):
     k = r["Kernel_Name"]
     if "stream_kernel" not in k: continue
-    acc[k[:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    if r["Counter_Name"] == "SQ_WAVES": acc[k[:70]]["dur"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    d = per[(k, r["Dispatch_Id"])]
+    d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.) + float(r["Counter_Value"])
+    d["dur"] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for (k, _), d in per.items():
+    key = "%s | %d VALU/wave" % (k[-60:], round(d["SQ_INSTS_VALU"] / d["SQ_WAVES"] / 50.) * 50)
+    for c, v in d.items(): acc[key][c].append(v)
 for k, d in acc.items():
     m = {c: sum(v) / len(v) for c, v in d.items()}
     print(k, "n=%d dur %.1f us" % (len(d["SQ_WAVES"]), m["dur"] / 1e3))

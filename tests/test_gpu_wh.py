@@ -363,3 +363,36 @@ def test_batches_of_steps_in_one_pass_equal_one_pass_per_step(ctx, n, forces, mo
                 assert np.array_equal(got, want), (steps, batch)
     finally:
         ctx.wh_batch(32)
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("forces", [[], C5_STACK, [("radiation_forces", {"c": C})], [("modify_orbits_forces", {"coordinates": 1}), ("gr_potential", {"c": C})]],
+                         ids=["force-free", "five-effects", "radiation", "barycentric-drag+gr_potential"])
+@pytest.mark.parametrize("n,n_planets", [(4, 2), (1500, 1), (4099, 6)])
+def test_batches_of_steps_behind_star_and_planets_equal_one_pass_per_step(ctx, n, n_planets, forces, mode):
+    """The same behind a head of several massive bodies: the head goes through the steps of a batch first (one wavefront, the
+    tables and the frame record of every step kept), then one pass takes every massless body through them.  Same operations
+    per body as one pass per step: the same bits, head bodies included."""
+    dt = 0.05
+    cols, pp, _ = synthetic.disk(n, n_planets)
+    cols["vx"][0], cols["vy"][0] = 1e-3, -2e-3
+    host = dict(cols)
+    for k in ("beta", "R_tides", "k1", "tau_a", "tau_e", "tau_inc"):
+        host[k] = pp[k]
+    ops = build_ops(forces, pp)
+    try:
+        for steps in (1, 2, 7, 9):
+            ctx.wh_batch(1)
+            one = DeviceParticles.from_host(host, device="cuda:0", n_head=n_planets + 1, tail_massless=True)
+            ctx.wh_steps(one.view(), ops, dt, steps, mode)
+            want = state_of(one)
+            for batch in (2, 4, 32):
+                ctx.wh_batch(batch)
+                dp = DeviceParticles.from_host(host, device="cuda:0", n_head=n_planets + 1, tail_massless=True)
+                ctx.wh_steps(dp.view(), ops, dt, steps, mode)
+                got = state_of(dp)
+                assert np.isfinite(got).all()
+                assert np.array_equal(got, want), (steps, batch)
+                assert float(np.abs(np.array(dp.acc_host())[:, :n_planets + 1]).max()) == 0.0
+    finally:
+        ctx.wh_batch(32)
