@@ -355,16 +355,18 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
             // next force evaluation) follows and records the frame of the massless bodies for the pass below -- unless the
             // pass of the step before has already done both in its extra workgroup
             if (step->nsub > 1) {
-                // a batch of steps in one pass: the head passes and head steps of all of them first, in one wavefront
-                HIP_TRY(launch_wh_head_batch(v, prog, const_cast<HeadConsts*>(step->tabs), ctx->status, K, step->dtk, ctx->whead, const_cast<double*>(step->star),
+                // a batch of steps in one pass: the head passes and head steps of all of them first, in one wavefront (unless the
+                // pass of the batch before has made them in its extra workgroup)
+                if (!step->head_ready) HIP_TRY(launch_wh_head_batch(v, prog, const_cast<HeadConsts*>(step->tabs), ctx->status, K, step->dtk, ctx->whead, const_cast<double*>(step->star),
                                              step->nsub, step->h_sub, step->h, exact, st));
             } else if (!step->head_ready) {
                 HIP_TRY(launch_head(v, prog, hc, ctx->status, exact, st));
                 HIP_TRY(launch_wh_head_step(v, K, prog.G, step->dtk, step->h, ctx->whead, const_cast<double*>(step->star), exact, st));
             }
         } else if (wh && step->nsub > 1) {
-            // a batch of steps in one pass: the head passes of all of them first, one after the other in one wavefront
-            HIP_TRY(launch_head_batch(v, prog, const_cast<HeadConsts*>(step->tabs), const_cast<double*>(step->star), step->nsub, step->h_sub, step->h,
+            // a batch of steps in one pass: the head passes of all of them first, one after the other in one wavefront (unless
+            // the pass of the batch before has made them in its extra workgroup)
+            if (!step->head_ready) HIP_TRY(launch_head_batch(v, prog, const_cast<HeadConsts*>(step->tabs), const_cast<double*>(step->star), step->nsub, step->h_sub, step->h,
                                       step->lead_in_head ? const_cast<double*>(step->star0) : nullptr, step->h0, st));
         } else if (!(wh && step->head_ready))
             HIP_TRY(launch_head(v, prog, hc, ctx->status, exact, st, wh ? const_cast<double*>(step->star) : nullptr, wh ? step->h : 0.,
@@ -868,8 +870,9 @@ constexpr int kMaxWhBatch = 64;
 
 // tables and records of the steps of a batch
 static int ensure_wh_batch(rebxamd_ctx* ctx) {
-    if (!ctx->hc_batch) HIP_TRY(hipMalloc((void**)&ctx->hc_batch, (size_t)kMaxWhBatch * sizeof(HeadConsts)));
-    if (!ctx->star_batch) HIP_TRY(hipMalloc((void**)&ctx->star_batch, (size_t)kMaxWhBatch * 16 * sizeof(double)));
+    // (two copies: the pass of one batch fills the tables of the next)
+    if (!ctx->hc_batch) HIP_TRY(hipMalloc((void**)&ctx->hc_batch, 2 * (size_t)kMaxWhBatch * sizeof(HeadConsts)));
+    if (!ctx->star_batch) HIP_TRY(hipMalloc((void**)&ctx->star_batch, 2 * (size_t)kMaxWhBatch * 16 * sizeof(double)));
     return REBXAMD_OK;
 }
 
@@ -919,13 +922,25 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
         if (batch > 1 && nsteps > 1) {
             rc = ensure_wh_batch(ctx);
             if (rc != REBXAMD_OK) return rc;
-            for (int64_t k = 0; k < nsteps;) {
+            bool ready = false;             // this batch's tables were filled by the pass of the batch before
+            for (int64_t k = 0, bi = 0; k < nsteps; bi++) {
                 const int nsub = (int)(nsteps - k < batch ? nsteps - k : batch);
                 const bool ends = k + nsub == nsteps;
-                StepArgs sa = {ends ? 0.5 * dt : dt, dt, ctx->star_batch, EPI_WHB, 0., 0., 0., {nullptr, nullptr, nullptr}, nullptr, k == 0 ? lead : nullptr, 0.5 * dt, {}};
+                const int cur = (int)(bi & 1), nxt = cur ^ 1;
+                StepArgs sa = {ends ? 0.5 * dt : dt, dt, ctx->star_batch + (size_t)cur * kMaxWhBatch * 16, EPI_WHB, 0., 0., 0., {nullptr, nullptr, nullptr}, nullptr,
+                               k == 0 ? lead : nullptr, 0.5 * dt, {}};
                 sa.wh_head = (int)K;
                 sa.jac = ctx->whead;
-                sa.nsub = nsub; sa.h_sub = dt; sa.tabs = ctx->hc_batch;
+                sa.nsub = nsub; sa.h_sub = dt; sa.tabs = ctx->hc_batch + (size_t)cur * kMaxWhBatch;
+                sa.head_ready = ready ? 1 : 0;
+                const int64_t left = nsteps - (k + nsub);
+                ready = false;
+                if (nsub > 1 && left > 1) {     // (a last batch of one step makes its own head pass)
+                    sa.next_nsub = (int)(left < batch ? left : batch);
+                    sa.next_hc = ctx->hc_batch + (size_t)nxt * kMaxWhBatch; sa.next_star = ctx->star_batch + (size_t)nxt * kMaxWhBatch * 16;
+                    sa.next_h = left <= batch ? 0.5 * dt : dt;
+                    ready = true;
+                }
                 if (nsub == 1) {            // a last batch of one step is an ordinary pass behind a head pass and a head step of their own
                     sa.nsub = 0; sa.tabs = nullptr; sa.star = ctx->star; sa.epi = EPI_WH;
                     ctx->hc_stage = 0;
@@ -990,12 +1005,24 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
         if (batch > 1 && nsteps > 1) {
             rc = ensure_wh_batch(ctx);
             if (rc != REBXAMD_OK) return rc;
-            for (int64_t k = 0; k < nsteps;) {
+            bool ready = false;             // this batch's tables were filled by the pass of the batch before
+            for (int64_t k = 0, bi = 0; k < nsteps; bi++) {
                 const int nsub = (int)(nsteps - k < batch ? nsteps - k : batch);
                 const bool ends = k + nsub == nsteps;
-                StepArgs sa = {ends ? 0.5 * dt : dt, dt, ctx->star_batch, EPI_WHB, 0., 0., 0., {nullptr, nullptr, nullptr}, nullptr, k == 0 ? star0 : nullptr, 0.5 * dt, {}};
+                const int cur = (int)(bi & 1), nxt = cur ^ 1;
+                StepArgs sa = {ends ? 0.5 * dt : dt, dt, ctx->star_batch + (size_t)cur * kMaxWhBatch * 16, EPI_WHB, 0., 0., 0., {nullptr, nullptr, nullptr}, nullptr,
+                               k == 0 ? star0 : nullptr, 0.5 * dt, {}};
                 sa.lead_in_head = k == 0 ? 1 : 0;
-                sa.nsub = nsub; sa.h_sub = dt; sa.tabs = ctx->hc_batch;
+                sa.nsub = nsub; sa.h_sub = dt; sa.tabs = ctx->hc_batch + (size_t)cur * kMaxWhBatch;
+                sa.head_ready = ready ? 1 : 0;
+                const int64_t left = nsteps - (k + nsub);
+                ready = false;
+                if (nsub > 1 && left > 1) {     // (a last batch of one step makes its own head pass)
+                    sa.next_nsub = (int)(left < batch ? left : batch);
+                    sa.next_hc = ctx->hc_batch + (size_t)nxt * kMaxWhBatch; sa.next_star = ctx->star_batch + (size_t)nxt * kMaxWhBatch * 16;
+                    sa.next_h = left <= batch ? 0.5 * dt : dt;
+                    ready = true;
+                }
                 if (nsub == 1) {            // a last batch of one step is an ordinary pass; its head pass goes through the same launcher
                     sa.nsub = 0; sa.tabs = nullptr; sa.star = ctx->star; sa.epi = EPI_WH;
                     ctx->hc_stage = 0;

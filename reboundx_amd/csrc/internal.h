@@ -119,7 +119,11 @@ struct StepArgs { double h, dtk; const double* star; int epi; double c0, c1, c2;
                   // registers in between -- the bodies are independent of one another and body 0 of them, so only the tables
                   // (tabs[j]) and records (star + 16 j) change from step to step; the trailing drift is h_sub after every step
                   // but the last of the batch, h after that one
-                  int nsub; double h_sub; const HeadConsts* tabs; };
+                  int nsub; double h_sub; const HeadConsts* tabs;
+                  // EPI_WHB with next_hc set: the extra workgroup of the pass takes the head through the NEXT batch of next_nsub steps
+                  // (tables next_hc[j], records next_star + 16 j; drift over h_sub after every step but the last, next_h after that
+                  // one), so that batch needs no head launch of its own (head_ready)
+                  int next_nsub; };
 
 enum { WARN_GR_ITER = 1u, WARN_GRFULL_SWEEPS = 2u, WARN_IM_ITER = 4u };
 

@@ -721,7 +721,32 @@ __global__ __launch_bounds__(BLOCK, (BACKREACT && SIG == 0ull) ? 2 : (!EXACT && 
     constexpr bool STEP = EPI != EPI_NONE && EPI != EPI_APPLY;        // forces start from zero
     const int tid = threadIdx.x;
     if (EPI == EPI_IM && step.stop != nullptr && *step.stop != 0u) return;      // a round queued past convergence
-    const bool chained = EPI == EPI_WH && step.next_hc != nullptr;
+    const bool chained = (EPI == EPI_WH || EPI == EPI_WHB) && step.next_hc != nullptr;
+    if (EPI == EPI_WHB && chained && blockIdx.x == 0) {
+        // the extra workgroup of a pass that carries a batch of steps: the head goes through the steps of the NEXT batch (it
+        // reads and writes the head bodies, the head's Jacobi state and the other copy of the batch tables, none of which a
+        // workgroup of this pass touches), one wavefront, one step after the other
+        if constexpr (EPI == EPI_WHB) {
+            if (tid >= 64) return;
+            if (step.wh_head > 1) {
+                __shared__ HeadShared hsh;
+                __shared__ WhHeadShared wsh;
+                for (int j = 0; j < step.next_nsub; j++) {
+                    head_body<EXACT>(v, prog, step.next_hc + j, status, nullptr, 0., hsh, tid);
+                    wh_head_step_body<EXACT>(v, step.wh_head, prog.G, step.dtk, j + 1 < step.next_nsub ? step.h_sub : step.next_h, step.jac,
+                                             step.next_star + 16 * j, wsh, tid);
+                    __syncthreads();
+                }
+            } else {
+                Src S;
+                load_src(v, 0, S);
+                for (int j = 0; j < step.next_nsub; j++)
+                    head_one_core(v, prog, step.next_hc + j, step.next_star + 16 * j, j + 1 < step.next_nsub ? step.h_sub : step.next_h, tid, nullptr, 0., S,
+                                  j + 1 == step.next_nsub);
+            }
+        }
+        return;
+    }
     if (chained && blockIdx.x == 0) {
         // the extra workgroup of a Wisdom-Holman pass: the head pass of the next step (it reads and
         // writes the head bodies and the other copy of the tables, which no workgroup of this pass touches).
@@ -1269,7 +1294,7 @@ hipError_t launch_stream(const View& v, const Program& prog, long long lo, const
     if (nb <= 0) return hipSuccess;
     // (large grids are padded to whole groups of 8 * XCD_RUN tiles: see the tile mapping in stream_kernel)
     const unsigned padded = (unsigned)nb >= XCD_REMAP_MIN_TILES ? ((unsigned)nb + 8u * XCD_RUN - 1u) / (8u * XCD_RUN) * (8u * XCD_RUN) : (unsigned)nb;
-    const dim3 g(padded + ((step && step->epi == EPI_WH && step->next_hc != nullptr) ? 1 : 0)), b(BLOCK);
+    const dim3 g(padded + ((step && (step->epi == EPI_WH || step->epi == EPI_WHB) && step->next_hc != nullptr) ? 1 : 0)), b(BLOCK);
     const int cols = (prog.need_vel ? COL_VEL : 0) | (prog.need_beta ? COL_BETA : 0) | (prog.need_tides ? COL_TIDES : 0) | (prog.need_tau ? COL_TAU : 0);
     if (exact) {
         if (backreact) launch_stream_cols<true, true>(g, b, st, vec2, fixed, cols, v, prog, lo, base, hc, partials, status, step);
