@@ -177,13 +177,14 @@ def c5_section(ctx, n, steps, mode, device):
     # Queued steps run in batches (rebxamd_wh_batch, 32 by default): one pass takes every grain through the steps of a batch in
     # registers -- positions, velocities, beta and the three timescales read (80 B) and positions and velocities written
     # (48 B) once per BATCH, i.e. 4 B per grain and step -- so the pass is bound by fp64 vector issue, not by memory.
-    # Instructions per wavefront (128 grains) and step from SQ_INSTS_VALU / SQ_WAVES (scripts/pmc_wh.sh): 729 for this stack.
+    # Instructions per wavefront (128 grains) and step from SQ_INSTS_VALU / SQ_WAVES of a 32-step pass (scripts/pmc_wh.sh 1000000 128):
+    # 22 100 / 32 = 690 for this stack.
     # A wave64 vector instruction occupies its SIMD for 4 cycles (more for the quarter-rate reciprocals and square roots).
     out = {"n": n, "steps": steps, "effects": 5, "steps_per_pass": WH_BATCH, "us_per_step_host_synced": synced * 1e6,
            "us_per_step_host_synced_open_run": synced_open * 1e6, "us_per_step_queued": queued * 1e6,
            "particle_steps_per_s": n / queued, "state_finite": finite,
            "hbm_bytes_per_particle_step": 128. / WH_BATCH,
-           "roofline": valu_issue_roofline(729, n, queued)}
+           "roofline": valu_issue_roofline(690, n, queued)}
     # the shape of BASELINE configuration 1 (star + planet + grains under radiation forces) at this size: the massive head steps in
     # Jacobi coordinates in one wavefront (three small launches per step), the grains in the same kind of pass, which also adds the
     # pull of both head bodies; positions, velocities and beta read (56 B), positions and velocities written (48 B)
@@ -204,8 +205,8 @@ def c5_section(ctx, n, steps, mode, device):
     out["star_planet_grains"] = {"n": n, "steps": steps1, "effects": 1, "us_per_step_queued": q1 * 1e6, "particle_steps_per_s": n / q1,
                                  "state_finite": bool(torch.isfinite(dq.cols["x"]).all().item()),
                                  "steps_per_pass": WH_BATCH, "hbm_bytes_per_particle_step": 104. / WH_BATCH,
-                                 # (775 instructions per wavefront and step: radiation + the pull of both head bodies + the Jacobi term + the drift)
-                                 "roofline": valu_issue_roofline(775, n, q1)}
+                                 # (20 337 / 32 = 635 instructions per wavefront and step: radiation + the pull of both head bodies + the Jacobi term + the drift)
+                                 "roofline": valu_issue_roofline(635, n, q1)}
     return out
 
 
