@@ -262,3 +262,32 @@ def test_smallest_particle_counts_go_through_every_stepping_entry_point(ctx, n):
         got = np.array([dp.cols[k].cpu().numpy() for k in ("x", "y", "z", "vx", "vy", "vz")])
         assert np.isfinite(got).all()
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("integrator", ["euler", "rk4", "implicit_midpoint"])
+def test_grids_large_enough_for_the_xcd_tile_order(ctx, integrator):
+    """From 4096 tiles of 512 bodies on, the streaming pass hands each XCD runs of consecutive tiles instead of tile = blockIdx,
+    and pads its grid to whole groups of runs.  Everything a workgroup leaves behind is indexed by its tile: the carried update
+    equals the separate passes bit for bit (both take the mapped order in their force passes; the partial sums of the
+    implicit scheme's convergence test are per tile), and the explicit scheme equals the checker."""
+    n = 2_150_003                       # 4200 tiles: the last group of runs is mostly padding, the last tile partial
+    cols, pp, _ = synthetic.disk(n, 1)
+    ops = build_ops(C5_STACK, pp)
+    out, rounds = [], []
+    for carried in (True, False):
+        dp = device_state(cols, pp)
+        try:
+            ctx.carried_steps(carried)
+            rounds.append(ctx.integrate_force(dp.view(), ops, integrator, 0.01, EXACT))
+        finally:
+            ctx.carried_steps(True)
+        out.append((vel(dp), np.array(dp.acc_host())))
+        del dp
+    assert rounds[0] == rounds[1]
+    assert np.isfinite(out[0][0]).all()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    if integrator == "euler":
+        ref = oracle.Sim(cols)
+        oracle.integrate_force(ref, integrator, 0.01, C5_STACK, pp)
+        vr = np.array([ref.cols[k] for k in ("vx", "vy", "vz")])
+        assert ulp_diff(out[0][0], vr).max() == 0

@@ -396,3 +396,29 @@ def test_batches_of_steps_behind_star_and_planets_equal_one_pass_per_step(ctx, n
                 assert float(np.abs(np.array(dp.acc_host())[:, :n_planets + 1]).max()) == 0.0
     finally:
         ctx.wh_batch(32)
+
+
+@pytest.mark.parametrize("n_planets", [0, 2])
+def test_batches_on_a_grid_large_enough_for_the_xcd_tile_order(ctx, n_planets):
+    """The same comparison where the pass hands each XCD runs of consecutive tiles (from 4096 tiles of 512 bodies on) and has
+    its extra workgroup in front of a padded grid."""
+    n, dt, steps = 2_150_003, 0.05, 7
+    cols, pp, _ = synthetic.disk(n, n_planets)
+    host = dict(cols)
+    for k in ("beta", "R_tides", "k1", "tau_a", "tau_e", "tau_inc"):
+        host[k] = pp[k]
+    ops = build_ops(C5_STACK, pp)
+    out = []
+    try:
+        for batch in (1, 3):
+            ctx.wh_batch(batch)
+            dp = DeviceParticles.from_host(host, device="cuda:0", n_head=n_planets + 1, tail_massless=True)
+            ctx.wh_steps(dp.view(), ops, dt, steps, 1)
+            out.append(state_of(dp))
+            del dp
+    finally:
+        ctx.wh_batch(32)
+    assert np.isfinite(out[0]).all()
+    assert np.array_equal(out[0], out[1])
+    start = np.array([cols[k] for k in ("x", "y", "z", "vx", "vy", "vz")])
+    assert np.abs(out[0] - start).max() > 0.1
