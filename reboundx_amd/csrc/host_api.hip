@@ -20,11 +20,13 @@
 #include <cfloat>
 #include <climits>
 #include <chrono>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
 #include <vector>
+#include <unistd.h>
 
 #define STRINGIFY2(s) #s
 #define STRINGIFY(s) STRINGIFY2(s)
@@ -184,7 +186,8 @@ double now_ms() {
 }
 
 // Host threads for the array-of-structs <-> column conversions (REBXAMD_HOST_THREADS, default 16,
-// at most 64; never more than the machine has).  Below ~100k particles one thread is faster than starting helpers.
+// at most 64; never more than the machine has): one per 16384 particles of the piece at hand, so that a helper's
+// wake-up (a few microseconds: they are parked, not started, see HostPool) is small against its share of the work.
 int host_threads(int N) {
     static const int configured = [] {
         const char* e = getenv("REBXAMD_HOST_THREADS");
@@ -193,11 +196,18 @@ int host_threads(int N) {
         if (hw > 0 && t > hw) t = hw;
         return t < 1 ? 1 : (t > 64 ? 64 : t);
     }();
-    return N < 100000 ? 1 : configured;
+    const int wanted = N / 16384;
+    return wanted < 2 ? 1 : (wanted < configured ? wanted : configured);
 }
 
-// fn(lo, hi, k) on nt contiguous chunks of [0, N); chunk k runs on its own thread
-constexpr int kPipelineBlock = 1 << 20;     // particles per block of the pack/upload and download/unpack pipelines
+// Particles per block of the pack/upload and download/unpack pipelines: about an eighth of the array, so that from a
+// hundred thousand particles on the copy engine works underneath the host threads, between 64 Ki (below it a block's
+// copies are all latency) and 1 Mi particles (above it nothing more is hidden); a multiple of 8192, which keeps every
+// block of a column 16-byte aligned.
+int pipeline_block(int N) {
+    const long long eighth = ((long long)N / 8 + 8191) / 8192 * 8192;
+    return (int)std::min<long long>(1 << 20, std::max<long long>(1 << 16, eighth));
+}
 
 // Systems this small move as one slab per direction and skip the synchronisations that only
 // separate the phases of rebxamd_last_timings (their enqueue times are reported instead: what
@@ -205,17 +215,81 @@ constexpr int kPipelineBlock = 1 << 20;     // particles per block of the pack/u
 // (Buffers that once held a large system keep their size: then the columns are copied one by one.)
 bool small_system(const Bridge* b, int N) { return N <= 16384 && b->cap <= 32768; }
 
+// Helper threads of the conversions, started once and parked on a condition variable between calls (starting a thread
+// costs tens of microseconds, a conversion of 10^5 particles a hundred).  One job at a time: a caller that finds the
+// pool busy (several simulations stepping on several host threads) starts threads of its own.  The pool is never
+// destroyed -- its threads must not outlive what they wait on at process exit -- and a forked child, which inherits
+// the object but none of the threads, starts afresh.
+class HostPool {
+  public:
+    static HostPool& get() {
+        static HostPool* pool = nullptr;
+        static std::mutex guard;
+        std::lock_guard<std::mutex> lock(guard);
+        if (!pool || pool->pid_ != getpid()) pool = new HostPool;
+        return *pool;
+    }
+    // call(arg, k) for k = 1 .. nt-1 on helpers, k = 0 on the caller; false (nothing done) when the pool is busy
+    bool run(int nt, void (*call)(void*, int), void* arg) {
+        std::unique_lock<std::mutex> busy(run_mu_, std::try_to_lock);
+        if (!busy.owns_lock()) return false;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            while ((int)workers_.size() < nt - 1) {
+                const int k = (int)workers_.size() + 1;
+                workers_.emplace_back([this, k, seen = gen_] { work(k, seen); });
+                workers_.back().detach();
+            }
+            call_ = call; arg_ = arg; njobs_ = nt; pending_ = nt - 1; gen_++;
+        }
+        cv_work_.notify_all();
+        call(arg, 0);
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [this] { return pending_ == 0; });
+        return true;
+    }
+
+  private:
+    HostPool() : pid_(getpid()) {}
+    void work(int k, unsigned long long seen) {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_work_.wait(lk, [&] { return gen_ != seen; });
+            seen = gen_;
+            if (k >= njobs_) continue;
+            void (*const call)(void*, int) = call_;
+            void* const arg = arg_;
+            lk.unlock();
+            call(arg, k);
+            lk.lock();
+            if (--pending_ == 0) cv_done_.notify_one();
+        }
+    }
+    const pid_t pid_;
+    std::mutex run_mu_, mu_;
+    std::condition_variable cv_work_, cv_done_;
+    std::vector<std::thread> workers_;
+    void (*call_)(void*, int) = nullptr;
+    void* arg_ = nullptr;
+    int njobs_ = 0, pending_ = 0;
+    unsigned long long gen_ = 0;
+};
+
+// fn(lo, hi, k) on nt contiguous chunks of [0, N), chunk 0 on the calling thread (every chunk is called, empty ones too)
 template <class Fn> void parallel_chunks(int N, int nt, Fn fn) {
     if (nt <= 1) { fn(0, N, 0); return; }
-    std::vector<std::thread> pool;
-    pool.reserve((size_t)nt - 1);
     const long long per = ((long long)N + nt - 1) / nt;
-    for (int k = 1; k < nt; k++) {
+    auto chunk = [&](int k) {
         const int lo = (int)std::min<long long>(N, k * per), hi = (int)std::min<long long>(N, (k + 1) * per);
-        pool.emplace_back([=] { fn(lo, hi, k); });
-    }
-    fn(0, (int)std::min<long long>(N, per), 0);
-    for (std::thread& t : pool) t.join();
+        fn(lo, hi, k);
+    };
+    using Chunk = decltype(chunk);
+    if (HostPool::get().run(nt, [](void* c, int k) { (*static_cast<Chunk*>(c))(k); }, &chunk)) return;
+    std::vector<std::thread> own;
+    own.reserve((size_t)nt - 1);
+    for (int k = 1; k < nt; k++) own.emplace_back([&chunk, k] { chunk(k); });
+    chunk(0);
+    for (std::thread& t : own) t.join();
 }
 
 }  // namespace
@@ -865,7 +939,7 @@ bool stage_in(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* b, c
     bool ok = true;
     // Large arrays go block by block: while the copy engine uploads one block of the columns, the host
     // threads pack the next one.
-    const int block = small_system(b, N) ? N : kPipelineBlock;
+    const int block = small_system(b, N) ? N : pipeline_block(N);
     unsigned long long sum = 1469598103934665603ull;
     long long last_massive = -1;
     double pack_ms = 0.;
@@ -1013,20 +1087,21 @@ void run_builtin(struct reb_simulation* sim, struct rebx_extras* rebx, const std
     } else {
         // block by block: the host threads scatter one block into the array of structs while the copy
         // engine downloads the next ones (one event per block marks its arrival)
-        const int nblocks = (N + kPipelineBlock - 1) / kPipelineBlock;
+        const int block = pipeline_block(N);
+        const int nblocks = (N + block - 1) / block;
         while ((int)b->block_done.size() < nblocks && ok) {
             hipEvent_t e = nullptr;
             ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
             if (ok) b->block_done.push_back(e);
         }
         for (int blk = 0; blk < nblocks && ok; blk++) {
-            const int b0 = blk * kPipelineBlock, b1 = (N - b0 > kPipelineBlock) ? b0 + kPipelineBlock : N;
+            const int b0 = blk * block, b1 = (N - b0 > block) ? b0 + block : N;
             for (int k = H_AX; k <= H_AZ && ok; k++)
                 ok = hipMemcpyAsync(b->h_dyn[k] + b0, b->d_dyn[k] + b0, (size_t)(b1 - b0) * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess;
             ok = ok && hipEventRecord(b->block_done[blk], st) == hipSuccess;
         }
         for (int blk = 0; blk < nblocks && ok; blk++) {
-            const int b0 = blk * kPipelineBlock, b1 = (N - b0 > kPipelineBlock) ? b0 + kPipelineBlock : N;
+            const int b0 = blk * block, b1 = (N - b0 > block) ? b0 + block : N;
             ok = hipEventSynchronize(b->block_done[blk]) == hipSuccess;
             if (!ok) break;
             parallel_chunks(b1 - b0, host_threads(b1 - b0), [&](int lo, int hi, int) {

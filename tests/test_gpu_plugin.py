@@ -688,3 +688,51 @@ def test_operator_fixture_of_the_reference_runs_through_the_timestep_hooks(name)
     assert np.abs(want - start.T).max() > 1e-7
     sim.free_particle_params()
     del rebx
+
+
+def test_two_simulations_stepping_on_two_host_threads_share_the_helper_threads():
+    """The array-of-structs <-> column conversions run on helper threads that are started once and parked between calls; they
+    take one job at a time, and a caller that finds them busy starts threads of its own.  Two simulations of 3e5 particles
+    evaluated from two host threads at once (ctypes releases the interpreter lock inside the call), several times over, must
+    each get what they get alone -- bit for bit in the reference-order arithmetic -- and a run of calls on one thread after
+    that must still find the helpers alive."""
+    import threading
+    n = 300_000
+    sims = []
+    for seed_shift in (0, 1):
+        cols, pp, _ = synthetic.disk(n, 1)
+        cols["x"][2:] += 1e-3 * seed_shift                     # two different systems
+        synthetic.add_newtonian(cols, n_head=2)
+        sim, arr, view = big_array_sim(cols)
+        for i in (0, 1):
+            arr[i]._sim = ctypes.pointer(sim)
+        rebx = Extras(sim)
+        rebx.set_mode("exact")
+        f = rebx.load_force("gr"); f.params["c"] = C
+        rebx.add_force(f)
+        sims.append((sim, rebx, view, np.array([cols["ax"], cols["ay"], cols["az"]]).T.copy()))
+
+    def evaluate(entry, times, out):
+        sim, _, view, start = entry
+        for _ in range(times):
+            view[:, 6:9] = start
+            sim.call_additional_forces()
+        out.append(view[:, 6:9].copy())
+
+    alone = []
+    for entry in sims:
+        got = []
+        evaluate(entry, 1, got)
+        alone.append(got[0])
+    assert not np.array_equal(alone[0], alone[1])
+    together = [[], []]
+    threads = [threading.Thread(target=evaluate, args=(sims[k], 6, together[k])) for k in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k in (0, 1):
+        assert np.array_equal(together[k][0], alone[k])
+    again = []
+    evaluate(sims[0], 3, again)
+    assert np.array_equal(again[0], alone[0])
