@@ -713,8 +713,20 @@ __host__ __device__ __forceinline__ unsigned stream_tiles(long long base, long l
 static constexpr unsigned XCD_RUN = 128;                    // consecutive tiles per XCD
 static constexpr unsigned XCD_REMAP_MIN_TILES = 4096;       // grids below this keep the linear order (no padding of small launches)
 
+// Workgroups per CU the register allocation of an instance is held to (= wavefronts per SIMD).  Measured choices:
+//   * the force-only instances of the common stacks fit 5 with a handful of spilled registers and gain 6 % from the fifth
+//     wavefront (C2: 160 -> 150 us at 1e7 grains); at 6 they spill ten times as much and lose a third;
+//   * the passes that carry a Wisdom-Holman step or a batch of them stay at 4, spills included (the batch pass, which is
+//     bound by vector issue and spills 78 registers there: 14.7 us per step at 2 without spills, 12.5 at 3, 12.1 at 4, 14.1 at 5);
+//   * the op-list walk over massive bodies needs ~180 registers (2).
+__host__ __device__ constexpr int stream_min_blocks(bool exact, bool backreact, int cols, Sig sig, int epi) {
+    if (backreact) return sig == 0ull ? 2 : ((!exact && epi == EPI_NONE) ? 5 : 3);
+    if (!exact && cols != COL_ALL) return (epi == EPI_NONE && sig != 0ull) ? 5 : 4;
+    return 3;
+}
+
 template <bool EXACT, bool BACKREACT, bool VEC2, int COLS, Sig SIG = 0ull, int EPI = EPI_NONE>
-__global__ __launch_bounds__(BLOCK, (BACKREACT && SIG == 0ull) ? 2 : (!EXACT && !BACKREACT && COLS != COL_ALL) ? 4 : 3) void stream_kernel(View v, Program prog, long long lo, long long base,
+__global__ __launch_bounds__(BLOCK, stream_min_blocks(EXACT, BACKREACT, COLS, SIG, EPI)) void stream_kernel(View v, Program prog, long long lo, long long base,
                                                        const HeadConsts* __restrict__ tab, double* partials, unsigned* status, StepArgs step) {
     static_assert(EPI == EPI_NONE || (EPI == EPI_APPLY ? BACKREACT && VEC2 && !EXACT : !BACKREACT && (COLS & COL_VEL)),
                   "a stepping pass streams massless bodies and needs their velocities; a pass that applies a prefix-sum force runs on any mass layout");
