@@ -716,12 +716,14 @@ static constexpr unsigned XCD_REMAP_MIN_TILES = 4096;       // grids below this 
 // Workgroups per CU the register allocation of an instance is held to (= wavefronts per SIMD).  Measured choices:
 //   * the force-only instances of the common stacks fit 5 with a handful of spilled registers and gain 6 % from the fifth
 //     wavefront (C2: 160 -> 150 us at 1e7 grains); at 6 they spill ten times as much and lose a third;
+//   * so does the pass that carries an Euler update (C5 stack: 238 -> 225 us); those of RK2 and of the implicit midpoint
+//     rule would spill 30-90 registers there and take 1.6-2.4 times as long: they stay at 4, like RK4;
 //   * the passes that carry a Wisdom-Holman step or a batch of them stay at 4, spills included (the batch pass, which is
 //     bound by vector issue and spills 78 registers there: 14.7 us per step at 2 without spills, 12.5 at 3, 12.1 at 4, 14.1 at 5);
 //   * the op-list walk over massive bodies needs ~180 registers (2).
 __host__ __device__ constexpr int stream_min_blocks(bool exact, bool backreact, int cols, Sig sig, int epi) {
     if (backreact) return sig == 0ull ? 2 : ((!exact && epi == EPI_NONE) ? 5 : 3);
-    if (!exact && cols != COL_ALL) return (epi == EPI_NONE && sig != 0ull) ? 5 : 4;
+    if (!exact && cols != COL_ALL) return ((epi == EPI_NONE || epi == EPI_EULER) && sig != 0ull) ? 5 : 4;
     return 3;
 }
 
