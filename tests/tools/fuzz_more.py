@@ -1,5 +1,8 @@
 """Runs the random-stack test of tests/test_gpu_fuzz.py on seeds beyond the ones pytest collects
-(development aid; GPU box):  python tests/tools/fuzz_more.py FIRST COUNT"""
+(development aid; GPU box):  python tests/tools/fuzz_more.py FIRST COUNT [stack | integrators | steps]
+  stack        the random stack, layout and parameters through rebxamd_apply (default)
+  integrators  the random stack through integrate_force (every scheme)
+  steps        the random stack through rebxamd_wh_steps"""
 import os
 import sys
 
@@ -9,12 +12,15 @@ import test_gpu_fuzz as tf
 from reboundx_amd.device import Context
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
+which = sys.argv[3] if len(sys.argv) > 3 else "stack"
+test = {"stack": tf.test_random_stack_layout_and_parameters, "integrators": tf.test_random_stack_through_the_force_integrators,
+        "steps": tf.test_random_stack_through_wisdom_holman_steps}[which]
 ctx = Context(0)
 bad = 0
 for seed in range(first, first + count):
     for mode in (1, 0):
         try:
-            tf.test_random_stack_layout_and_parameters(ctx, seed, mode)
+            test(ctx, seed, mode)
         except AssertionError as e:
             bad += 1
             print("FAIL seed", seed, "mode", mode, str(e)[:300], flush=True)
