@@ -354,14 +354,17 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
             // tables of this step; the head's own Wisdom-Holman step (gravity among its bodies, Jacobi kick, drift to the
             // next force evaluation) follows and records the frame of the massless bodies for the pass below -- unless the
             // pass of the step before has already done both in its extra workgroup
+            // (lead_in_head: the first step of a run -- the start of the run rides in the same launch)
+            double* const lead = step->lead_in_head ? const_cast<double*>(step->star0) : nullptr;
             if (step->nsub > 1) {
                 // a batch of steps in one pass: the head passes and head steps of all of them first, in one wavefront (unless the
                 // pass of the batch before has made them in its extra workgroup)
                 if (!step->head_ready) HIP_TRY(launch_wh_head_batch(v, prog, const_cast<HeadConsts*>(step->tabs), ctx->status, K, step->dtk, ctx->whead, const_cast<double*>(step->star),
-                                             step->nsub, step->h_sub, step->h, exact, st));
+                                             step->nsub, step->h_sub, step->h, exact, st, lead, step->h0));
             } else if (!step->head_ready) {
-                HIP_TRY(launch_head(v, prog, hc, ctx->status, exact, st));
-                HIP_TRY(launch_wh_head_step(v, K, prog.G, step->dtk, step->h, ctx->whead, const_cast<double*>(step->star), exact, st));
+                // head pass and head step of this one step in one launch
+                HIP_TRY(launch_wh_head_batch(v, prog, hc, ctx->status, K, step->dtk, ctx->whead, const_cast<double*>(step->star), 1, step->h, step->h, exact, st,
+                                             lead, step->h0));
             }
         } else if (wh && step->nsub > 1) {
             // a batch of steps in one pass: the head passes of all of them first, one after the other in one wavefront (unless
@@ -907,9 +910,7 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
             if (!com && (src < 0 || src >= K)) return fail(ctx, REBXAMD_ERR_UNSUPPORTED, "rebxamd_wh_steps: every op's source must be one of the massive bodies");
         }
         if (!view->x || !view->ax || !view->ay || !view->az) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_steps: position/acceleration columns missing");
-        const View v = make_view(view);
-        double* const lead = ctx->star + 32;
-        HIP_TRY(launch_wh_head_begin(v, K, view->G, 0.5 * dt, ctx->whead, lead, exact, st));
+        double* const lead = ctx->star + 32;       // record of the head's centre of mass at the start of the run, filled by the first head launch
         struct StageReset { rebxamd_ctx* c; ~StageReset() { c->hc_stage = 0; } } stage_reset{ctx};
         // With massless bodies behind the head, the pass of step k also runs, in one extra workgroup, the head pass and the head
         // step of step k + 1 (they never read a massless body) into the other copy of the tables and of the record: one launch
@@ -931,6 +932,7 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
                                k == 0 ? lead : nullptr, 0.5 * dt, {}};
                 sa.wh_head = (int)K;
                 sa.jac = ctx->whead;
+                sa.lead_in_head = k == 0 ? 1 : 0;
                 sa.nsub = nsub; sa.h_sub = dt; sa.tabs = ctx->hc_batch + (size_t)cur * kMaxWhBatch;
                 sa.head_ready = ready ? 1 : 0;
                 const int64_t left = nsteps - (k + nsub);
@@ -959,6 +961,7 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
             StepArgs sa = {h, dt, ctx->star + 16 * cur, EPI_WH, 0., 0., 0., {nullptr, nullptr, nullptr}, nullptr, k == 0 ? lead : nullptr, 0.5 * dt, {}};
             sa.wh_head = (int)K;
             sa.jac = ctx->whead;
+            sa.lead_in_head = k == 0 ? 1 : 0;
             if (chain && k + 1 < nsteps) { sa.next_hc = ctx->hc + nxt; sa.next_star = ctx->star + 16 * nxt; sa.next_h = k + 2 < nsteps ? dt : 0.5 * dt; }
             sa.head_ready = (chain && k > 0) ? 1 : 0;
             rc = run_streaming(ctx, view, ops, 0, nops, mode, st, -1, nullptr, false, &sa);

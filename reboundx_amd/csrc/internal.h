@@ -136,8 +136,9 @@ hipError_t launch_head(const View& v, const Program& prog, HeadConsts* hc, unsig
 hipError_t launch_head_batch(const View& v, const Program& prog, HeadConsts* hc, double* star, int nsub, double h, double h_last, double* lead,
                              double h_lead, hipStream_t st);
 // star + planets: head passes and head steps of nsub consecutive Wisdom-Holman steps (tables hc[j], frame records star + 16 j); see wh_head_batch_kernel
+// (lead != nullptr: the start of the run -- record `lead`, leading drift of the head over h_lead -- ahead of the first step)
 hipError_t launch_wh_head_batch(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, long long K, double dtk, double* jac, double* star,
-                                int nsub, double h, double h_last, bool exact, hipStream_t st);
+                                int nsub, double h, double h_last, bool exact, hipStream_t st, double* lead = nullptr, double h_lead = 0.);
 hipError_t launch_stream(const View& v, const Program& prog, long long lo, const HeadConsts* hc, double* partials,
                          int* nblocks_out, bool backreact, bool exact, bool vec2, bool fixed, unsigned* status, hipStream_t st,
                          const StepArgs* step = nullptr);
@@ -183,7 +184,6 @@ hipError_t launch_wh_drift(double* const x[3], double* const v[3], double* const
 // step (after the head pass has left the additional accelerations of the head bodies in their columns): gravity among the head
 // bodies without the pair (0,1), Jacobi kick over dtk, record of the centre of mass and its acceleration in `rec`, drift over h,
 // Jacobi -> inertial columns, acceleration columns of the head cleared.
-hipError_t launch_wh_head_begin(const View& v, long long K, double G, double h0, double* jac, double* lead, bool exact, hipStream_t st);
 hipError_t launch_wh_head_step(const View& v, long long K, double G, double dtk, double h, double* jac, double* rec, bool exact, hipStream_t st);
 long long im_partial_count(long long n);
 hipError_t launch_im_update(double* const fin[3], const double* const orig[3], double* const avgv[3], double* const avga[3], double dt,

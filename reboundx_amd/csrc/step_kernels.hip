@@ -172,39 +172,11 @@ __global__ __launch_bounds__(TB) void wh_drift_kernel(Cols3 x, Cols3 v, Cols3 a,
 
 // ---------------------------------------------------------------- Wisdom-Holman steps of a short massive head (wh_head.h)
 template <bool EXACT>
-__global__ __launch_bounds__(64) void wh_head_begin_kernel(View v, int K, double G, double h0, double* jac, double* lead) {
-    __shared__ WhHeadShared sh;
-    const int t = threadIdx.x;
-    if (t < K) {
-        sh.q[t][0] = v.x[t]; sh.q[t][1] = v.y[t]; sh.q[t][2] = v.z[t]; sh.q[t][3] = v.vx[t]; sh.q[t][4] = v.vy[t]; sh.q[t][5] = v.vz[t];
-        sh.m[t] = v.m[t];
-    }
-    __syncthreads();
-    if (t == 0) {
-        wh_head_to_jacobi(sh, K);
-        const double none[3] = {0., 0., 0.};
-        wh_head_record(sh, K, G, h0, none, lead);
-    }
-    __syncthreads();
-    wh_head_drift<EXACT>(sh, K, G, h0, t);
-    __syncthreads();
-    if (t == 0) wh_head_to_inertial(sh, K);
-    __syncthreads();
-    wh_head_store(v, sh, K, t, jac);
-}
-
-template <bool EXACT>
 __global__ __launch_bounds__(64) void wh_head_step_kernel(View v, int K, double G, double dtk, double h, double* jac, double* rec) {
     __shared__ WhHeadShared sh;
     wh_head_step_body<EXACT>(v, K, G, dtk, h, jac, rec, sh, threadIdx.x);
 }
 
-hipError_t launch_wh_head_begin(const View& v, long long K, double G, double h0, double* jac, double* lead, bool exact, hipStream_t st) {
-    if (K < 1 || K > REBXAMD_MAX_HEAD || K > v.n) return hipErrorInvalidValue;
-    if (exact) hipLaunchKernelGGL(wh_head_begin_kernel<true>, dim3(1), dim3(64), 0, st, v, (int)K, G, h0, jac, lead);
-    else hipLaunchKernelGGL(wh_head_begin_kernel<false>, dim3(1), dim3(64), 0, st, v, (int)K, G, h0, jac, lead);
-    return hipGetLastError();
-}
 hipError_t launch_wh_head_step(const View& v, long long K, double G, double dtk, double h, double* jac, double* rec, bool exact, hipStream_t st) {
     if (K < 1 || K > REBXAMD_MAX_HEAD || K > v.n) return hipErrorInvalidValue;
     if (exact) hipLaunchKernelGGL(wh_head_step_kernel<true>, dim3(1), dim3(64), 0, st, v, (int)K, G, dtk, h, jac, rec);

@@ -1200,13 +1200,18 @@ hipError_t launch_head_batch(const View& v, const Program& prog, HeadConsts* hc,
 // Star + planets: the head passes and the head's own Wisdom-Holman steps of nsub consecutive steps, one after the other in one
 // wavefront (lane = head body; every lane reads back only what it has stored itself): tables hc[j] and frame records
 // star[16 j] of step j, the head's state after the batch in the columns and in `jac`.  The head drifts over h after every
-// step but the last of the batch, over h_last after that one.
+// step but the last of the batch, over h_last after that one.  lead != nullptr (first step of a run): the start of the run
+// first (wh_head_begin_body: record `lead`, leading drift over h_lead).
 template <bool EXACT>
 __global__ __launch_bounds__(64) void wh_head_batch_kernel(View v, Program prog, HeadConsts* hc, unsigned* status, int K, double dtk, double* jac,
-                                                           double* star, int nsub, double h, double h_last) {
+                                                           double* star, int nsub, double h, double h_last, double* lead, double h_lead) {
     __shared__ HeadShared hsh;
     __shared__ WhHeadShared wsh;
     const int t = threadIdx.x;
+    if (lead != nullptr) {
+        wh_head_begin_body<EXACT>(v, K, prog.G, h_lead, jac, lead, wsh, t);
+        __syncthreads();
+    }
     for (int j = 0; j < nsub; j++) {
         head_body<EXACT>(v, prog, hc + j, status, nullptr, 0., hsh, t);
         wh_head_step_body<EXACT>(v, K, prog.G, dtk, j + 1 < nsub ? h : h_last, jac, star + 16 * j, wsh, t);
@@ -1215,10 +1220,10 @@ __global__ __launch_bounds__(64) void wh_head_batch_kernel(View v, Program prog,
 }
 
 hipError_t launch_wh_head_batch(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, long long K, double dtk, double* jac, double* star,
-                                int nsub, double h, double h_last, bool exact, hipStream_t st) {
+                                int nsub, double h, double h_last, bool exact, hipStream_t st, double* lead, double h_lead) {
     if (nsub < 1 || K < 2 || K > REBXAMD_MAX_HEAD || K > v.n) return hipErrorInvalidValue;
-    if (exact) hipLaunchKernelGGL(wh_head_batch_kernel<true>, dim3(1), dim3(64), 0, st, v, prog, hc, status, (int)K, dtk, jac, star, nsub, h, h_last);
-    else hipLaunchKernelGGL(wh_head_batch_kernel<false>, dim3(1), dim3(64), 0, st, v, prog, hc, status, (int)K, dtk, jac, star, nsub, h, h_last);
+    if (exact) hipLaunchKernelGGL(wh_head_batch_kernel<true>, dim3(1), dim3(64), 0, st, v, prog, hc, status, (int)K, dtk, jac, star, nsub, h, h_last, lead, h_lead);
+    else hipLaunchKernelGGL(wh_head_batch_kernel<false>, dim3(1), dim3(64), 0, st, v, prog, hc, status, (int)K, dtk, jac, star, nsub, h, h_last, lead, h_lead);
     return hipGetLastError();
 }
 

@@ -89,6 +89,29 @@ __device__ __forceinline__ void wh_head_record(const WhHeadShared& sh, int K, do
     rec[12] = G * sh.eta[K - 1];
 }
 
+// Start of a run: the head's Jacobi state from the columns, the record of its centre of mass for the leading half drift of
+// the massless bodies (`lead`), the head's own leading drift over h0, the drifted inertial state back into the columns and the
+// Jacobi state into `jac`.  Called by the 64 lanes of one wavefront, t = lane.
+template <bool EXACT>
+__device__ __forceinline__ void wh_head_begin_body(const View& v, int K, double G, double h0, double* jac, double* lead, WhHeadShared& sh, int t) {
+    if (t < K) {
+        sh.q[t][0] = v.x[t]; sh.q[t][1] = v.y[t]; sh.q[t][2] = v.z[t]; sh.q[t][3] = v.vx[t]; sh.q[t][4] = v.vy[t]; sh.q[t][5] = v.vz[t];
+        sh.m[t] = v.m[t];
+    }
+    __syncthreads();
+    if (t == 0) {
+        wh_head_to_jacobi(sh, K);
+        const double none[3] = {0., 0., 0.};
+        wh_head_record(sh, K, G, h0, none, lead);
+    }
+    __syncthreads();
+    wh_head_drift<EXACT>(sh, K, G, h0, t);
+    __syncthreads();
+    if (t == 0) wh_head_to_inertial(sh, K);
+    __syncthreads();
+    wh_head_store(v, sh, K, t, jac);
+}
+
 // The head's step after the head pass has left the additional accelerations of the head bodies in their columns: gravity among
 // the head bodies, Jacobi kick over dtk, record of the centre of mass in `rec`, drift over h, new inertial state into the columns
 // (accelerations cleared), Jacobi state into `jac`.  Called by the 64 lanes of one wavefront, t = lane.
