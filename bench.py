@@ -10,7 +10,8 @@ grains (plus a replica of the star): weak scaling, no data-path communication.
 Prints one JSON line (rank 0).  `value` = particle-force evaluations per second of the whole
 job, inputs already resident in HBM.  `roofline` prices the streaming kernel against HBM
 (algorithmic 112 B per particle: pos 24 + vel 24 + m 8 + beta 8 + acc 24 read + 24 written),
-its time measured with HIP events on the launch stream.  `cpu_baseline` times the CPU checker
+its time measured with two HIP events that bracket the timed steps on the launch stream (per step: the kernel plus the
+one-wavefront head pass in front of it).  `cpu_baseline` times the CPU checker
 (a single-threaded port of the reference algorithm) on the same particles on this host.
 """
 import argparse
@@ -384,15 +385,20 @@ def main():
         ctx.apply(view, ops, mode)
     torch.cuda.synchronize()
     barrier()
-    ctx.timing_enable(True)
+    # Two HIP events bracket the K timed steps on the launch stream (torch's current stream is the one the library launches
+    # on): device time per step = the streaming kernel + the one-wavefront head pass in front of it, an upper bound of the
+    # kernel's own duration.  (Events around every launch inside the loop cost 3-6 us per step, on the wall clock and in
+    # the durations they report alike: `scripts/bench_stream.py` and the rocprofv3 trace under profiles/ give the kernel alone.)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(args.steps):
         ctx.apply(view, ops, mode)
+    ev1.record()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    kernel_ms, launches = ctx.timing_read()
-    ctx.timing_enable(False)
+    kernel_ms, launches = ev0.elapsed_time(ev1), args.steps
 
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
@@ -432,7 +438,8 @@ def main():
                                    "gravitational_harmonics(J2,J4) + gr fused, device-resident fp64 columns",
                        "particles_per_gpu": args.n_per_gpu, "arithmetic": args.mode, "sharding": "particle index, no communication"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "stream_kernel (tail pass)", "kernel_us": kernel_s * 1e6,
+                         "traffic": traffic, "kernel": "stream_kernel (tail pass; the HIP-event time per step also holds the one-wavefront head pass launched in front of it)",
+                         "kernel_us": kernel_s * 1e6,
                          "algorithmic_bytes_per_launch": BYTES_PER_EVAL * tail},
         }
         if not args.no_cpu and world == 1:

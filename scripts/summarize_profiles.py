@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Condenses the raw rocprofv3 outputs of scripts/collect_profiles.sh (gpurun_out/prof_*) into
 the files kept under profiles/:
-  <round>_bench_kernel_stats.csv  per-kernel calls / total / average / min / max of `bench.py --no-cpu`
+  <round>_bench_kernel_stats.csv  per-kernel calls / total / average / min / max of `bench.py --no-cpu --ooc-n 0`
+  <round>_out_of_cache_kernel_stats.csv  the same of the out-of-cache section alone (the headline kernel on 4e7 grains)
   traffic.json                    HBM bytes per launch of the streaming kernel from the PMC passes (headline size, and 4e7 grains: out of cache)
   <round>_bench.json              the JSON line that profiled bench run printed
 usage: python scripts/summarize_profiles.py [round, default r02]
@@ -38,6 +39,9 @@ def condense(src, dst):
 
 def kernel_stats():
     condense(os.path.join(OUT, "prof_trace", "bench_kernel_stats.csv"), os.path.join(PROF, ROUND + "_bench_kernel_stats.csv"))
+    ooc = os.path.join(OUT, "prof_trace_ooc", "ooc_kernel_stats.csv")
+    if os.path.exists(ooc):
+        condense(ooc, os.path.join(PROF, ROUND + "_out_of_cache_kernel_stats.csv"))
 
 
 def side_profiles():
