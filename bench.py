@@ -237,6 +237,13 @@ def c3_section(ctx, n, mode, device):
         dt = (time.perf_counter() - t0) / 10
         out[label] = {"us_per_eval": dt * 1e6, "evals_per_s": n / dt,
                       "roofline": {"bound": "hbm", "achieved": 144 * n / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 144 * n / dt / 1e9 / HBM_PEAK_GBS}}
+        if label == "jacobi":
+            # The roofline above prices the stack's 144 algorithmic bytes.  Jacobi coordinates tie every body to the sums over the
+            # bodies before it and to the reactions of the bodies behind it: a forward and a backward sweep over data that does
+            # not fit on the chip cannot move less than 240 B per body, and the three sweeps of this implementation move 296 B.
+            out[label]["bytes_moved_per_body"] = 296
+            out[label]["two_sweep_floor_bytes_per_body"] = 240
+            out[label]["frac_of_peak_on_bytes_moved"] = 296 * n / dt / 1e9 / HBM_PEAK_GBS
     return out
 
 
