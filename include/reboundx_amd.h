@@ -482,13 +482,16 @@ int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_o
  * wants one launch and one Kepler drift per step -- what REBOUND's WHFast does with safe_mode = 0 and
  * reb_integrator_synchronize.  No counterpart in the reference.  One massive body followed by massless ones
  * (view->n_head = 1, view->tail_massless = 1), a force stack of at least one op that is one streaming run whose source
- * is body 0 (no gr_full, no barycentric modify_orbits_forces); anything else: REBXAMD_ERR_UNSUPPORTED, use rebxamd_wh_steps.
+ * is body 0 (no gr_full, no barycentric modify_orbits_forces); or a head of 2 .. 64 massive bodies followed by at least
+ * one massless one (view->tail_massless = 1, acceleration columns present) under any stack rebxamd_wh_steps takes behind
+ * such a head (the empty one included); anything else: REBXAMD_ERR_UNSUPPORTED, use rebxamd_wh_steps.
  *   rebxamd_wh_run_begin   opens the run (launches nothing; keeps copies of *view and of the ops).  Until the run is
  *                          closed the caller must leave the columns where they are and must not write positions,
  *                          velocities, masses or parameters.
  *   rebxamd_wh_run_steps   nsteps more steps, each ONE pass: { drift dt (dt/2 in the first step of the run) ; forces ;
- *                          kick }.  Between calls the massless bodies sit at the middle of the last step, kicked; body 0's
- *                          row is one drift further (the next step's head pass has already run).
+ *                          kick }.  Between calls the massless bodies sit at the middle of the last step, kicked; the rows
+ *                          of the massive bodies are one drift further (the next step's head pass, and behind several
+ *                          massive bodies their next step, have already run).
  *   rebxamd_wh_run_end     the closing half drift: the columns hold the synchronised state, bit for bit what
  *                          rebxamd_wh_steps(view, ops, dt, <steps taken>) would have left.  Closes the run.
  * All three are asynchronous on `stream` (the same stream for the whole run). */

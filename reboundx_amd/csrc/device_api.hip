@@ -37,7 +37,7 @@ struct rebxamd_ctx {
     double* star_batch = nullptr;
     int wh_batch = 32;                  // steps per pass (1: one pass per step)
     // a Wisdom-Holman run left unsynchronised between calls (rebxamd_wh_run_begin .. rebxamd_wh_run_end)
-    struct WhRun { bool open = false; int64_t k = 0; double dt = 0.; int mode = 0; rebxamd_view view; std::vector<rebxamd_op> ops; } run;
+    struct WhRun { bool open = false; int64_t k = 0; double dt = 0.; int mode = 0; long long K = 1; rebxamd_view view; std::vector<rebxamd_op> ops; } run;
     double* integ = nullptr;            // stage columns of the force integrators
     size_t integ_cap = 0;
     double* shard = nullptr;            // per-range forces and reactions of the sharded Jacobi/barycentric modify_orbits_forces
@@ -112,7 +112,7 @@ extern "C" int rebxamd_create(int device, rebxamd_ctx** out) {
         hipMalloc((void**)&ctx->ll, sizeof(long long)) != hipSuccess ||
         hipMalloc((void**)&ctx->gf_flag, 4 * sizeof(unsigned)) != hipSuccess ||
         hipMalloc((void**)&ctx->star, 96 * sizeof(double)) != hipSuccess ||
-        hipMalloc((void**)&ctx->whead, 8 * REBXAMD_MAX_HEAD * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&ctx->whead, 3 * 8 * REBXAMD_MAX_HEAD * sizeof(double)) != hipSuccess ||     // Jacobi state + two copies of the state between kick and drift
         hipHostMalloc(&ctx->hpin, 512, hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void**)&ctx->chunk_sums, sizeof(double) * REBXAMD_MAX_OPS * 64 * 3) != hipSuccess ||
         hipMemset(ctx->hc, 0, 4 * sizeof(HeadConsts)) != hipSuccess ||
@@ -363,8 +363,9 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
                                              step->nsub, step->h_sub, step->h, exact, st, lead, step->h0));
             } else if (!step->head_ready) {
                 // head pass and head step of this one step in one launch
-                HIP_TRY(launch_wh_head_batch(v, prog, hc, ctx->status, K, step->dtk, ctx->whead, const_cast<double*>(step->star), 1, step->h, step->h, exact, st,
-                                             lead, step->h0));
+                const double hh = step->head_h != 0. ? step->head_h : step->h;       // (an unsynchronised run: the grains wait, the head drifts)
+                HIP_TRY(launch_wh_head_batch(v, prog, hc, ctx->status, K, step->dtk, ctx->whead, const_cast<double*>(step->star), 1, hh, hh, exact, st,
+                                             lead, step->h0, step->pre));
             }
         } else if (wh && step->nsub > 1) {
             // a batch of steps in one pass: the head passes of all of them first, one after the other in one wavefront (unless
@@ -1078,6 +1079,23 @@ extern "C" int rebxamd_wh_run_begin(rebxamd_ctx* ctx, const rebxamd_view* view, 
     if (ctx->run.open) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_run_begin: a run is already open on this context (close it with rebxamd_wh_run_end)");
     if (nops < 0 || nops > REBXAMD_MAX_OPS || (nops > 0 && !ops)) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_run_begin: bad argument");
     if (!view->m || !view->x || !view->vx) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_run_begin: position/velocity/mass columns missing");
+    const long long Kh = view->n_head < view->n ? view->n_head : view->n;
+    if (Kh > 1) {
+        // star + planets + massless bodies: the head steps one step ahead in the extra workgroup of every pass
+        bool fits = ctx->carried_steps && Kh <= REBXAMD_MAX_HEAD && view->tail_massless && view->n > Kh && (nops == 0 || one_streaming_run(ops, nops)) &&
+                    view->ax && view->ay && view->az;
+        for (int k = 0; k < nops && fits; k++) {
+            const bool com = ops[k].kind == REBXAMD_OP_MOF && ops[k].iarg != REBX_COORDINATES_PARTICLE;
+            const int src = (ops[k].kind == REBXAMD_OP_GR || ops[k].kind == REBXAMD_OP_GR_POTENTIAL) ? 0 : ops[k].src;
+            if (!com && (src < 0 || src >= Kh)) fits = false;
+        }
+        if (!fits)
+            return fail(ctx, REBXAMD_ERR_UNSUPPORTED, "rebxamd_wh_run_begin behind several massive bodies handles a head of at most 64 of them followed by massless ones (tail_massless = 1, acceleration columns present) under a stack that is one streaming run of forces whose sources are head bodies; use rebxamd_wh_steps otherwise");
+        ctx->run.open = true; ctx->run.k = 0; ctx->run.dt = dt; ctx->run.mode = mode; ctx->run.K = Kh;
+        ctx->run.view = *view;
+        ctx->run.ops.assign(ops, ops + nops);
+        return REBXAMD_OK;
+    }
     bool ok = ctx->carried_steps && view->n_head == 1 && view->tail_massless && view->n > 1 && one_streaming_run(ops, nops);
     for (int k = 0; k < nops && ok; k++) {
         const bool com = ops[k].kind == REBXAMD_OP_MOF && ops[k].iarg != REBX_COORDINATES_PARTICLE;
@@ -1086,11 +1104,17 @@ extern "C" int rebxamd_wh_run_begin(rebxamd_ctx* ctx, const rebxamd_view* view, 
     }
     if (!ok)
         return fail(ctx, REBXAMD_ERR_UNSUPPORTED, "rebxamd_wh_run_begin handles one massive body followed by massless ones (n_head = 1, tail_massless = 1) under a non-empty stack that is one streaming run of forces whose source is body 0 (no gr_full, no barycentric modify_orbits_forces); use rebxamd_wh_steps otherwise");
-    ctx->run.open = true; ctx->run.k = 0; ctx->run.dt = dt; ctx->run.mode = mode;
+    ctx->run.open = true; ctx->run.k = 0; ctx->run.dt = dt; ctx->run.mode = mode; ctx->run.K = 1;
     ctx->run.view = *view;
     ctx->run.ops.assign(ops, ops + nops);
     return REBXAMD_OK;
 }
+
+// Where an unsynchronised run behind several massive bodies keeps its records (slots of 16 doubles in ctx->star): the frame
+// records of three consecutive steps in rotation -- pass k drifts the grains about the record of step k - 1, kicks them with
+// that of step k, and its extra workgroup writes that of step k + 1 --, the record of the start of the run, the closing one.
+static double* run_record(rebxamd_ctx* ctx, int64_t k) { static const int slot[3] = {0, 16, 48}; return ctx->star + slot[((k % 3) + 3) % 3]; }
+static double* run_pre(rebxamd_ctx* ctx, int64_t k) { return ctx->whead + 8 * REBXAMD_MAX_HEAD * (1 + (int)(k & 1)); }
 
 extern "C" int rebxamd_wh_run_steps(rebxamd_ctx* ctx, int64_t nsteps, void* stream) {
     if (!ctx) return REBXAMD_ERR_ARG;
@@ -1100,6 +1124,29 @@ extern "C" int rebxamd_wh_run_steps(rebxamd_ctx* ctx, int64_t nsteps, void* stre
     hipStream_t st = (hipStream_t)stream;
     const double dt = ctx->run.dt;
     struct StageReset { rebxamd_ctx* c; ~StageReset() { c->hc_stage = 0; } } stage_reset{ctx};
+    if (ctx->run.K > 1) {
+        // Step k is one pass: { the grains drift dt (dt/2 in step 0) about the head's centre of mass; forces and the pull of the
+        // head bodies; kick }.  The head is one step ahead: its head pass and its own step (kick, whole drift) for step k + 1 ride
+        // in the extra workgroup of pass k; the state it has between kick and drift is kept for the end of the run.
+        for (int64_t j = 0; j < nsteps; j++) {
+            const int64_t k = ctx->run.k;
+            const int cur = (int)(k & 1), nxt = cur ^ 1;
+            ctx->hc_stage = cur;
+            StepArgs sa = {0., dt, run_record(ctx, k), EPI_WH, 0., 0., 0., {nullptr, nullptr, nullptr}, nullptr,
+                           k == 0 ? ctx->star + 32 : run_record(ctx, k - 1), k == 0 ? 0.5 * dt : dt, {}};
+            sa.wh_head = (int)ctx->run.K;
+            sa.jac = ctx->whead;
+            sa.head_h = dt; sa.pre = run_pre(ctx, k);
+            sa.next_hc = ctx->hc + nxt; sa.next_star = run_record(ctx, k + 1); sa.next_h = dt; sa.next_pre = run_pre(ctx, k + 1);
+            sa.head_ready = k > 0 ? 1 : 0;
+            sa.lead_in_head = k == 0 ? 1 : 0;
+            const int rc = run_streaming(ctx, &ctx->run.view, ctx->run.ops.data(), 0, (int)ctx->run.ops.size(), ctx->run.mode, st, -1, nullptr, false, &sa);
+            if (rc == STEP_NOT_CARRIED) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_run_steps: the force stack cannot ride in one pass over this layout");
+            if (rc != REBXAMD_OK) return rc;
+            ctx->run.k = k + 1;
+        }
+        return REBXAMD_OK;
+    }
     for (int64_t j = 0; j < nsteps; j++) {
         const int64_t k = ctx->run.k;
         const int cur = (int)(k & 1), nxt = cur ^ 1;
@@ -1127,6 +1174,16 @@ extern "C" int rebxamd_wh_run_end(rebxamd_ctx* ctx, void* stream) {
     const rebxamd_view* view = &ctx->run.view;
     double* const x[3] = {const_cast<double*>(view->x), const_cast<double*>(view->y), const_cast<double*>(view->z)};
     double* const v[3] = {const_cast<double*>(view->vx), const_cast<double*>(view->vy), const_cast<double*>(view->vz)};
+    if (ctx->run.K > 1) {
+        // the head back to its state after the kick of the last step (it has run a whole step ahead since) and over the half
+        // drift that closes that step; the grains over the same half drift about the head's centre of mass
+        const int64_t last_step = ctx->run.k - 1;
+        const bool exact = ctx->run.mode == REBXAMD_MODE_EXACT;
+        const double h = 0.5 * ctx->run.dt;
+        HIP_TRY(launch_wh_head_close(make_view(view), ctx->run.K, view->G, h, run_pre(ctx, last_step), ctx->whead, run_record(ctx, last_step), ctx->star + 80, exact, st));
+        HIP_TRY(launch_wh_drift_about(x, v, ctx->run.K, view->n, h, ctx->star + 80, exact, st));
+        return REBXAMD_OK;
+    }
     // body 0 back to where the last pass's forces saw it (its row ran ahead by the leading drift of a step that never came),
     // then the closing half drift of everything
     const int last = (int)((ctx->run.k - 1) & 1);

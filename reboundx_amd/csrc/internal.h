@@ -123,7 +123,11 @@ struct StepArgs { double h, dtk; const double* star; int epi; double c0, c1, c2;
                   // EPI_WHB with next_hc set: the extra workgroup of the pass takes the head through the NEXT batch of next_nsub steps
                   // (tables next_hc[j], records next_star + 16 j; drift over h_sub after every step but the last, next_h after that
                   // one), so that batch needs no head launch of its own (head_ready)
-                  int next_nsub; };
+                  int next_nsub;
+                  // EPI_WH behind several massive bodies, run left unsynchronised between steps: the grains make no trailing drift
+                  // (h == 0) while the head drifts over head_h after its kick; the head's state between kick and drift is kept in
+                  // `pre` by a head launch of this step, in `next_pre` by the chained head step of the next one
+                  double head_h; double* pre; double* next_pre; };
 
 enum { WARN_GR_ITER = 1u, WARN_GRFULL_SWEEPS = 2u, WARN_IM_ITER = 4u };
 
@@ -138,7 +142,7 @@ hipError_t launch_head_batch(const View& v, const Program& prog, HeadConsts* hc,
 // star + planets: head passes and head steps of nsub consecutive Wisdom-Holman steps (tables hc[j], frame records star + 16 j); see wh_head_batch_kernel
 // (lead != nullptr: the start of the run -- record `lead`, leading drift of the head over h_lead -- ahead of the first step)
 hipError_t launch_wh_head_batch(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, long long K, double dtk, double* jac, double* star,
-                                int nsub, double h, double h_last, bool exact, hipStream_t st, double* lead = nullptr, double h_lead = 0.);
+                                int nsub, double h, double h_last, bool exact, hipStream_t st, double* lead = nullptr, double h_lead = 0., double* pre = nullptr);
 hipError_t launch_stream(const View& v, const Program& prog, long long lo, const HeadConsts* hc, double* partials,
                          int* nblocks_out, bool backreact, bool exact, bool vec2, bool fixed, unsigned* status, hipStream_t st,
                          const StepArgs* step = nullptr);
@@ -184,6 +188,11 @@ hipError_t launch_wh_drift(double* const x[3], double* const v[3], double* const
 // step (after the head pass has left the additional accelerations of the head bodies in their columns): gravity among the head
 // bodies without the pair (0,1), Jacobi kick over dtk, record of the centre of mass and its acceleration in `rec`, drift over h,
 // Jacobi -> inertial columns, acceleration columns of the head cleared.
+// closing half drift of the massless bodies [first, n) about the frame in `rec`; end of an unsynchronised run behind a head of
+// several massive bodies (see wh_head_close_body)
+hipError_t launch_wh_drift_about(double* const x[3], double* const v[3], long long first, long long n, double h, const double* rec, bool exact, hipStream_t st);
+hipError_t launch_wh_head_close(const View& v, long long K, double G, double h, const double* pre, double* jac, const double* rec_last, double* rec_close,
+                                bool exact, hipStream_t st);
 hipError_t launch_wh_head_step(const View& v, long long K, double G, double dtk, double h, double* jac, double* rec, bool exact, hipStream_t st);
 long long im_partial_count(long long n);
 hipError_t launch_im_update(double* const fin[3], const double* const orig[3], double* const avgv[3], double* const avga[3], double dt,

@@ -156,8 +156,9 @@ __global__ void wh_star_drift_kernel(Cols3 x, CCols3 v, Cols3 a, const double* m
 // KICK: v_i += dtk*(a_i - a_0) first (Jacobi kick with massless bodies; a_i is cleared afterwards so
 // that the next force pass accumulates onto zero), then the Kepler drift over h.
 template <bool EXACT, bool KICK>
-__global__ __launch_bounds__(TB) void wh_drift_kernel(Cols3 x, Cols3 v, Cols3 a, double h, double dtk, long long n, const double* __restrict__ star) {
-    const long long i = (long long)blockIdx.x * TB + threadIdx.x + 1;
+__global__ __launch_bounds__(TB) void wh_drift_kernel(Cols3 x, Cols3 v, Cols3 a, double h, double dtk, long long n, const double* __restrict__ star,
+                                                      long long first) {
+    const long long i = (long long)blockIdx.x * TB + threadIdx.x + first;      // (the bodies before `first` are the head)
     if (i >= n) return;
     double s[6] = {x.x[i], x.y[i], x.z[i], v.x[i], v.y[i], v.z[i]};
     double ax = 0., ay = 0., az = 0.;
@@ -277,13 +278,37 @@ hipError_t launch_wh_drift(double* const x[3], double* const v[3], double* const
     hipLaunchKernelGGL(wh_star_drift_kernel, dim3(1), dim3(64), 0, st, cx, ccv, ca, m, G, h, star);
     if (n > 1) {
         if (a) {
-            if (exact) hipLaunchKernelGGL((wh_drift_kernel<true, true>), grid_for(n - 1), dim3(TB), 0, st, cx, cv, ca, h, dtk, n, star);
-            else hipLaunchKernelGGL((wh_drift_kernel<false, true>), grid_for(n - 1), dim3(TB), 0, st, cx, cv, ca, h, dtk, n, star);
+            if (exact) hipLaunchKernelGGL((wh_drift_kernel<true, true>), grid_for(n - 1), dim3(TB), 0, st, cx, cv, ca, h, dtk, n, star, 1LL);
+            else hipLaunchKernelGGL((wh_drift_kernel<false, true>), grid_for(n - 1), dim3(TB), 0, st, cx, cv, ca, h, dtk, n, star, 1LL);
         } else {
-            if (exact) hipLaunchKernelGGL((wh_drift_kernel<true, false>), grid_for(n - 1), dim3(TB), 0, st, cx, cv, ca, h, dtk, n, star);
-            else hipLaunchKernelGGL((wh_drift_kernel<false, false>), grid_for(n - 1), dim3(TB), 0, st, cx, cv, ca, h, dtk, n, star);
+            if (exact) hipLaunchKernelGGL((wh_drift_kernel<true, false>), grid_for(n - 1), dim3(TB), 0, st, cx, cv, ca, h, dtk, n, star, 1LL);
+            else hipLaunchKernelGGL((wh_drift_kernel<false, false>), grid_for(n - 1), dim3(TB), 0, st, cx, cv, ca, h, dtk, n, star, 1LL);
         }
     }
+    return hipGetLastError();
+}
+
+// Kepler drift over h of the bodies [first, n) about the frame that `rec` records (no kick): the closing half drift of the
+// massless bodies behind a head of several massive ones.
+hipError_t launch_wh_drift_about(double* const x[3], double* const v[3], long long first, long long n, double h, const double* rec, bool exact, hipStream_t st) {
+    if (n <= first) return hipSuccess;
+    const Cols3 cx = {x[0], x[1], x[2]}, cv = {v[0], v[1], v[2]}, ca = {nullptr, nullptr, nullptr};
+    if (exact) hipLaunchKernelGGL((wh_drift_kernel<true, false>), grid_for(n - first), dim3(TB), 0, st, cx, cv, ca, h, 0., n, rec, first);
+    else hipLaunchKernelGGL((wh_drift_kernel<false, false>), grid_for(n - first), dim3(TB), 0, st, cx, cv, ca, h, 0., n, rec, first);
+    return hipGetLastError();
+}
+
+template <bool EXACT>
+__global__ __launch_bounds__(64) void wh_head_close_kernel(View v, int K, double G, double h, const double* pre, double* jac, const double* rec_last,
+                                                           double* rec_close) {
+    __shared__ WhHeadShared sh;
+    wh_head_close_body<EXACT>(v, K, G, h, pre, jac, rec_last, rec_close, sh, threadIdx.x);
+}
+hipError_t launch_wh_head_close(const View& v, long long K, double G, double h, const double* pre, double* jac, const double* rec_last, double* rec_close,
+                                bool exact, hipStream_t st) {
+    if (K < 2 || K > REBXAMD_MAX_HEAD || K > v.n) return hipErrorInvalidValue;
+    if (exact) hipLaunchKernelGGL(wh_head_close_kernel<true>, dim3(1), dim3(64), 0, st, v, (int)K, G, h, pre, jac, rec_last, rec_close);
+    else hipLaunchKernelGGL(wh_head_close_kernel<false>, dim3(1), dim3(64), 0, st, v, (int)K, G, h, pre, jac, rec_last, rec_close);
     return hipGetLastError();
 }
 

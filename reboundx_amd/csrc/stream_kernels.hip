@@ -774,7 +774,7 @@ __global__ __launch_bounds__(BLOCK, stream_min_blocks(EXACT, BACKREACT, COLS, SI
                 __shared__ WhHeadShared wsh;
                 if (tid >= 64) return;
                 head_body<EXACT>(v, prog, step.next_hc, status, nullptr, 0., hsh, tid);
-                wh_head_step_body<EXACT>(v, step.wh_head, prog.G, step.dtk, step.next_h, step.jac, step.next_star, wsh, tid);
+                wh_head_step_body<EXACT>(v, step.wh_head, prog.G, step.dtk, step.next_h, step.jac, step.next_star, wsh, tid, step.next_pre);
                 return;
             }
         }
@@ -1204,7 +1204,7 @@ hipError_t launch_head_batch(const View& v, const Program& prog, HeadConsts* hc,
 // first (wh_head_begin_body: record `lead`, leading drift over h_lead).
 template <bool EXACT>
 __global__ __launch_bounds__(64) void wh_head_batch_kernel(View v, Program prog, HeadConsts* hc, unsigned* status, int K, double dtk, double* jac,
-                                                           double* star, int nsub, double h, double h_last, double* lead, double h_lead) {
+                                                           double* star, int nsub, double h, double h_last, double* lead, double h_lead, double* pre) {
     __shared__ HeadShared hsh;
     __shared__ WhHeadShared wsh;
     const int t = threadIdx.x;
@@ -1214,16 +1214,16 @@ __global__ __launch_bounds__(64) void wh_head_batch_kernel(View v, Program prog,
     }
     for (int j = 0; j < nsub; j++) {
         head_body<EXACT>(v, prog, hc + j, status, nullptr, 0., hsh, t);
-        wh_head_step_body<EXACT>(v, K, prog.G, dtk, j + 1 < nsub ? h : h_last, jac, star + 16 * j, wsh, t);
+        wh_head_step_body<EXACT>(v, K, prog.G, dtk, j + 1 < nsub ? h : h_last, jac, star + 16 * j, wsh, t, pre);
         __syncthreads();
     }
 }
 
 hipError_t launch_wh_head_batch(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, long long K, double dtk, double* jac, double* star,
-                                int nsub, double h, double h_last, bool exact, hipStream_t st, double* lead, double h_lead) {
+                                int nsub, double h, double h_last, bool exact, hipStream_t st, double* lead, double h_lead, double* pre) {
     if (nsub < 1 || K < 2 || K > REBXAMD_MAX_HEAD || K > v.n) return hipErrorInvalidValue;
-    if (exact) hipLaunchKernelGGL(wh_head_batch_kernel<true>, dim3(1), dim3(64), 0, st, v, prog, hc, status, (int)K, dtk, jac, star, nsub, h, h_last, lead, h_lead);
-    else hipLaunchKernelGGL(wh_head_batch_kernel<false>, dim3(1), dim3(64), 0, st, v, prog, hc, status, (int)K, dtk, jac, star, nsub, h, h_last, lead, h_lead);
+    if (exact) hipLaunchKernelGGL(wh_head_batch_kernel<true>, dim3(1), dim3(64), 0, st, v, prog, hc, status, (int)K, dtk, jac, star, nsub, h, h_last, lead, h_lead, pre);
+    else hipLaunchKernelGGL(wh_head_batch_kernel<false>, dim3(1), dim3(64), 0, st, v, prog, hc, status, (int)K, dtk, jac, star, nsub, h, h_last, lead, h_lead, pre);
     return hipGetLastError();
 }
 

@@ -115,8 +115,11 @@ __device__ __forceinline__ void wh_head_begin_body(const View& v, int K, double 
 // The head's step after the head pass has left the additional accelerations of the head bodies in their columns: gravity among
 // the head bodies, Jacobi kick over dtk, record of the centre of mass in `rec`, drift over h, new inertial state into the columns
 // (accelerations cleared), Jacobi state into `jac`.  Called by the 64 lanes of one wavefront, t = lane.
+// pre != nullptr: the head's Jacobi state after the kick and before the drift is kept there (layout of `jac`): what a run
+// left unsynchronised between steps needs to close with a half drift where this step made a whole one.
 template <bool EXACT>
-__device__ __forceinline__ void wh_head_step_body(const View& v, int K, double G, double dtk, double h, double* jac, double* rec, WhHeadShared& sh, int t) {
+__device__ __forceinline__ void wh_head_step_body(const View& v, int K, double G, double dtk, double h, double* jac, double* rec, WhHeadShared& sh, int t,
+                                                  double* pre = nullptr) {
     if (t < K) {
         sh.q[t][0] = v.x[t]; sh.q[t][1] = v.y[t]; sh.q[t][2] = v.z[t]; sh.q[t][3] = v.vx[t]; sh.q[t][4] = v.vy[t]; sh.q[t][5] = v.vz[t];
         sh.m[t] = v.m[t];
@@ -165,6 +168,35 @@ __device__ __forceinline__ void wh_head_step_body(const View& v, int K, double G
             const double pre3 = dtk * sqrt(r2i) * r2i * G * sh.eta[t];
             j[3] += pre3 * j[0]; j[4] += pre3 * j[1]; j[5] += pre3 * j[2];
         }
+    }
+    __syncthreads();
+    if (pre != nullptr && t < K) {
+        for (int c = 0; c < 6; c++) pre[6 * t + c] = sh.j[t][c];
+        pre[6 * REBXAMD_MAX_HEAD + t] = sh.eta[t];
+    }
+    wh_head_drift<EXACT>(sh, K, G, h, t);
+    __syncthreads();
+    if (t == 0) wh_head_to_inertial(sh, K);
+    __syncthreads();
+    wh_head_store(v, sh, K, t, jac);
+}
+
+// End of a run left unsynchronised between steps: the head goes back to its state after the kick of the last step (`pre`)
+// and drifts over h (half a step) from there, as the last step of a closed run does; rec_close <- the frame record of that
+// step (`rec_last`, made for a whole drift) with the frame's position after the half drift.
+template <bool EXACT>
+__device__ __forceinline__ void wh_head_close_body(const View& v, int K, double G, double h, const double* pre, double* jac, const double* rec_last,
+                                                   double* rec_close, WhHeadShared& sh, int t) {
+    if (t < K) {
+        for (int c = 0; c < 6; c++) sh.j[t][c] = pre[6 * t + c];
+        sh.eta[t] = pre[6 * REBXAMD_MAX_HEAD + t];
+        sh.m[t] = v.m[t];
+    }
+    if (t == 0) {
+#pragma clang fp contract(off)
+        for (int c = 0; c < 6; c++) rec_close[c] = rec_last[c];
+        for (int c = 0; c < 3; c++) { rec_close[6 + c] = rec_last[c] + h * rec_last[3 + c]; rec_close[9 + c] = rec_last[9 + c]; }
+        rec_close[12] = rec_last[12];
     }
     __syncthreads();
     wh_head_drift<EXACT>(sh, K, G, h, t);

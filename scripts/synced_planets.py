@@ -1,5 +1,6 @@
-"""Latency of a host-synchronised Wisdom-Holman step (rebxamd_wh_steps(..., 1) + a stream synchronisation) behind a head of
-several massive bodies (development aid): star + `planets` planets + 10^6 grains under radiation forces.
+"""Latency of a host-synchronised Wisdom-Holman step behind a head of several massive bodies (development aid): star +
+`planets` planets + 10^6 grains under radiation forces; closed steps (rebxamd_wh_steps(..., 1) + a stream synchronisation)
+and a run left open between the host's waits (rebxamd_wh_run_steps(1) + a stream synchronisation).
 usage: python scripts/synced_planets.py"""
 import ctypes
 import os
@@ -38,3 +39,16 @@ for planets in (0, 1, 4):
         torch.cuda.current_stream().synchronize()
     t = (time.perf_counter() - t0) / steps
     print("planets %d: %.1f us per synchronised step (rc %d)" % (planets, t * 1e6, rc))
+    rc = lib.rebxamd_wh_run_begin(ctx._h, vref, arr, len(ops), dt, 0, stream)
+    assert rc == 0, rc
+    for _ in range(20):
+        lib.rebxamd_wh_run_steps(ctx._h, 1, stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rc = lib.rebxamd_wh_run_steps(ctx._h, 1, stream)
+        torch.cuda.current_stream().synchronize()
+    t = (time.perf_counter() - t0) / steps
+    lib.rebxamd_wh_run_end(ctx._h, stream)
+    torch.cuda.synchronize()
+    print("planets %d: %.1f us per synchronised step of an open run (rc %d)" % (planets, t * 1e6, rc))
