@@ -203,7 +203,27 @@ def c5_section(ctx, n, steps, mode, device):
     ctx.wh_steps(v1, ops1, dt, steps1, mode)
     torch.cuda.synchronize()
     q1 = (time.perf_counter() - t0) / steps1
+    # one call and one wait per step behind the planet as well: closed steps, then a run left open between the waits
+    arr1 = (Op * len(ops1))(*ops1)
+    v1ref = ctypes.byref(v1)
+    steps2 = max(1, steps // 10)
+    t0 = time.perf_counter()
+    for _ in range(steps2):
+        rc = lib.rebxamd_wh_steps(ctx._h, v1ref, arr1, len(ops1), dt, 1, mode, stream)
+        torch.cuda.current_stream().synchronize()
+    s1 = (time.perf_counter() - t0) / steps2
+    rc = rc or lib.rebxamd_wh_run_begin(ctx._h, v1ref, arr1, len(ops1), dt, mode, stream)
+    t0 = time.perf_counter()
+    for _ in range(steps2):
+        rc = rc or lib.rebxamd_wh_run_steps(ctx._h, 1, stream)
+        torch.cuda.current_stream().synchronize()
+    so1 = (time.perf_counter() - t0) / steps2
+    rc = rc or lib.rebxamd_wh_run_end(ctx._h, stream)
+    torch.cuda.synchronize()
+    if rc != 0:
+        raise RuntimeError("rebxamd_wh_run_* behind star + planet: %d" % rc)
     out["star_planet_grains"] = {"n": n, "steps": steps1, "effects": 1, "us_per_step_queued": q1 * 1e6, "particle_steps_per_s": n / q1,
+                                 "us_per_step_host_synced": s1 * 1e6, "us_per_step_host_synced_open_run": so1 * 1e6,
                                  "state_finite": bool(torch.isfinite(dq.cols["x"]).all().item()),
                                  "steps_per_pass": WH_BATCH, "hbm_bytes_per_particle_step": 104. / WH_BATCH,
                                  # (20 337 / 32 = 635 instructions per wavefront and step: radiation + the pull of both head bodies + the Jacobi term + the drift)
