@@ -260,10 +260,10 @@ def c3_section(ctx, n, mode, device):
         if label == "jacobi":
             # The roofline above prices the stack's 144 algorithmic bytes.  Jacobi coordinates tie every body to the sums over the
             # bodies before it and to the reactions of the bodies behind it: a forward and a backward sweep over data that does
-            # not fit on the chip cannot move less than 240 B per body, and the three sweeps of this implementation move 296 B.
-            out[label]["bytes_moved_per_body"] = 296
+            # not fit on the chip cannot move less than 240 B per body, and the three sweeps of this implementation move 280 B.
+            out[label]["bytes_moved_per_body"] = 280
             out[label]["two_sweep_floor_bytes_per_body"] = 240
-            out[label]["frac_of_peak_on_bytes_moved"] = 296 * n / dt / 1e9 / HBM_PEAK_GBS
+            out[label]["frac_of_peak_on_bytes_moved"] = 280 * n / dt / 1e9 / HBM_PEAK_GBS
     return out
 
 

@@ -91,13 +91,12 @@ struct HeadConsts {
 //   EPI_WHB   nsub consecutive Wisdom-Holman steps of every body, which stays in registers in between;
 //             an instance of its own so that the one-step pass keeps its register allocation
 enum { EPI_NONE = 0, EPI_WH = 1, EPI_EULER = 2, EPI_RK2 = 3, EPI_RK4 = 4, EPI_IM = 5, EPI_APPLY = 6, EPI_WHB = 7 };
-// What the per-body pass of a prefix-sum force leaves for the pass that applies it: the force in the body's
-// own frame (aj), the share of it that falls back on the bodies before (share), the reactions summed over
-// the workgroups behind each workgroup of that pass (behind_blocks, 3 per workgroup) and per wavefront
-// segment (wave_totals, 3 per segment, waves_per_block segments of segment_bodies bodies per workgroup);
-// all != nullptr (barycentric coordinates): every body receives the same total instead.
-struct ScanTail { const double* aj[3]; const double* share; const double* behind_blocks; const double* wave_totals; const double* all;
-                  int waves_per_block, segment_bodies; };
+// What the per-body pass of a prefix-sum force leaves for the pass that applies it, which works one wavefront per part of a
+// wavefront segment of that pass (segment_bodies bodies in SSUB parts): the force in the body's own frame (aj) and, per part,
+// the mass of every body before the part (part_mass: the share of a body's force that falls back on the bodies before it,
+// m / (eta + m), is formed from it and a prefix sum of the masses over the wavefront) and the reactions summed over every body
+// behind the part (part_behind, 3 per part); all != nullptr (barycentric coordinates): every body receives the same total instead.
+struct ScanTail { const double* aj[3]; const double* part_mass; const double* part_behind; const double* all; int segment_bodies; };
 struct StepArgs { double h, dtk; const double* star; int epi; double c0, c1, c2; double* aux[3]; double* partials;
                   const double* star0; double h0;      // EPI_WH: a leading Kepler drift over h0 about the record star0 (nullptr: none)
                   ScanTail tail;                       // EPI_APPLY

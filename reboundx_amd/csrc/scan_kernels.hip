@@ -121,7 +121,11 @@ template <int KIND, bool EXACT>
 __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, const double* nax, const double* nay, const double* naz,
                                                 const double* blocksums, const double* wavesums, const double* totals,
                                                 double* ajx, double* ajy, double* ajz, double* wf,
-                                                double* wsums, double* wwave, unsigned* status, const double* pre, long long first_acting, const double* m0) {
+                                                double* wsums, double* wwave, unsigned* status, const double* pre, long long first_acting, const double* m0,
+                                                double* wrun = nullptr, double* part_mass = nullptr) {
+    // wrun (may be null): running totals of the reactions at the end of each of the first SSUB - 1 parts of every segment, for
+    // a pass that applies the force one wavefront per part; part_mass (with wrun): the mass of every body before each part --
+    // that pass then forms the share f = m / (eta + m) itself (wf is not written)
     constexpr int C = (KIND == SCAN_GR) ? 10 : 7;
     __shared__ double lds3[SW][3];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -145,6 +149,8 @@ __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, cons
         const long long i = seg + t * 64 + lane;
         const bool live = i < v.n;
         if (t + 1 < ST) nxt.load(v, nax, nay, naz, i + 64);
+        if (KIND != SCAN_MOF_BARY && part_mass != nullptr && t % (ST / SSUB) == 0 && lane == 0)
+            part_mass[((long long)blockIdx.x * SW + wave) * SSUB + t / (ST / SSUB)] = base[0];
         double q[C], own[C];
         q[0] = cur.m;
         q[1] = cur.m * cur.x; q[2] = cur.m * cur.y; q[3] = cur.m * cur.z;
@@ -189,8 +195,16 @@ __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, cons
             // the reaction itself (f times the force) is not stored: the last pass forms it again
             // from these four numbers, with the same rounding
             __builtin_nontemporal_store(a.x, ajx + i); __builtin_nontemporal_store(a.y, ajy + i); __builtin_nontemporal_store(a.z, ajz + i);
-            if (KIND != SCAN_MOF_BARY) __builtin_nontemporal_store(f, wf + i);
+            if (KIND != SCAN_MOF_BARY && part_mass == nullptr) __builtin_nontemporal_store(f, wf + i);
             wacc[0] += reaction(f, a.x); wacc[1] += reaction(f, a.y); wacc[2] += reaction(f, a.z);
+        }
+        if (wrun != nullptr && (t + 1) % (ST / SSUB) == 0 && t + 1 < ST) {
+            const int part = (t + 1) / (ST / SSUB) - 1;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const double h = wave_total(wacc[k], lane);
+                if (lane == 0) wrun[(((long long)blockIdx.x * SW + wave) * (SSUB - 1) + part) * 3 + k] = h;
+            }
         }
         if (KIND != SCAN_MOF_BARY) {
 #pragma unroll
@@ -460,14 +474,32 @@ __global__ __launch_bounds__(SB) void gr_hamiltonian_main(View v, double G, doub
     }
 }
 
+// Table for a pass that applies the force one wavefront per part of a segment (thread = part): the reactions of every body
+// behind the part (part_behind, 3 per part), from the exclusive sums per workgroup (wsum), the totals per segment (wwave) and
+// the running totals inside the segments (wrun).
+__global__ __launch_bounds__(256) void scan_part_tables(const double* wsum, const double* wwave, const double* wrun, long long nparts, double* part_behind) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nparts) return;
+    const long long seg = idx / SSUB, block = seg / SW;
+    const int part = (int)(idx % SSUB), w = (int)(seg % SW);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double behind = wsum[block * 3 + k];
+        for (int q = SW - 1; q > w; q--) behind += wwave[(block * SW + q) * 3 + k];
+        // (the rest of this segment: its total less the running total at the end of this part)
+        if (part + 1 < SSUB) behind += wwave[seg * 3 + k] - wrun[(seg * (SSUB - 1) + part) * 3 + k];
+        part_behind[idx * 3 + k] = behind;
+    }
+}
+
 // ------------------------------------------------------------------ host driver
 int scan_segment_bodies() { return 64 * ST; }
 size_t scan_workspace_doubles(long long n) {
     const long long nb = (n + SB - 1) / SB;
     const long long nbs = (n + SCHUNK - 1) / SCHUNK;
     // 7 body columns (newton 3, aJ 3, reaction share 1) + compact list (4 doubles + 1 index) + workgroup sums (10 + 3 + 1) + totals
-    // + wavefront sums of the weighted-sum passes
-    return (size_t)(7 * n + 5 * n + 14 * nb + 64 + 13 * SW * nbs);
+    // + wavefront sums of the weighted-sum passes, running totals inside the segments and the table per part
+    return (size_t)(7 * n + 5 * n + 14 * nb + 64 + (13 + 7 * SSUB) * SW * nbs);
 }
 
 hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, double* ws, unsigned* status, hipStream_t st, ScanTail* tail) {
@@ -488,6 +520,9 @@ hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, 
     const long long nbs = (n + SCHUNK - 1) / SCHUNK;        // workgroups of the weighted-sum passes
     double* wavesums = count + 8;                           // nbs * SW * 10
     double* wwave = wavesums + 10 * SW * nbs;               // nbs * SW * 3
+    double* wrun = tail != nullptr ? wwave + 3 * SW * nbs : nullptr;            // nbs * SW * (SSUB - 1) * 3
+    double* part_behind = wwave + 3 * SSUB * SW * nbs;                          // nbs * SW * SSUB * 3
+    double* part_mass = tail != nullptr ? part_behind + 3 * SSUB * SW * nbs : nullptr;      // nbs * SW * SSUB
     const dim3 g((unsigned)nb), gs((unsigned)nbs), b(SB);
     int kind = SCAN_GR;
     if (op.kind == REBXAMD_OP_MOF) kind = (op.iarg == REBX_COORDINATES_BARYCENTRIC) ? SCAN_MOF_BARY : SCAN_MOF_JACOBI;
@@ -499,23 +534,27 @@ hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, 
         else hipLaunchKernelGGL(newton_from_compact<false>, g, b, 0, st, v, cx, cy, cz, cgm, cidx, count, nax, nay, naz);
         hipLaunchKernelGGL(scan_block_totals<10>, gs, b, 0, st, v, nax, nay, naz, bs, wavesums);
         hipLaunchKernelGGL((scan_of_totals<10, false>), dim3(10), dim3(SOT), 0, st, bs, nbs, totals);
-        if (exact) hipLaunchKernelGGL((scan_main<SCAN_GR, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wf, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
-        else hipLaunchKernelGGL((scan_main<SCAN_GR, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wf, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
+        if (exact) hipLaunchKernelGGL((scan_main<SCAN_GR, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wf, wsum, wwave, status, (const double*)nullptr, 1LL, v.m, wrun, part_mass);
+        else hipLaunchKernelGGL((scan_main<SCAN_GR, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wf, wsum, wwave, status, (const double*)nullptr, 1LL, v.m, wrun, part_mass);
     } else {
         hipLaunchKernelGGL(scan_block_totals<7>, gs, b, 0, st, v, nax, nay, naz, bs, wavesums);
         hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(7), dim3(SOT), 0, st, bs, nbs, totals);
         if (kind == SCAN_MOF_JACOBI) {
-            if (exact) hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wf, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
-            else hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wf, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
+            if (exact) hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wf, wsum, wwave, status, (const double*)nullptr, 1LL, v.m, wrun, part_mass);
+            else hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wf, wsum, wwave, status, (const double*)nullptr, 1LL, v.m, wrun, part_mass);
         } else {
-            if (exact) hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wf, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
-            else hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wf, wsum, wwave, status, (const double*)nullptr, 1LL, v.m);
+            if (exact) hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wf, wsum, wwave, status, (const double*)nullptr, 1LL, v.m, wrun, part_mass);
+            else hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wf, wsum, wwave, status, (const double*)nullptr, 1LL, v.m, wrun, part_mass);
         }
     }
     hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(3), dim3(SOT), 0, st, wsum, nbs, wtot);
     if (tail != nullptr) {
         // the caller's streaming pass applies the force
-        *tail = ScanTail{{ajx, ajy, ajz}, wf, wsum, wwave, kind == SCAN_MOF_BARY ? wtot : nullptr, SW, 64 * ST};
+        *tail = ScanTail{{ajx, ajy, ajz}, part_mass, part_behind, kind == SCAN_MOF_BARY ? wtot : nullptr, 64 * ST};
+        if (kind != SCAN_MOF_BARY) {
+            const long long nparts = nbs * SW * SSUB;
+            hipLaunchKernelGGL(scan_part_tables, dim3((unsigned)((nparts + 255) / 256)), dim3(256), 0, st, wsum, wwave, wrun, nparts, part_behind);
+        }
         return hipGetLastError();
     }
     if (kind == SCAN_MOF_BARY) hipLaunchKernelGGL(scan_apply<true>, gs, b, 0, st, v, ajx, ajy, ajz, wf, wsum, wwave, wtot, (const double*)nullptr);

@@ -11,6 +11,8 @@ static constexpr int SB = 256;          // elements per scan workgroup (one per 
 static constexpr int SW = SB / 64;
 static constexpr int ST = 8;            // tiles of SB elements per workgroup in the weighted-sum passes: short lists of workgroup totals
 static constexpr int SCHUNK = SB * ST;
+static constexpr int SSUB = 4;          // parts of a wavefront segment at whose ends the per-body pass can leave running totals (ST / SSUB tiles each)
+static_assert(ST % SSUB == 0, "whole tiles per part");
 
 // Workgroup-wide scan of C values per thread.  REVERSE: suffix instead of prefix.
 // On return v[c] holds the INCLUSIVE scan and tot[c] the workgroup total.

@@ -23,6 +23,7 @@
 #include "kepler.h"
 #include "updates.h"
 #include "wave_ops.h"
+#include "scan_ops.h"
 #include "wh_head.h"
 
 namespace rebxamd {
@@ -792,6 +793,19 @@ __global__ __launch_bounds__(BLOCK, stream_min_blocks(EXACT, BACKREACT, COLS, SI
         blk = ((seq / XCD_RUN) * 8u + xcd) * XCD_RUN + seq % XCD_RUN;
         if (blk >= nb) return;
     }
+    // A pass that applies a prefix-sum force, one wavefront per part of a segment of the per-body pass: the reactions of the
+    // bodies behind the part are asked for first, so that they arrive together with the columns
+    double tab_behind[3] = {0., 0., 0.}, tab_mass = 0.;
+    if constexpr (EPI == EPI_APPLY) {
+        static_assert(WAVES == SSUB && 2 * BLOCK == 64 * ST, "one wavefront per part of a segment of the weighted-sum passes");
+        const ScanTail& T = step.tail;
+        if (T.all == nullptr) {
+            const long long part = (long long)blk * SSUB + (tid >> 6);
+#pragma unroll
+            for (int c = 0; c < 3; c++) tab_behind[c] = T.part_behind[part * 3 + c];
+            tab_mass = T.part_mass[part];
+        }
+    }
     const long long i0 = base + 2 * ((long long)blk * BLOCK + tid);
     const bool in0 = i0 < v.n, in1 = i0 + 1 < v.n;
     const bool act0 = in0 && i0 >= lo, act1 = in1 && i0 + 1 >= lo;
@@ -1013,12 +1027,11 @@ __global__ __launch_bounds__(BLOCK, stream_min_blocks(EXACT, BACKREACT, COLS, SI
         return;
     }
     if (EPI == EPI_APPLY) {
-        // The workgroup's 2*BLOCK bodies are one wavefront segment of the per-body pass (the
-        // launcher checks the sizes): the reactions behind the segment come from that pass's
-        // tables, those inside it from a suffix sum over the workgroup.
-        __shared__ double later[WAVES][3];
+        // The workgroup's 2*BLOCK bodies are one wavefront segment of the per-body pass (the launcher checks the sizes), each
+        // of its wavefronts one part of it: the reactions behind the part come from that pass's table, those inside it from a
+        // suffix sum over the wavefront.
         const ScanTail& T = step.tail;
-        const int wave = tid >> 6, lane = tid & 63;
+        const int lane = tid & 63;
         double aj[2][3], f[2] = {0., 0.};
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -1031,10 +1044,14 @@ __global__ __launch_bounds__(BLOCK, stream_min_blocks(EXACT, BACKREACT, COLS, SI
 #pragma unroll
             for (int c = 0; c < 3; c++) s[0][c] = s[1][c] = T.all[c];
         } else {
-            if (full) ldpair(T.share, i0, f[0], f[1]);
-            else { if (act0) f[0] = ldone(T.share, i0); if (act1) f[1] = ldone(T.share, i0 + 1); }
-            const long long sb = blk / T.waves_per_block;
-            const int sw = blk % T.waves_per_block;
+            {
+                // the share of each body's force that falls back on the bodies before it: m / (eta + m), eta = their mass
+                const double m0 = act0 ? p[0].m : 0., m1 = act1 ? p[1].m : 0.;
+                const double pair = m0 + m1;
+                const double eta0 = tab_mass + (wave_incl_scan(pair, lane) - pair), eta1 = eta0 + m0;
+                f[0] = eta0 + m0 > 0. ? m0 / (eta0 + m0) : 0.;
+                f[1] = eta1 + m1 > 0. ? m1 / (eta1 + m1) : 0.;
+            }
             double w[2][3], excl[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
@@ -1043,15 +1060,7 @@ __global__ __launch_bounds__(BLOCK, stream_min_blocks(EXACT, BACKREACT, COLS, SI
                 const double pair = w[0][c] + w[1][c];
                 const double incl = wave_incl_scan_rev(pair, lane);
                 excl[c] = incl - pair;                       // the lanes behind this one
-                if (lane == 0) later[wave][c] = incl;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                double behind = T.behind_blocks[sb * 3 + c];
-                for (int q = T.waves_per_block - 1; q > sw; q--) behind += T.wave_totals[(sb * T.waves_per_block + q) * 3 + c];
-                for (int q = WAVES - 1; q > wave; q--) behind += later[q][c];
-                s[1][c] = w[1][c] + (excl[c] + behind);
+                s[1][c] = w[1][c] + (excl[c] + tab_behind[c]);
                 s[0][c] = w[0][c] + s[1][c];
             }
         }
