@@ -229,6 +229,109 @@ __global__ __launch_bounds__(SB) void scan_main(View v, DevOp op, double G, cons
     }
 }
 
+// Pass 3 of modify_orbits_forces in Jacobi coordinates, default arithmetic, for a caller whose pass applies the force one
+// wavefront per part of a segment (16-byte aligned columns, which that caller has checked): a part is one tile of 128
+// consecutive bodies, two per lane -- 16-byte loads and stores and half the wavefront scans of the one-body-per-lane pass.
+// A tile's 1 KiB of requests per stream and wavefront keeps the memory system busy without a second set of registers for
+// the next tile (162 registers as it is: three wavefronts per SIMD; held to 128 it spills and loses 20 %).  Outputs as
+// scan_main's with wrun and part_mass (aJ stored, the share not).
+typedef double scan_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ldnt2(const double* col, long long i, long long n, double none, double& a, double& b) {
+    a = b = none;
+    if (col == nullptr) return;
+    if (i + 1 < n) { const scan_d2 t = __builtin_nontemporal_load(reinterpret_cast<const scan_d2*>(col + i)); a = t.x; b = t.y; }
+    else if (i < n) a = ldnt(col, i);
+}
+__device__ __forceinline__ void stnt2(double* col, long long i, long long n, double a, double b) {
+    if (i + 1 < n) { scan_d2 t; t.x = a; t.y = b; __builtin_nontemporal_store(t, reinterpret_cast<scan_d2*>(col + i)); }
+    else if (i < n) __builtin_nontemporal_store(a, col + i);
+}
+
+__global__ __launch_bounds__(SB) void mof_jacobi_pairs(View v, const double* blocksums, const double* wavesums, double* ajx, double* ajy, double* ajz,
+                                                       double* wsums, double* wwave, double* wrun, double* part_mass, const double* pre, long long first_acting) {
+    static_assert(ST / SSUB == 2, "a part is two tiles of 64 bodies = one tile of 128");
+    __shared__ double lds3[SW][3];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long seg = segment_start(wave);
+    const double nan = unset_value();
+    double base[7], run[3] = {0., 0., 0.};
+#pragma unroll
+    for (int c = 0; c < 7; c++) {
+        base[c] = blocksums[(long long)blockIdx.x * 7 + c];
+        for (int w = 0; w < wave; w++) base[c] += wavesums[((long long)blockIdx.x * SW + w) * 7 + c];
+        if (pre != nullptr) base[c] += pre[c];
+    }
+#pragma unroll 1
+    for (int t = 0; t < SSUB; t++) {
+        const long long i = seg + t * 128 + 2 * lane;
+        double m[2], r[6][2], tau[3][2];
+        ldnt2(v.m, i, v.n, 0., m[0], m[1]);
+        ldnt2(v.x, i, v.n, 0., r[0][0], r[0][1]); ldnt2(v.y, i, v.n, 0., r[1][0], r[1][1]); ldnt2(v.z, i, v.n, 0., r[2][0], r[2][1]);
+        ldnt2(v.vx, i, v.n, 0., r[3][0], r[3][1]); ldnt2(v.vy, i, v.n, 0., r[4][0], r[4][1]); ldnt2(v.vz, i, v.n, 0., r[5][0], r[5][1]);
+        ldnt2(v.ta, i, v.n, nan, tau[0][0], tau[0][1]); ldnt2(v.te, i, v.n, nan, tau[1][0], tau[1][1]); ldnt2(v.ti, i, v.n, nan, tau[2][0], tau[2][1]);
+        if (lane == 0) part_mass[((long long)blockIdx.x * SW + wave) * SSUB + t] = base[0];
+        // S0: the sums over every body before this lane's first body; base moves on to the end of the tile
+        double q0[7], S0[7];
+        {
+            q0[0] = m[0];
+            const double pair = m[0] + m[1];
+            const double incl = wave_incl_scan(pair, lane);
+            S0[0] = base[0] + (incl - pair);
+            base[0] += lane_value(incl, 63);
+        }
+#pragma unroll
+        for (int c = 1; c < 7; c++) {
+            q0[c] = m[0] * r[c - 1][0];
+            const double pair = q0[c] + m[1] * r[c - 1][1];
+            const double incl = wave_incl_scan(pair, lane);
+            S0[c] = base[c] + (incl - pair);
+            base[c] += lane_value(incl, 63);
+        }
+        double a2[3][2] = {{0., 0.}, {0., 0.}, {0., 0.}}, wl[3] = {0., 0., 0.};
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (i + k >= v.n || i + k < first_acting) continue;
+            double S[7];
+#pragma unroll
+            for (int c = 0; c < 7; c++) S[c] = S0[c] + (k ? q0[c] : 0.);
+            const double eta = S[0], mi = m[k];
+            Part p;
+            p.x = r[0][k]; p.y = r[1][k]; p.z = r[2][k]; p.vx = r[3][k]; p.vy = r[4][k]; p.vz = r[5][k]; p.m = mi;
+            p.beta = p.Rt = p.k1 = nan;
+            p.ta = tau[0][k]; p.te = tau[1][k]; p.ti = tau[2][k];
+            Src ref;
+            const double inv = eta > 0. ? 1. / eta : 1.;
+            ref.x = S[1] * inv; ref.y = S[2] * inv; ref.z = S[3] * inv; ref.vx = S[4] * inv; ref.vy = S[5] * inv; ref.vz = S[6] * inv; ref.m = eta;
+            V3 a = {0., 0., 0.};
+            mof_fast(p, ref, a);
+            const double f = mi / (eta + mi);
+            a2[0][k] = a.x; a2[1][k] = a.y; a2[2][k] = a.z;
+            wl[0] += reaction(f, a.x); wl[1] += reaction(f, a.y); wl[2] += reaction(f, a.z);
+        }
+        stnt2(ajx, i, v.n, a2[0][0], a2[0][1]); stnt2(ajy, i, v.n, a2[1][0], a2[1][1]); stnt2(ajz, i, v.n, a2[2][0], a2[2][1]);
+#pragma unroll
+        for (int k = 0; k < 3; k++) run[k] += wave_total(wl[k], lane);
+        if (t + 1 < SSUB && lane == 0) {
+            const long long hrow = ((long long)blockIdx.x * SW + wave) * (SSUB - 1) + t;
+#pragma unroll
+            for (int k = 0; k < 3; k++) wrun[hrow * 3 + k] = run[k];
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { lds3[wave][k] = run[k]; wwave[((long long)blockIdx.x * SW + wave) * 3 + k] = run[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            double t = 0.;
+            for (int w = 0; w < SW; w++) t += lds3[w][k];
+            wsums[(long long)blockIdx.x * 3 + k] = t;
+        }
+    }
+}
+
 // pass 5: a_i += aJ_i - (sum of the reactions of bodies k >= i)   [barycentric: of all bodies]
 // A tile's loads carry no branch (rows behind the end read the last body and are masked) and the
 // next tile is requested before the current one is worked on.
@@ -541,6 +644,8 @@ hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, 
         hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(7), dim3(SOT), 0, st, bs, nbs, totals);
         if (kind == SCAN_MOF_JACOBI) {
             if (exact) hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wf, wsum, wwave, status, (const double*)nullptr, 1LL, v.m, wrun, part_mass);
+            else if (tail != nullptr && (n & 1) == 0)     // (an even n keeps the workspace columns 16-byte aligned, like the caller's)
+                hipLaunchKernelGGL(mof_jacobi_pairs, gs, b, 0, st, v, (const double*)bs, (const double*)wavesums, ajx, ajy, ajz, wsum, wwave, wrun, part_mass, (const double*)nullptr, 1LL);
             else hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wf, wsum, wwave, status, (const double*)nullptr, 1LL, v.m, wrun, part_mass);
         } else {
             if (exact) hipLaunchKernelGGL((scan_main<SCAN_MOF_BARY, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wf, wsum, wwave, status, (const double*)nullptr, 1LL, v.m, wrun, part_mass);
