@@ -92,11 +92,14 @@ struct HeadConsts {
 //             an instance of its own so that the one-step pass keeps its register allocation
 enum { EPI_NONE = 0, EPI_WH = 1, EPI_EULER = 2, EPI_RK2 = 3, EPI_RK4 = 4, EPI_IM = 5, EPI_APPLY = 6, EPI_WHB = 7 };
 // What the per-body pass of a prefix-sum force leaves for the pass that applies it, which works one wavefront per part of a
-// wavefront segment of that pass (segment_bodies bodies in SSUB parts): the force in the body's own frame (aj) and, per part,
-// the mass of every body before the part (part_mass: the share of a body's force that falls back on the bodies before it,
-// m / (eta + m), is formed from it and a prefix sum of the masses over the wavefront) and the reactions summed over every body
-// behind the part (part_behind, 3 per part); all != nullptr (barycentric coordinates): every body receives the same total instead.
-struct ScanTail { const double* aj[3]; const double* part_mass; const double* part_behind; const double* all; int segment_bodies; };
+// wavefront segment of that pass (segment_bodies bodies in SSUB parts, SW segments per workgroup of that pass): the force in
+// the body's own frame (aj); per part, the mass of every body before the part (part_mass: the share of a body's force that
+// falls back on the bodies before it, m / (eta + m), is formed from it and a prefix sum of the masses over the wavefront); and
+// the reactions (3 doubles per row) summed over the workgroups behind each workgroup (behind_blocks), per segment (seg_totals)
+// and up to the end of each of the first SSUB - 1 parts of every segment (seg_running), from which every wavefront adds up the
+// reactions of the bodies behind its part.  all != nullptr (barycentric coordinates): every body receives the same total instead.
+struct ScanTail { const double* aj[3]; const double* part_mass; const double* behind_blocks; const double* seg_totals; const double* seg_running;
+                  const double* all; int segment_bodies; };
 struct StepArgs { double h, dtk; const double* star; int epi; double c0, c1, c2; double* aux[3]; double* partials;
                   const double* star0; double h0;      // EPI_WH: a leading Kepler drift over h0 about the record star0 (nullptr: none)
                   ScanTail tail;                       // EPI_APPLY

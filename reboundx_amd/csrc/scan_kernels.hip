@@ -577,24 +577,6 @@ __global__ __launch_bounds__(SB) void gr_hamiltonian_main(View v, double G, doub
     }
 }
 
-// Table for a pass that applies the force one wavefront per part of a segment (thread = part): the reactions of every body
-// behind the part (part_behind, 3 per part), from the exclusive sums per workgroup (wsum), the totals per segment (wwave) and
-// the running totals inside the segments (wrun).
-__global__ __launch_bounds__(256) void scan_part_tables(const double* wsum, const double* wwave, const double* wrun, long long nparts, double* part_behind) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= nparts) return;
-    const long long seg = idx / SSUB, block = seg / SW;
-    const int part = (int)(idx % SSUB), w = (int)(seg % SW);
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        double behind = wsum[block * 3 + k];
-        for (int q = SW - 1; q > w; q--) behind += wwave[(block * SW + q) * 3 + k];
-        // (the rest of this segment: its total less the running total at the end of this part)
-        if (part + 1 < SSUB) behind += wwave[seg * 3 + k] - wrun[(seg * (SSUB - 1) + part) * 3 + k];
-        part_behind[idx * 3 + k] = behind;
-    }
-}
-
 // ------------------------------------------------------------------ host driver
 int scan_segment_bodies() { return 64 * ST; }
 size_t scan_workspace_doubles(long long n) {
@@ -602,7 +584,7 @@ size_t scan_workspace_doubles(long long n) {
     const long long nbs = (n + SCHUNK - 1) / SCHUNK;
     // 7 body columns (newton 3, aJ 3, reaction share 1) + compact list (4 doubles + 1 index) + workgroup sums (10 + 3 + 1) + totals
     // + wavefront sums of the weighted-sum passes, running totals inside the segments and the table per part
-    return (size_t)(7 * n + 5 * n + 14 * nb + 64 + (13 + 7 * SSUB) * SW * nbs);
+    return (size_t)(7 * n + 5 * n + 14 * nb + 64 + (13 + 4 * SSUB) * SW * nbs);
 }
 
 hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, double* ws, unsigned* status, hipStream_t st, ScanTail* tail) {
@@ -624,8 +606,7 @@ hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, 
     double* wavesums = count + 8;                           // nbs * SW * 10
     double* wwave = wavesums + 10 * SW * nbs;               // nbs * SW * 3
     double* wrun = tail != nullptr ? wwave + 3 * SW * nbs : nullptr;            // nbs * SW * (SSUB - 1) * 3
-    double* part_behind = wwave + 3 * SSUB * SW * nbs;                          // nbs * SW * SSUB * 3
-    double* part_mass = tail != nullptr ? part_behind + 3 * SSUB * SW * nbs : nullptr;      // nbs * SW * SSUB
+    double* part_mass = tail != nullptr ? wwave + 3 * SSUB * SW * nbs : nullptr;            // nbs * SW * SSUB
     const dim3 g((unsigned)nb), gs((unsigned)nbs), b(SB);
     int kind = SCAN_GR;
     if (op.kind == REBXAMD_OP_MOF) kind = (op.iarg == REBX_COORDINATES_BARYCENTRIC) ? SCAN_MOF_BARY : SCAN_MOF_JACOBI;
@@ -655,11 +636,7 @@ hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, 
     hipLaunchKernelGGL((scan_of_totals<3, true>), dim3(3), dim3(SOT), 0, st, wsum, nbs, wtot);
     if (tail != nullptr) {
         // the caller's streaming pass applies the force
-        *tail = ScanTail{{ajx, ajy, ajz}, part_mass, part_behind, kind == SCAN_MOF_BARY ? wtot : nullptr, 64 * ST};
-        if (kind != SCAN_MOF_BARY) {
-            const long long nparts = nbs * SW * SSUB;
-            hipLaunchKernelGGL(scan_part_tables, dim3((unsigned)((nparts + 255) / 256)), dim3(256), 0, st, wsum, wwave, wrun, nparts, part_behind);
-        }
+        *tail = ScanTail{{ajx, ajy, ajz}, part_mass, wsum, wwave, wrun, kind == SCAN_MOF_BARY ? wtot : nullptr, 64 * ST};
         return hipGetLastError();
     }
     if (kind == SCAN_MOF_BARY) hipLaunchKernelGGL(scan_apply<true>, gs, b, 0, st, v, ajx, ajy, ajz, wf, wsum, wwave, wtot, (const double*)nullptr);

@@ -800,10 +800,24 @@ __global__ __launch_bounds__(BLOCK, stream_min_blocks(EXACT, BACKREACT, COLS, SI
         static_assert(WAVES == SSUB && 2 * BLOCK == 64 * ST, "one wavefront per part of a segment of the weighted-sum passes");
         const ScanTail& T = step.tail;
         if (T.all == nullptr) {
-            const long long part = (long long)blk * SSUB + (tid >> 6);
+            // (blk = this workgroup's segment of the per-body pass; every address is known here, so the requests leave together)
+            const int part = tid >> 6, w = (int)(blk % SW);
+            const long long seg = blk, first = seg - w;          // first: segment 0 of the same workgroup of that pass
+            const long long running = (seg * (SSUB - 1) + (part + 1 < SSUB ? part : SSUB - 2)) * 3;
 #pragma unroll
-            for (int c = 0; c < 3; c++) tab_behind[c] = T.part_behind[part * 3 + c];
-            tab_mass = T.part_mass[part];
+            for (int c = 0; c < 3; c++) {
+                double later[SW];
+#pragma unroll
+                for (int q = 1; q < SW; q++) later[q] = T.seg_totals[(first + q) * 3 + c];
+                const double own = T.seg_totals[seg * 3 + c], done = T.seg_running[running + c];
+                double behind = T.behind_blocks[(first / SW) * 3 + c];
+#pragma unroll
+                for (int q = SW - 1; q >= 1; q--) if (q > w) behind += later[q];
+                // (the rest of this segment: its total less the running total at the end of this wavefront's part)
+                if (part + 1 < SSUB) behind += own - done;
+                tab_behind[c] = behind;
+            }
+            tab_mass = T.part_mass[seg * SSUB + part];
         }
     }
     const long long i0 = base + 2 * ((long long)blk * BLOCK + tid);
@@ -1315,6 +1329,8 @@ hipError_t launch_stream(const View& v, const Program& prog, long long lo, const
                          int* nblocks_out, bool backreact, bool exact, bool vec2, bool fixed, unsigned* status, hipStream_t st, const StepArgs* step) {
     if (step && step->epi == EPI_APPLY) {
         if (!backreact || exact || !vec2 || lo != 0 || step->tail.segment_bodies != 2 * BLOCK) return hipErrorInvalidValue;
+        if (step->tail.all == nullptr && (step->tail.behind_blocks == nullptr || step->tail.seg_totals == nullptr || step->tail.seg_running == nullptr || step->tail.part_mass == nullptr))
+            return hipErrorInvalidValue;
     } else if (step && backreact) return hipErrorInvalidValue;
     const long long base = lo & ~1ll;
     const int nb = stream_block_count(lo, v.n, vec2);
