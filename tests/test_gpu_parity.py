@@ -373,7 +373,7 @@ RIDING_STACKS = {
 
 @pytest.mark.parametrize("fixed", [True, False])
 @pytest.mark.parametrize("stack", sorted(RIDING_STACKS))
-@pytest.mark.parametrize("n", [700, 20_001])
+@pytest.mark.parametrize("n", [510, 514, 700, 2050, 8194, 20_001])        # (around the 128-, 512- and 2048-body marks of the passes; even and odd)
 def test_streaming_pass_that_also_applies_a_prefix_sum_force(ctx, n, stack, fixed):
     """Default arithmetic, massive bodies anywhere: the pass of the streaming forces also adds the
     last prefix-sum force (its force per body minus the reactions of the bodies behind), so the
