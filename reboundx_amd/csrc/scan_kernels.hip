@@ -584,19 +584,20 @@ size_t scan_workspace_doubles(long long n) {
     const long long nbs = (n + SCHUNK - 1) / SCHUNK;
     // 7 body columns (newton 3, aJ 3, reaction share 1) + compact list (4 doubles + 1 index) + workgroup sums (10 + 3 + 1) + totals
     // + wavefront sums of the weighted-sum passes, running totals inside the segments and the table per part
-    return (size_t)(7 * n + 5 * n + 14 * nb + 64 + (13 + 4 * SSUB) * SW * nbs);
+    return (size_t)(12 * ((n + 1) & ~1LL) + 14 * nb + 64 + (13 + 4 * SSUB) * SW * nbs);
 }
 
 hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, double* ws, unsigned* status, hipStream_t st, ScanTail* tail) {
     const long long n = v.n;
     if (n <= 0) return hipSuccess;
     const long long nb = (n + SB - 1) / SB;
-    double* nax = ws; double* nay = nax + n; double* naz = nay + n;
-    double* ajx = naz + n; double* ajy = ajx + n; double* ajz = ajy + n;
-    double* wf = ajz + n;
-    double* cx = wf + n; double* cy = cx + n; double* cz = cy + n; double* cgm = cz + n;
-    long long* cidx = reinterpret_cast<long long*>(cgm + n);
-    double* bs = reinterpret_cast<double*>(cidx + n);      // nb * 10
+    const long long ns = (n + 1) & ~1LL;                    // every body column of the workspace starts 16-byte aligned
+    double* nax = ws; double* nay = nax + ns; double* naz = nay + ns;
+    double* ajx = naz + ns; double* ajy = ajx + ns; double* ajz = ajy + ns;
+    double* wf = ajz + ns;
+    double* cx = wf + ns; double* cy = cx + ns; double* cz = cy + ns; double* cgm = cz + ns;
+    long long* cidx = reinterpret_cast<long long*>(cgm + ns);
+    double* bs = reinterpret_cast<double*>(cidx + ns);     // nb * 10
     double* wsum = bs + 10 * nb;                            // nb * 3
     double* fl = wsum + 3 * nb;                             // nb
     double* totals = fl + nb;                               // 16
@@ -625,7 +626,7 @@ hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, 
         hipLaunchKernelGGL((scan_of_totals<7, false>), dim3(7), dim3(SOT), 0, st, bs, nbs, totals);
         if (kind == SCAN_MOF_JACOBI) {
             if (exact) hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, true>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wf, wsum, wwave, status, (const double*)nullptr, 1LL, v.m, wrun, part_mass);
-            else if (tail != nullptr && (n & 1) == 0)     // (an even n keeps the workspace columns 16-byte aligned, like the caller's)
+            else if (tail != nullptr)
                 hipLaunchKernelGGL(mof_jacobi_pairs, gs, b, 0, st, v, (const double*)bs, (const double*)wavesums, ajx, ajy, ajz, wsum, wwave, wrun, part_mass, (const double*)nullptr, 1LL);
             else hipLaunchKernelGGL((scan_main<SCAN_MOF_JACOBI, false>), gs, b, 0, st, v, op, G, nax, nay, naz, bs, wavesums, totals, ajx, ajy, ajz, wf, wsum, wwave, status, (const double*)nullptr, 1LL, v.m, wrun, part_mass);
         } else {
