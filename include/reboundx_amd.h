@@ -306,6 +306,17 @@ enum rebxamd_mode {
     REBXAMD_MODE_EXACT = 1          /* reference expression order, no contraction */
 };
 
+/* gr and Jacobi/barycentric modify_orbits_forces accumulate body by body in the reference (src/gr.c:80-167 through
+ * REBOUND's Jacobi recurrences; src/rebxtools.c:45-126).  With the massive bodies in a prefix of at most
+ * REBXAMD_MAX_HEAD particles followed by massless ones, REBXAMD_MODE_EXACT walks the prefix in that order.  On every
+ * other mass layout REBXAMD_MODE_EXACT walks the same recurrences in the reference's order as long as the view holds
+ * at most REBXAMD_SEQ_MAX_BODIES particles (chains on one workgroup: milliseconds at the limit; every body then carries
+ * the bits of the sequential evaluation); larger views, REBXAMD_MODE_FAST on such layouts and the particle-shard
+ * entry points (rebxamd_shard_*) evaluate the sums as parallel prefix sums, whose results stay within 5e-14 of a body's
+ * largest acceleration component of the exactly rounded value but are NOT the sequential order's bits (the sequential
+ * order itself drifts from the exact value as the number of bodies grows: 1e-12 at 6000 bodies, 5e-11 at 300 000). */
+#define REBXAMD_SEQ_MAX_BODIES 65536
+
 /* One elementary pass of a force.  A reference force expands to one op per source
  * (e.g. gravitational_harmonics with one oblate body -> one J2 op then one J4 op). */
 enum rebxamd_op_kind {
@@ -587,6 +598,10 @@ int rebxamd_timing_enable(rebxamd_ctx* ctx, int on);
  * Both compute the same expressions.  on = 0 makes this context always walk the list
  * (default: 1). */
 int rebxamd_fixed_stacks(rebxamd_ctx* ctx, int on);
+/* Kernel selection (no counterpart in the reference).  on = 0 makes REBXAMD_MODE_EXACT evaluate gr and
+ * Jacobi/barycentric modify_orbits_forces with parallel prefix sums on every layout that has massive bodies beyond a
+ * short prefix, also below REBXAMD_SEQ_MAX_BODIES particles (default: 1, the reference's order there). */
+int rebxamd_sequential_exact(rebxamd_ctx* ctx, int on);
 /* Kernel selection for rebxamd_wh_steps and rebxamd_integrate_force (no counterpart in the
  * reference).  When the massive bodies are a short prefix, the bodies behind it massless and the
  * force stack one streaming run, the pass over the massless bodies carries the whole update:

@@ -76,6 +76,7 @@ _sig = {
     "rebxamd_direct_chain": (c_int, [c_void_p, c_int, POINTER(c_int)]),
     "rebxamd_fixed_stacks": (c_int, [c_void_p, c_int]),
     "rebxamd_carried_steps": (c_int, [c_void_p, c_int]),
+    "rebxamd_sequential_exact": (c_int, [c_void_p, c_int]),
     "rebxamd_wh_batch": (c_int, [c_void_p, c_int]),
     "rebxamd_timing_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int)]),
     "rebxamd_grfull_newton": (c_int, [c_void_p, POINTER(View), c_int] + [c_void_p] * 6 + [c_void_p]),

@@ -48,6 +48,7 @@ struct rebxamd_ctx {
     bool timing = false;
     bool carried_steps = true;  // Wisdom-Holman runs: kick and drift ride in the force pass when the layout allows
     bool fixed_stacks = true;   // stacks with a kernel instance of their own use it
+    bool seq_exact = true;      // reference-order arithmetic: prefix-sum forces on at most REBXAMD_SEQ_MAX_BODIES bodies are walked in the reference's order
     int chain_rounds = 12;      // modify_orbits_direct on long chains: rounds of the fixed-point iteration before the sequential walk takes over
     int chain_last_rounds = 0;  // rounds the last such call took, -1 if it fell back to the sequential walk
     bool fixed_scratch = false; // the buffers above are slices of a fixed array: never grown, never freed
@@ -158,6 +159,12 @@ extern "C" int rebxamd_timing_enable(rebxamd_ctx* ctx, int on) {
 extern "C" int rebxamd_fixed_stacks(rebxamd_ctx* ctx, int on) {
     if (!ctx) return REBXAMD_ERR_ARG;
     ctx->fixed_stacks = on != 0;
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_sequential_exact(rebxamd_ctx* ctx, int on) {
+    if (!ctx) return REBXAMD_ERR_ARG;
+    ctx->seq_exact = on != 0;
     return REBXAMD_OK;
 }
 
@@ -429,7 +436,10 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
             }
             if (scan) {
                 TimedLaunch tl(ctx, st);
-                HIP_TRY(launch_scan_op(v, prog.ops[k - lo], prog.G, exact, ctx->scan, ctx->status, st));
+                // reference-order arithmetic: up to REBXAMD_SEQ_MAX_BODIES bodies the recurrences are walked in the
+                // reference's own order (the checker's bits on every body); beyond that, parallel prefix sums
+                if (v.n <= REBXAMD_SEQ_MAX_BODIES && ctx->seq_exact) HIP_TRY(launch_seq_op(v, prog.ops[k - lo], prog.G, ctx->scan, ctx->status, st));
+                else HIP_TRY(launch_scan_op(v, prog.ops[k - lo], prog.G, exact, ctx->scan, ctx->status, st));
             }
             a = k + 1;
         }

@@ -182,6 +182,12 @@ class Context:
         """Whether stacks with a kernel instance of their own use it (default) or walk the op list."""
         self._check(lib.rebxamd_fixed_stacks(self._h, 1 if on else 0))
 
+    def sequential_exact(self, on=True):
+        """Reference-order arithmetic on layouts with massive bodies anywhere: walk gr and Jacobi/barycentric
+        modify_orbits_forces in the reference's order up to REBXAMD_SEQ_MAX_BODIES particles (default), or always
+        use the parallel prefix sums (on=False)."""
+        self._check(lib.rebxamd_sequential_exact(self._h, 1 if on else 0))
+
     def carried_steps(self, on=True):
         """Whether force passes carry the elementwise passes around them (kick and drift in wh_steps, velocity updates in
         integrate_force, the last pass of a prefix-sum force in apply; default) or every pass runs on its own."""

@@ -4,14 +4,24 @@ arithmetic modes and both kernel selections (instances built for a stack / walki
 list).  Seeds are fixed: every run tests the same cases.
 
 Bar: 1e-12 of the size of the particle's update vector (plus, for massive bodies, the size of
-the pushes they collect from the others, which arrive as parallel sums); stacks that go through
-the prefix-sum passes (gr or Jacobi/barycentric modify_orbits_forces with massive bodies beyond
-the head) get the allowance of those passes, n/1e4."""
+the pushes they collect from the others, which arrive as parallel sums).  Stacks that hold gr or
+Jacobi/barycentric modify_orbits_forces on a layout with massive bodies beyond the head: in
+reference-order arithmetic the device walks the reference's recurrences in the reference's order
+(all sizes here are below its limit), so the same bar holds; in the default arithmetic those two
+forces are parallel prefix sums, a different rounding of the same sums than the checker's
+sequential one, and the bar gains the checker's own distance from the exact result, measured per
+component without the device (|device - checker| <= |device - exact| + |checker - exact|): its
+distance from the binary128 value of each such force evaluated on zero accelerations, plus what
+the accelerations already in the columns do to its sequential additions -- a body with a large
+acceleration that collects thousands of reactions each smaller than half an ulp of it loses every
+one of them in the reference's order (seed 6956, body 1: the whole Jacobi reaction, 1.5e-15 on an
+acceleration of 0.038) -- which is the checker's update in place minus its update from zero."""
 import numpy as np
 import pytest
 
-from gpu_common import TOL, run_device, run_oracle
+from gpu_common import TOL, err_vs_exact, record, run_device, run_oracle, ulp_diff
 from reboundx_amd import synthetic
+from test_gpu_parity import ROUNDING, exact_and_sequential, is_prefix_sum_force, zero_acc
 
 pytestmark = pytest.mark.gpu
 C = synthetic.C_DEFAULT
@@ -72,6 +82,11 @@ def random_case(seed):
 @pytest.mark.parametrize("mode", [1, 0], ids=["exact", "fast"])
 @pytest.mark.parametrize("seed", range(150))
 def test_random_stack_layout_and_parameters(ctx, seed, mode):
+    run_case(ctx, seed, mode)
+
+
+def run_case(ctx, seed, mode):
+    """Runs case `seed`; returns whether the binary128 term had to be added to the bar."""
     cols, pp, stack, n, scan = random_case(seed)
     ref = run_oracle(cols, pp, stack)
     base = np.stack([cols["ax"], cols["ay"], cols["az"]])
@@ -80,11 +95,14 @@ def test_random_stack_layout_and_parameters(ctx, seed, mode):
     # massive bodies collect pushes from the others: sum_j m_j |update_j| / m_i bounds their size
     total = float((m * upd).sum())
     react = np.where(m > 0, (total - m * upd) / np.where(m > 0, m, 1.0), 0.0)
-    # floor: the reference adds up to n terms one after the other into a_i (barycentric reactions, pushes
-    # on a source), each addition rounding at the size of a_i; a regrouped sum differs by ~sqrt(n) such roundings
-    den = np.maximum(upd + react, np.abs(ref).max(axis=0) * (4 + np.sqrt(n)) * np.finfo(float).eps / TOL)
+    # floor: every force of the stack adds up to n terms one after the other into a_i in the reference (barycentric
+    # reactions, pushes on a source), each addition rounding at the size of a_i; a regrouped sum differs by
+    # ~sqrt(n x forces) such roundings
+    den = np.maximum(upd + react, np.abs(ref).max(axis=0) * (4 + np.sqrt(n * len(stack))) * np.finfo(float).eps / TOL)
     den = np.where(den == 0.0, 1.0, den)
-    bar = TOL * (max(1.0, n / 1e4) if scan else 1.0) * (16 if any(f[0] == "central_force" for f in stack) else 1)
+    bar = TOL * (16 if any(f[0] == "central_force" for f in stack) else 1)
+    allowed = bar * den[None, :] * np.ones((3, 1))
+    widened = False
     for fixed in (True, False):
         try:
             ctx.fixed_stacks(fixed)
@@ -92,8 +110,67 @@ def test_random_stack_layout_and_parameters(ctx, seed, mode):
         finally:
             ctx.fixed_stacks(True)
         assert np.isfinite(got).all(), (seed, stack)
-        err = np.abs(got - ref).max(axis=0) / den
-        assert err.max() <= bar, "seed %d stack %s: %.3e at particle %d (n=%d)" % (seed, [f[0] for f in stack], err.max(), int(err.argmax()), n)
+        err = np.abs(got - ref)
+        if scan and mode == 0 and not widened and (err > allowed).any():
+            # (binary128 is software arithmetic: evaluated only for the cases that need it)
+            for f in stack:
+                if is_prefix_sum_force(f):
+                    allowed = allowed + exact_and_sequential(cols, pp, f)[2]
+            allowed = allowed + np.abs((ref - base) - run_oracle(zero_acc(cols), pp, stack))
+            widened = True
+        excess = (err - allowed) / den[None, :]
+        assert excess.max() <= 0., "seed %d stack %s: %.3e beyond its bound at particle %d (n=%d)" % (
+            seed, [f[0] for f in stack], excess.max(), int(excess.max(axis=0).argmax()), n)
+    return widened
+
+
+# seeds beyond the collected range whose prefix-sum stacks were 1.0e-12 ... 2.3e-12 from the sequential checker
+# (Jacobi modify_orbits_forces and gr with 9 ... 9001 massive bodies among 4100 / 9001)
+FORMER_MISSES = [4858, 6577, 6956, 7457]
+
+
+@pytest.mark.parametrize("mode", [1, 0], ids=["exact", "fast"])
+@pytest.mark.parametrize("seed", FORMER_MISSES)
+def test_stacks_that_were_further_than_the_plain_bar_from_the_sequential_checker(ctx, seed, mode):
+    """Each prefix-sum force of these stacks against its binary128 value: the device's parallel sums stay at the
+    rounding level of the terms while the sequential checker itself is 1e-12 away on these layouts; then the
+    whole stack with the bound derived from that.  In reference-order arithmetic the stack is walked in the
+    reference's order and meets the plain bar."""
+    cols, pp, stack, n, scan = random_case(seed)
+    assert scan
+    zc = zero_acc(cols)
+    m = cols["m"]
+    dev_worst = seq_worst = 0.
+    for f in stack:
+        if not is_prefix_sum_force(f):
+            continue
+        hi, lo, seq_err = exact_and_sequential(zc, pp, f)
+        ctx.sequential_exact(False)         # (the prefix sums are what is measured, in either arithmetic)
+        try:
+            got, _ = run_device(ctx, zc, pp, [f], 1.0, mode)
+        finally:
+            ctx.sequential_exact(True)
+        dev_err = err_vs_exact(got, hi, lo)
+        # scale of the terms that enter a row: the body's own update and the reactions it collects, sum_j m_j |a_j| / m_i
+        upd = np.abs(hi).max(axis=0)
+        total = float((m * upd).sum())
+        scale = upd + np.where(m > 0, (total - m * upd) / np.where(m > 0, m, 1.0), 0.0)
+        scale = np.where(scale == 0., 1., scale)
+        dev_rel, seq_rel = (dev_err / scale[None, :]).max(), (seq_err / scale[None, :]).max()
+        record("fuzz-seed-%d:%s%s:n=%d:mode=%d" % (seed, f[0], f[1].get("coordinates", ""), n, mode), device_vs_terms=dev_rel, sequential_vs_terms=seq_rel)
+        # the device stays at the rounding level of the terms; a component whose own expression cancels (r.v of a nearly
+        # circular orbit) is no better in ANY fp64 evaluation: there, no further from exact than twice the checker
+        assert (dev_err <= np.maximum(ROUNDING * scale[None, :], 2. * seq_err)).all(), (f, dev_rel)
+        dev_worst, seq_worst = max(dev_worst, dev_rel), max(seq_worst, seq_rel)
+    assert seq_worst >= 5. * dev_worst, (seq_worst, dev_worst)      # what moved these cases is the checker's sequential sum
+    if mode == 1:
+        # reference-order arithmetic walks the reference's order: every body that is not the target of a parallel
+        # sum of pushes carries the checker's bits for a stack of the prefix-sum forces alone
+        only = [f for f in stack if is_prefix_sum_force(f)]
+        got, _ = run_device(ctx, cols, pp, only, 1.0, mode)
+        assert ulp_diff(got, run_oracle(cols, pp, only)).max() == 0
+    widened = run_case(ctx, seed, mode)
+    assert not (mode == 1 and widened)
 
 
 def random_tail_case(seed, planets_max):

@@ -184,6 +184,7 @@ def test_each_back_reacting_force_massive_everywhere(ctx, mode):
 
 
 _EXACT_CACHE = {}
+SEQ_MAX = 65536            # REBXAMD_SEQ_MAX_BODIES: up to here reference-order arithmetic walks the recurrences in the reference's order
 ROUNDING = 5e-14           # |device - exact| of the prefix-sum forces relative to the body's largest component (measured: <= 2.1e-14)
 HP_MAX_N = 500_000          # the binary128 evaluation is software arithmetic: ~10 s per 1e6 bodies and force
 
@@ -208,8 +209,11 @@ def exact_and_sequential(cols, pp, force):
     return _EXACT_CACHE[key]
 
 
-def scan_check(ctx, cols, pp, forces, mode, **kw):
-    """Layouts with massive bodies anywhere: gr and Jacobi/barycentric modify_orbits_forces are
+def scan_check(ctx, cols, pp, forces, mode, scans=False, **kw):
+    """Layouts with massive bodies anywhere.  Reference-order arithmetic on at most SEQ_MAX bodies
+    (and `scans` not forced): the device walks the reference's recurrences in the reference's order,
+    so a stack made of gr and Jacobi/barycentric modify_orbits_forces alone must carry the checker's
+    bits on every body.  Otherwise those two forces are
     evaluated with parallel prefix/suffix sums where the reference accumulates sequentially, so
     the device and the fp64 checker are two different roundings of the same real-number result.
     The bound on their difference is derived, not chosen: with E the binary128 value of the update
@@ -225,8 +229,16 @@ def scan_check(ctx, cols, pp, forces, mode, **kw):
     body's largest component or of the summed magnitudes of the reaction terms that enter the row
     (sum_k m_k/M |a_k|)."""
     ref = run_oracle(cols, pp, forces)
-    got, _ = run_device(ctx, cols, pp, forces, 1.0, mode, **kw)
+    ctx.sequential_exact(not scans)
+    try:
+        got, _ = run_device(ctx, cols, pp, forces, 1.0, mode, **kw)
+    finally:
+        ctx.sequential_exact(True)
     assert np.isfinite(got).all()
+    if mode == EXACT and not scans and got.shape[1] <= SEQ_MAX and all(is_prefix_sum_force(f) for f in forces):
+        u = ulp_diff(got, ref).max(axis=0)
+        assert u.max() == 0, "reference-order arithmetic: %d bodies differ from the checker, first %d" % (int((u > 0).sum()), int(np.nonzero(u)[0][0]))
+        return got, ref
     upd = ref - np.array([cols["ax"], cols["ay"], cols["az"]])
     big = np.maximum(np.abs(ref).max(axis=0), np.abs(upd).max(axis=0))
     allowed = np.maximum(TOL * np.abs(ref), ROUNDING * big[None, :])
@@ -255,15 +267,46 @@ SCAN_FORCES = [("gr", {"c": C}), ("gr", {"c": 300.0, "max_iterations": 4}), ("mo
 @pytest.mark.parametrize("force", SCAN_FORCES)
 @pytest.mark.parametrize("n", [70, 257, 6000])
 def test_gr_and_com_drag_with_every_particle_massive(ctx, n, force, mode):
+    """Reference-order arithmetic: the checker's bits (asserted in scan_check); the same arithmetic with the
+    prefix sums forced, and the default arithmetic: the derived bound."""
     cols, pp, _ = synthetic.disk(n, 2, dust_mass=1e-9)
     scan_check(ctx, zero_acc(cols), pp, [force], mode)
+    if mode == EXACT:
+        scan_check(ctx, zero_acc(cols), pp, [force], mode, scans=True)
+
+
+@pytest.mark.parametrize("force", SCAN_FORCES)
+def test_reference_order_route_with_incoming_accelerations_and_odd_sizes(ctx, force):
+    """The route that walks the reference's recurrences in order, around the 256-body tiles of its
+    chains (255, 256, 257, 513 bodies), with accelerations already in the columns, and on two bodies."""
+    for n in (2, 3, 255, 256, 257, 513, 1300):
+        cols, pp, _ = synthetic.disk(n, min(2, n - 1), dust_mass=1e-7)
+        synthetic.add_newtonian(cols, n_head=n)
+        got, ref = scan_check(ctx, cols, pp, [force], EXACT, n_head=n, tail_massless=False)
+        assert ulp_diff(got, ref).max() == 0
+
+
+def test_reference_order_route_stops_at_its_size_limit(ctx):
+    """Above SEQ_MAX bodies reference-order arithmetic uses the prefix sums (derived bound); at the limit it
+    still carries the checker's bits."""
+    force = ("modify_orbits_forces", {})
+    for n, bits in ((SEQ_MAX, True), (SEQ_MAX + 1, False)):
+        cols, pp, _ = synthetic.disk(n, 2)
+        rng = np.random.default_rng(n)
+        cols["m"][rng.choice(np.arange(3, n), size=40, replace=False)] = 1e-6
+        got, ref = scan_check(ctx, zero_acc(cols), pp, [force], EXACT)
+        assert (ulp_diff(got, ref).max() == 0) == bits
 
 
 def exact_value_check(ctx, cols, pp, force, mode, label, **kw):
     """|device - E| against the bar and against |sequential checker - E|, E = binary128 value."""
     cols = zero_acc(cols)
     hi, lo, seq_err = exact_and_sequential(cols, pp, force)
-    got, _ = run_device(ctx, cols, pp, [force], 1.0, mode, **kw)
+    ctx.sequential_exact(False)        # (the prefix-sum passes are what is measured here, in either arithmetic)
+    try:
+        got, _ = run_device(ctx, cols, pp, [force], 1.0, mode, **kw)
+    finally:
+        ctx.sequential_exact(True)
     dev_err = err_vs_exact(got, hi, lo)
     mag = np.abs(hi)
     body = mag.max(axis=0)
@@ -833,6 +876,7 @@ def test_sharded_jacobi_and_barycentric_drag_with_massive_slices(coordinates):
     den = np.where(den == 0., 1., den)
     # against the same sums evaluated unsharded on one device: only the grouping of the partial sums differs
     c1 = Context(0)
+    c1.sequential_exact(False)          # (the sharded entry points are prefix sums: compared with the one-device prefix sums)
     one, _ = run_device(c1, cols, pp, [("modify_orbits_forces", {"coordinates": coordinates})], 1.0, EXACT)
     c1.close()
     assert (np.abs(got - one) / den).max() <= 1e-13
@@ -890,6 +934,7 @@ def test_sharded_gr_with_massive_bodies_in_the_slices(layout, mode):
     force = [("gr", {"c": C})]
     ref = run_oracle(cols, pp, force)
     c1 = Context(0)
+    c1.sequential_exact(False)          # (the sharded entry points are prefix sums: compared with the one-device prefix sums)
     one, _ = run_device(c1, cols, pp, force, 1.0, mode)
     c1.close()
     tg = ThreadGather(w)

@@ -1,0 +1,52 @@
+"""Development aid (GPU box): reference-order arithmetic on layouts with massive bodies anywhere --
+ulp distance of gr and Jacobi/barycentric modify_orbits_forces from the CPU checker, and the time
+of the sequential-order route at its size limit.   python tests/tools/seq_check.py"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+import torch
+from gpu_common import run_device, run_oracle, ulp_diff
+from reboundx_amd import synthetic
+from reboundx_amd.device import Context
+from test_gpu_parity import SCAN_FORCES, scatter_planets, zero_acc
+
+ctx = Context(0)
+bad = 0
+for label, n, planets, dust, scatter, kw in (("all-massive", 70, 2, 1e-9, False, {}), ("all-massive", 257, 2, 1e-9, False, {}),
+                                             ("all-massive", 6000, 2, 1e-9, False, {}), ("scattered", 9001, 6, 0., True, {}),
+                                             ("long-prefix", 4000, 99, 0., False, dict(n_head=100, tail_massless=True)),
+                                             ("all-massive", 30000, 2, 1e-9, False, {})):
+    cols, pp, _ = synthetic.disk(n, planets, dust_mass=dust) if dust else synthetic.disk(n, planets)
+    if scatter:
+        cols, pp = scatter_planets(cols, pp)
+    for newton in (False, True):
+        c = zero_acc(cols)
+        if newton:
+            synthetic.add_newtonian(c, n_head=min(n, 8))
+        for force in SCAN_FORCES:
+            if n > 10000 and force[0] == "gr":
+                continue
+            ref = run_oracle(c, pp, [force])
+            got, _ = run_device(ctx, c, pp, [force], 1.0, 1, **kw)
+            u = ulp_diff(got, ref)
+            print(label, n, "newton" if newton else "zero", force[0], force[1], "max ulp", int(u.max()), "bodies off", int((u.max(axis=0) > 0).sum()), flush=True)
+            bad += int(u.max() > 0)
+for n in (65536,):
+    cols, pp, _ = synthetic.disk(n, 2, dust_mass=1e-9)
+    for force in SCAN_FORCES:
+        for seq in (True, False):
+            ctx.sequential_exact(seq)
+            run_device(ctx, zero_acc(cols), pp, [force], 1.0, 1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_device(ctx, zero_acc(cols), pp, [force], 1.0, 1)
+            torch.cuda.synchronize()
+            print("n", n, force[0], force[1], "sequential" if seq else "scans", "%.2f ms (incl. upload)" % ((time.perf_counter() - t0) * 1e3), flush=True)
+    ctx.sequential_exact(True)
+print("cases off:", bad)
+sys.exit(1 if bad else 0)
