@@ -16,6 +16,15 @@ committed JSON files, never the reference tree.
   notebook_kats.json -- numbers printed in the stored outputs of the reference's notebooks
       (ipython_examples/*.ipynb), with the cell they come from.
 
+  reference_archives.json, key "integrate_force" -- from reboundx/test/binaries/test.sa, the archive the
+      reference's test_simulationarchive.py writes (:44-47, :74-77, ...: one snapshot at t = 1000, one at
+      t = 2000, both reached with exact_finish_time, i.e. a shortened last step) next to test.rebx
+      (copied under tests/golden/rebx/): star + planet (m = 1e-4, a = 1, e = 0.2), dt = P/100, with
+      the integrate_force operator over gr (c = 100) as the one pre-timestep step, dt_fraction 1 and
+      no "integrator" parameter (the default scheme, Euler: src/integrate_force.c:40-44).  Also kept:
+      the archive's integrator field (REBOUND's binary field 51; the WHFast archives above hold 1
+      there, and so does this one) and gravity_ignore_terms (field 14).
+
 Floats are stored as C99 hex strings so that the fixtures are exact.
 """
 import json
@@ -46,7 +55,9 @@ def read_sa(path, max_snapshots):
         time = struct.unpack_from("<d", d, info[0][1])[0]
         p = np.frombuffer(d, dtype=np.float64, count=info[85][0] // 8, offset=info[85][1]).reshape(-1, 16)
         if not out:
-            scalars = {"G": struct.unpack_from("<d", d, info[1][1])[0], "dt": struct.unpack_from("<d", d, info[3][1])[0]}
+            scalars = {"G": struct.unpack_from("<d", d, info[1][1])[0], "dt": struct.unpack_from("<d", d, info[3][1])[0],
+                       "integrator": struct.unpack_from("<i", d, info[51][1])[0],
+                       "gravity_ignore_terms": struct.unpack_from("<i", d, info[14][1])[0]}
         out.append((time, p))
     return header, scalars, out
 
@@ -59,12 +70,23 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     arch = {"source": "reboundx/test/binaries/<force>.sa (reference test fixtures), all snapshots",
             "columns": ["x", "y", "z", "vx", "vy", "vz", "m"], "forces": {}}
+    whfast_field = None
     for name in FORCES:
         header, scalars, snaps = read_sa(os.path.join(REF, "reboundx", "test", "binaries", name + ".sa"), 99)
+        assert whfast_field in (None, scalars["integrator"])
+        whfast_field = scalars["integrator"]
         arch["header"] = header
         arch["G"], arch["dt"] = float(scalars["G"]).hex(), float(scalars["dt"]).hex()
         arch["forces"][name] = [{"t": float(t).hex(), "particles": [hexrow(np.concatenate([row[:6], row[9:10]])) for row in p]}
                                 for t, p in snaps]
+    header, scalars, snaps = read_sa(os.path.join(REF, "reboundx", "test", "binaries", "test.sa"), 99)
+    assert scalars["integrator"] == whfast_field and len(snaps) == 2
+    arch["integrate_force"] = {
+        "source": "reboundx/test/binaries/test.sa + test.rebx (written by reboundx/test/test_simulationarchive.py)",
+        "G": float(scalars["G"]).hex(), "dt": float(scalars["dt"]).hex(), "integrator_field": scalars["integrator"],
+        "integrator": "whfast (the field holds the value the WHFast archives of test_machine_independent.py hold)",
+        "gravity_ignore_terms": scalars["gravity_ignore_terms"],
+        "snapshots": [{"t": float(t).hex(), "particles": [hexrow(np.concatenate([row[:6], row[9:10]])) for row in p]} for t, p in snaps]}
     with open(os.path.join(OUT, "reference_archives.json"), "w") as f:
         json.dump(arch, f, indent=1)
 

@@ -121,3 +121,57 @@ def test_replay_with_the_operator_run_on_the_device(archives, name):
     assert np.abs(got - ref).max() <= 2e-9
     assert np.abs(ref[:, :6] - start[:, :6]).max() > 0.1
     sim.free_particle_params()
+
+
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_replay_of_the_integrate_force_archive_with_the_operator_run_on_the_device(archives, mode):
+    """test.sa / test.rebx (reboundx/test/test_simulationarchive.py:56-84): star + planet under WHFast from
+    t = 1000 to t = 2000 (15 916 steps of dt and a shortened last one) with the integrate_force operator over
+    gr, c = 100, ahead of every step; no `integrator` parameter in the file: the default scheme, Euler
+    (src/integrate_force.c:40-44).  The operator comes out of the reference's own parameter file through
+    rebx_init_extras_from_binary and runs on the device through sim->pre_timestep_modifications."""
+    entry = archives["integrate_force"]
+    start, ref = rows(entry["snapshots"][0]), rows(entry["snapshots"][1])
+    dt, t0, t1 = float.fromhex(entry["dt"]), float.fromhex(entry["snapshots"][0]["t"]), float.fromhex(entry["snapshots"][1]["t"])
+    sim = Simulation(integrator="whfast")
+    for p in start:
+        sim.add(m=p[6], x=p[0], y=p[1], z=p[2], vx=p[3], vy=p[4], vz=p[5])
+    sim.dt = dt
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rebx = Extras(sim, os.path.join(GOLDEN, "rebx", "test.rebx"))
+    rebx.set_mode(mode)
+    assert sim.pre_timestep_modifications and not sim.post_timestep_modifications and not sim.additional_forces
+    ps = sim.particles
+    n = 2
+    fields = ("x", "y", "z", "vx", "vy", "vz", "m")
+
+    def pre(ptr, _h, _user):
+        s = ptr.contents
+        cols = [np.ctypeslib.as_array(ctypes.cast(getattr(s, k), ctypes.POINTER(ctypes.c_double)), shape=(n,)) for k in fields]
+        for i in range(n):
+            for k, c in zip(fields, cols):
+                setattr(ps[i], k, float(c[i]))
+        sim.pre_timestep_modifications(ctypes.byref(sim))
+        for i in range(n):
+            for k, c in zip(fields, cols):
+                c[i] = getattr(ps[i], k)
+
+    cols = {k: start[:, j].copy() for j, k in enumerate(fields)}
+    for k in ("ax", "ay", "az"):
+        cols[k] = np.zeros(n)
+    state = oracle.Sim(cols)
+    t, whole = t0, 0
+    while t + dt < t1:
+        t = (t + dt / 2) + dt / 2
+        whole += 1
+    cb = oracle._STEP_FN(pre)
+    assert oracle.lib.orc_whfast_steps(ctypes.byref(state.s), dt, whole, oracle._FORCE_FN(0), cb, oracle._STEP_FN(0), None) == 0
+    sim.dt = t1 - t                                   # the operator acts for sim->dt * dt_fraction (src/core.c:882-896)
+    assert oracle.lib.orc_whfast_steps(ctypes.byref(state.s), t1 - t, 1, oracle._FORCE_FN(0), cb, oracle._STEP_FN(0), None) == 0
+    sim.process_messages()
+    got = np.array([state.cols[k] for k in fields]).T
+    assert whole == 15916
+    assert np.abs(got - ref).max() <= 3e-10
+    assert np.abs(ref[:, :6] - start[:, :6]).max() > 0.1
+    sim.free_particle_params()

@@ -566,6 +566,50 @@ def test_operator_archives_replay_to_roundoff(archives):
     assert abs(ref[0, 6] - 1.0) < 1e-12          # modify_orbits_direct leaves the masses alone
 
 
+# ------------------------------------------------------------- integrate_force pinned by the reference's test.sa / test.rebx
+
+def replay_integrate_force_archive(entry, scheme, operator=None):
+    """From the archive's first snapshot (t = 1000) to its second (t = 2000) as REBOUND ran it
+    (reboundx/test/test_simulationarchive.py:56-84: WHFast, exact_finish_time): whole steps of dt
+    while the next one does not pass the end, then one step of what is left; before every step the
+    operator stored in test.rebx -- integrate_force over gr with c = 100, dt_fraction 1 -- acts for
+    that step's dt (src/core.c:882-896).  operator(view, h): the operator; default: the checker's."""
+    dt, G = float.fromhex(entry["dt"]), float.fromhex(entry["G"])
+    t0, c0, _ = _archive_state(entry["snapshots"][0])
+    t1, _, ref = _archive_state(entry["snapshots"][1])
+    if operator is None:
+        operator = lambda v, h: oracle.integrate_force(v, scheme, 1.0 * h, [("gr", {"c": 1e2})], {})
+    sim = oracle.Sim(c0, G)
+    t, whole = t0, 0
+    while t + dt < t1:                       # (REBOUND adds dt/2 to the time twice per WHFast step)
+        t = (t + dt / 2) + dt / 2
+        whole += 1
+    oracle.whfast_steps(sim, dt, whole, None, None, pre=operator)
+    oracle.whfast_steps(sim, t1 - t, 1, None, None, pre=operator)
+    return np.array([sim.cols[k] for k in ("x", "y", "z", "vx", "vy", "vz")]).T, ref, whole
+
+
+def test_integrate_force_archive_pins_the_euler_scheme(archives):
+    """test.sa / test.rebx of the reference's own suite: star + planet under WHFast with the
+    integrate_force operator over gr ahead of every step and no `integrator` parameter, i.e. the
+    default scheme, Euler (src/integrate_force.c:40-44, src/integrator_euler.c:33-41).  Replayed
+    with the checker's restatements, the state lands on the archived one to roundoff; any other
+    scheme, another placement of the operator or no operator does not."""
+    entry = archives["integrate_force"]
+    assert entry["integrator_field"] == 1 and entry["gravity_ignore_terms"] == 1
+    got, ref, whole = replay_integrate_force_archive(entry, "euler")
+    assert whole == 15916
+    miss = np.abs(got - ref).max()
+    assert miss <= 3e-10, miss
+    for scheme in ("rk2", "rk4", "implicit_midpoint"):
+        other, _, _ = replay_integrate_force_archive(entry, scheme)
+        assert np.abs(other - ref).max() > 1e3 * max(miss, 1e-12), scheme
+    none, _, _ = replay_integrate_force_archive(entry, None, operator=lambda v, h: None)
+    assert np.abs(none - ref).max() > 0.1          # gr with c = 100 turns the orbit by > 0.1 rad per 1000 time units
+    half, _, _ = replay_integrate_force_archive(entry, None, operator=lambda v, h: oracle.integrate_force(v, "euler", 0.5 * h, [("gr", {"c": 1e2})], {}))
+    assert np.abs(half - ref).max() > 1e-3
+
+
 # ------------------------------------------------------------- conservation (test_conservation.py)
 
 CONSERVED = {
