@@ -250,6 +250,11 @@ void rebx_gravitational_harmonics(struct reb_simulation* const sim, struct rebx_
 void rebx_ephemeris_forces(struct reb_simulation* const sim, struct rebx_force* const force, struct reb_particle* const particles, const int N);
 
 /* src/reboundx.h:436,448, src/radiation_forces.c:119-124 */
+/* src/central_force.c:143-152 (declared src/reboundx.h:458): Acentral that makes the pericentre of p's orbit about
+ * `primary` turn at the rate pomegadot under a central force a = Acentral r^gamma:
+ * G m_primary pomegadot / (1 + gamma/2) / d^(gamma+2) / n, d = separation, n = mean motion of the osculating orbit.
+ * gamma = -2: reb_error and 0 (the precession vanishes there).  G is p.sim->G. */
+double rebx_central_force_Acentral(const struct reb_particle p, const struct reb_particle primary, const double pomegadot, const double gamma);
 double rebx_rad_calc_beta(const double G, const double c, const double source_mass, const double source_luminosity, const double radius, const double density, const double Q_pr);
 double rebx_rad_calc_particle_radius(const double G, const double c, const double source_mass, const double source_luminosity, const double beta, const double density, const double Q_pr);
 

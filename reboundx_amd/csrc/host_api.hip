@@ -690,6 +690,35 @@ extern "C" double rebx_rad_calc_particle_radius(const double G, const double c, 
     return 3. * source_luminosity * Q_pr / (16. * 3.14159265358979323846 * G * source_mass * c * density * beta);
 }
 
+// src/central_force.c:143-152: the normalisation A of a central force a = A r^gamma that turns the pericentre of
+// p's orbit about `primary` at the rate pomegadot.  The reference takes the separation d and the mean motion n from
+// REBOUND's reb_tools_particle_to_orbit (mu = G (m_p + m_primary), a = -mu / (v^2 - 2 mu / d), n = sign(a) sqrt(|mu / a^3|));
+// an orbit REBOUND calls undefined (primary without mass, zero separation) comes back as NaN there, and so it does here.
+extern "C" double rebx_central_force_Acentral(const struct reb_particle p, const struct reb_particle primary, const double pomegadot, const double gamma) {
+    struct reb_simulation* const sim = p.sim;
+    const double G = sim ? sim->G : 1.;
+    const double TINY = 1.E-308;
+    double d = NAN, n = NAN;
+    if (primary.m > TINY) {
+        const double mu = G * (p.m + primary.m);
+        const double dx = p.x - primary.x, dy = p.y - primary.y, dz = p.z - primary.z;
+        const double dvx = p.vx - primary.vx, dvy = p.vy - primary.vy, dvz = p.vz - primary.vz;
+        const double sep = sqrt(dx * dx + dy * dy + dz * dz);
+        if (sep > TINY) {
+            const double vsquared = dvx * dvx + dvy * dvy + dvz * dvz;
+            const double a = -mu / (vsquared - 2. * (mu / sep));
+            d = sep;
+            n = a / fabs(a) * sqrt(fabs(mu / (a * a * a)));
+        }
+    }
+    if (fabs(gamma + 2.) < DBL_EPSILON) {       // the precession vanishes for a force law r^-2: A would diverge
+        const char* const msg = "Precession vanishes for force law varying as r^-2, so can't initialize Acentral from a precession rate for gamma=-2)\n";
+        if (sim) reb_error(sim, msg); else fputs(msg, stderr);
+        return 0.;
+    }
+    return G * primary.m * pomegadot / (1. + gamma / 2.) / pow(d, gamma + 2.) / n;
+}
+
 // ------------------------------------------------------------------ extensions
 extern "C" void rebxamd_invalidate_params(struct rebx_extras* rebx) { touch(rebx); }
 static int dense_index(const char* name) {

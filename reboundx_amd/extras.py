@@ -343,6 +343,12 @@ class Extras(Structure):
         return lib.rebx_rad_calc_beta(c_double(G), c_double(c), c_double(source_mass), c_double(source_luminosity),
                                       c_double(radius), c_double(density), c_double(Q_pr))
 
+    def central_force_Acentral(self, p, primary, pomegadot, gamma):
+        """reboundx/extras.py:172-177."""
+        a = lib.rebx_central_force_Acentral(p, primary, c_double(pomegadot), c_double(gamma))
+        self.process_messages()
+        return a
+
     def rad_calc_particle_radius(self, G, c, source_mass, source_luminosity, beta, density, Q_pr):
         return lib.rebx_rad_calc_particle_radius(c_double(G), c_double(c), c_double(source_mass), c_double(source_luminosity),
                                                  c_double(beta), c_double(density), c_double(Q_pr))
@@ -498,6 +504,8 @@ lib.rebx_set_param_pointer.restype = None
 lib.rebx_len.argtypes = [c_void_p]
 lib.rebx_len.restype = c_int
 lib.rebx_rad_calc_beta.argtypes = [c_double] * 7
+lib.rebx_central_force_Acentral.argtypes = [Particle, Particle, c_double, c_double]
+lib.rebx_central_force_Acentral.restype = c_double
 lib.rebx_rad_calc_beta.restype = c_double
 lib.rebx_rad_calc_particle_radius.argtypes = [c_double] * 7
 lib.rebx_rad_calc_particle_radius.restype = c_double
@@ -553,7 +561,7 @@ PLUGIN_API_SYMBOLS = (
     "rebx_set_param_int", "rebx_set_param_uint32", "rebx_register_param", "rebx_get_type", "rebx_len", "rebx_error",
     "rebx_additional_forces", "rebx_reset_accelerations", "rebx_gr", "rebx_gr_full", "rebx_gr_potential",
     "rebx_radiation_forces", "rebx_modify_orbits_forces", "rebx_tides_precession", "rebx_central_force",
-    "rebx_gravitational_harmonics", "rebx_ephemeris_forces", "rebx_rad_calc_beta", "rebx_rad_calc_particle_radius",
+    "rebx_gravitational_harmonics", "rebx_ephemeris_forces", "rebx_rad_calc_beta", "rebx_rad_calc_particle_radius", "rebx_central_force_Acentral",
     "rebxamd_invalidate_params", "rebxamd_set_mode", "rebxamd_last_timings", "rebxamd_set_param_column", "rebxamd_get_param_column",
     "rebx_build_str", "rebx_version_str", "rebx_githash_str",
 )

@@ -367,3 +367,36 @@ def test_host_code_is_clean_under_address_sanitizer():
         pytest.skip("no hipcc")
     r = subprocess.run(["bash", os.path.join(ROOT, "scripts", "asan_check.sh")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "host lifecycle ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_central_force_acentral_from_a_precession_rate():
+    """rebx_central_force_Acentral (src/central_force.c:143-152): G M pomegadot / (1 + gamma/2) / d^(gamma+2) / n with the
+    separation and the mean motion of the osculating orbit; gamma = -2 is an error (the precession vanishes) and gives 0.
+    The value it returns makes the force do what it says: checked in tests/test_gpu_notebooks.py-style runs is not
+    needed here -- the expression is closed-form."""
+    import math
+    G, M, m, a, e = 2.5, 1.3, 2e-3, 1.7, 0.3
+    sim = Simulation(G=G)
+    mu = G * (M + m)
+    d = a * (1 - e)                                   # planet at pericentre
+    v = math.sqrt(mu * (1 + e) / (a * (1 - e)))
+    sim.add(m=M, x=0.1, y=-0.2, z=0.05, vx=0.01, vy=0.02, vz=-0.03)
+    sim.add(m=m, x=0.1 + d, y=-0.2, z=0.05, vx=0.01, vy=0.02 + v, vz=-0.03)
+    rebx = Extras(sim)
+    ps = sim.particles
+    n = math.sqrt(mu / a ** 3)
+    for gamma, rate in ((-1., 1e-3), (-3., -2e-4), (0.5, 7e-6)):
+        got = rebx.central_force_Acentral(ps[1], ps[0], rate, gamma)
+        want = G * M * rate / (1. + gamma / 2.) / d ** (gamma + 2.) / n
+        assert got == pytest.approx(want, rel=1e-13)
+    with pytest.raises(RuntimeError, match="Precession vanishes"):
+        rebx.central_force_Acentral(ps[1], ps[0], 1e-3, -2.)
+    assert lib.rebx_central_force_Acentral(ps[1], ps[0], 1e-3, -2.) == 0.
+    with pytest.raises(RuntimeError):
+        sim.process_messages()
+    # an unbound orbit has a negative mean motion in REBOUND's convention (n = a/|a| sqrt(|mu/a^3|)): the sign carries over
+    ps[1].vy = 0.02 + 3. * v
+    assert rebx.central_force_Acentral(ps[1], ps[0], 1e-3, -1.) < 0.
+    # a primary without mass: REBOUND's orbit is undefined (NaN), and so is the result
+    ps[0].m = 0.
+    assert math.isnan(rebx.central_force_Acentral(ps[1], ps[0], 1e-3, -1.))
