@@ -347,16 +347,19 @@ typedef struct rebxamd_op {
 } rebxamd_op;
 
 #define REBXAMD_MAX_OPS 32
-#define REBXAMD_UNSET_BITS 0x7FF8000000000000ull
+#define REBXAMD_UNSET_BITS 0x7FF8000000000000ull        /* what C's NAN and numpy.nan hold: the usual way to write "not set" */
+#define REBXAMD_NAN_VALUE_BITS 0x7FF8000000000001ull    /* the one NaN that stands for a parameter whose VALUE is NaN */
 #define REBXAMD_MAX_HEAD 64
 
 /* A set of particles resident in device memory, as fp64 columns of length n.
  *
- * Per-particle parameter columns mark "not set on this particle" with the quiet NaN whose payload
- * is empty (REBXAMD_UNSET_BITS: the bits C's NAN macro, numpy.nan and std::nan("") hold); a NULL
- * column means not set on any particle.  A NaN with any other bit pattern is a value and runs
- * through the arithmetic, as a NaN-valued parameter does in the reference (which finds the
- * parameter in the list and computes with it, e.g. src/modify_orbits_forces.c:78-108).
+ * Per-particle parameter columns mark "not set on this particle" with a NaN: any NaN, whatever its
+ * sign and payload (NAN, numpy.nan, -nan, the 0/0 of host arithmetic, a NaN a computed column
+ * inherited), except the single pattern REBXAMD_NAN_VALUE_BITS; a NULL column means not set on any
+ * particle.  REBXAMD_NAN_VALUE_BITS is a parameter that IS set and whose value is NaN: it runs through
+ * the arithmetic, as a NaN-valued parameter does in the reference (which finds the parameter in the
+ * list and computes with it, e.g. src/modify_orbits_forces.c:78-108).  The plugin layer uploads
+ * such parameters with that pattern.
  *
  * n_head / tail_massless describe the mass layout: if tail_massless != 0 the
  * caller asserts that every particle with index >= n_head has m == 0 exactly
@@ -408,8 +411,10 @@ int rebxamd_apply(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* 
  * source) x ceil(n / 512) x 24 bytes must fit in the array less 80 KiB (3 such ops: n <= 2.9e7).
  * warnings_dev: device word in which kernels raise the rebxamd_fetch_warnings bits (the caller
  * clears it), or NULL (bits are dropped).  errbuf (may be NULL) receives a message on failure.
- * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two
- * host threads) race. */
+ * Every call on a GPU shares that GPU's array and one host-side record per GPU (warning word, table
+ * index, error text).  The host side of a call is serialised per GPU by a lock inside the library, so
+ * host threads may call concurrently; the work they queue is not ordered by it: calls whose kernels
+ * overlap on one GPU (two streams) race on the array, and the caller has to order them. */
 int rebxamd_apply_static(const rebxamd_view* view, const rebxamd_op* ops, int nops, int mode, uint32_t* warnings_dev, void* stream,
                          char* errbuf, int errbuf_len);
 
@@ -510,7 +515,10 @@ int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_o
  *                          massive bodies their next step, have already run).
  *   rebxamd_wh_run_end     the closing half drift: the columns hold the synchronised state, bit for bit what
  *                          rebxamd_wh_steps(view, ops, dt, <steps taken>) would have left.  Closes the run.
- * All three are asynchronous on `stream` (the same stream for the whole run). */
+ * All three are asynchronous on `stream`, which must be the same for the whole run (REBXAMD_ERR_ARG otherwise).  While a
+ * run is open the context's tables and records belong to it: rebxamd_apply, rebxamd_apply_targets, rebxamd_add_pushes,
+ * rebxamd_integrate_force, rebxamd_wh_drift, rebxamd_wh_steps, rebxamd_wh_batch, rebxamd_modify_orbits_direct and
+ * rebxamd_potentials on the same context return REBXAMD_ERR_ARG (use a second context, or close the run). */
 int rebxamd_wh_run_begin(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, double dt, int mode, void* stream);
 int rebxamd_wh_run_steps(rebxamd_ctx* ctx, int64_t nsteps, void* stream);
 int rebxamd_wh_run_end(rebxamd_ctx* ctx, void* stream);

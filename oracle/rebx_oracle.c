@@ -41,14 +41,14 @@ static void scatter_acc(const orc_sim* s, body* p) {
     free(p);
 }
 
-/* A column entry stands for "rebx_get_param returned NULL" when it holds the quiet NaN with an empty
- * payload (what NAN and numpy.nan are); a NaN of any other bit pattern is a parameter that IS in the
- * list and whose value is NaN: the reference computes with it (src/core.c:614-622 returns the pointer). */
+/* A column entry stands for "rebx_get_param returned NULL" when it holds a NaN -- any NaN, whatever its sign
+ * or payload -- except the one pattern 0x7FF8000000000001, which stands for a parameter that IS in the list
+ * and whose value is NaN: the reference computes with it (src/core.c:614-622 returns the pointer). */
 static inline int has(const double* col, int i) {
     if (col == NULL) return 0;
     uint64_t u;
     memcpy(&u, &col[i], sizeof u);
-    return u != 0x7FF8000000000000ull;
+    return col[i] == col[i] || u == 0x7FF8000000000001ull;
 }
 static inline int flagged(const uint8_t* col, int i) { return col != NULL && col[i] != 0; }
 

@@ -37,7 +37,7 @@ struct rebxamd_ctx {
     double* star_batch = nullptr;
     int wh_batch = 32;                  // steps per pass (1: one pass per step)
     // a Wisdom-Holman run left unsynchronised between calls (rebxamd_wh_run_begin .. rebxamd_wh_run_end)
-    struct WhRun { bool open = false; int64_t k = 0; double dt = 0.; int mode = 0; long long K = 1; rebxamd_view view; std::vector<rebxamd_op> ops; } run;
+    struct WhRun { bool open = false; void* stream = nullptr; int64_t k = 0; double dt = 0.; int mode = 0; long long K = 1; rebxamd_view view; std::vector<rebxamd_op> ops; } run;
     double* integ = nullptr;            // stage columns of the force integrators
     size_t integ_cap = 0;
     double* shard = nullptr;            // per-range forces and reactions of the sharded Jacobi/barycentric modify_orbits_forces
@@ -88,6 +88,13 @@ static int fail(rebxamd_ctx* ctx, int code, const char* what, hipError_t e = hip
     do {                                                                     \
         hipError_t _e = (call);                                              \
         if (_e != hipSuccess) return fail(ctx, REBXAMD_ERR_HIP, #call, _e);  \
+    } while (0)
+
+// While a Wisdom-Holman run is open on a context (rebxamd_wh_run_begin .. rebxamd_wh_run_end) its tables, records of body 0 /
+// of the head and table index belong to that run: the entry points that would overwrite them refuse.
+#define REFUSE_DURING_RUN(name)                                                                                              \
+    do {                                                                                                                     \
+        if (ctx->run.open) return fail(ctx, REBXAMD_ERR_ARG, name ": a Wisdom-Holman run is open on this context (rebxamd_wh_run_end closes it)"); \
     } while (0)
 
 // A small result (at most 512 bytes) from device memory to `dst`, waiting for the stream: through
@@ -498,6 +505,7 @@ static int apply_ops(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_o
 
 extern "C" int rebxamd_apply(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, int mode, void* stream) {
     if (!ctx) return REBXAMD_ERR_ARG;
+    REFUSE_DURING_RUN("rebxamd_apply");
     if (!view || nops < 0 || (nops > 0 && !ops) || view->n < 0 || view->n_head < 0) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_apply: bad argument");
     if (mode != REBXAMD_MODE_FAST && mode != REBXAMD_MODE_EXACT) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_apply: bad mode");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -522,9 +530,12 @@ static constexpr size_t SS_PARTIALS = SS_CHUNKS + round256(sizeof(double) * REBX
 static_assert(SS_PARTIALS + (1u << 20) <= STATIC_SCRATCH_BYTES, "the fixed scratch array is too small for its tables");
 
 static constexpr int STATIC_MAX_DEVICES = 64;
-struct StaticSlot { bool ready = false; rebxamd_ctx ctx; };
+// One slot per GPU: its own lock, held for the whole host side of a call (set-up, argument checks, launches -- the
+// launches are asynchronous, so that is microseconds).  The per-device context below is host state that a call changes
+// (warning word, table index, error text); two host threads on one GPU take turns on it.  What the lock cannot order is
+// the work on the GPU: calls queued on different streams of one GPU still share the device array.
+struct StaticSlot { std::mutex lock; bool ready = false; rebxamd_ctx ctx; };
 static StaticSlot g_static[STATIC_MAX_DEVICES];
-static std::mutex g_static_mutex;
 
 static void copy_msg(char* dst, int len, const char* msg) {
     if (!dst || len <= 0) return;
@@ -545,8 +556,8 @@ extern "C" int rebxamd_apply_static(const rebxamd_view* view, const rebxamd_op* 
         return REBXAMD_ERR_HIP;
     }
     StaticSlot& slot = g_static[dev];
+    std::lock_guard<std::mutex> lock(slot.lock);
     {
-        std::lock_guard<std::mutex> lock(g_static_mutex);
         if (!slot.ready) {
             // set-up, once per device, with that device current
             unsigned char* ptr = nullptr;
@@ -600,6 +611,7 @@ extern "C" int rebxamd_apply_static(const rebxamd_view* view, const rebxamd_op* 
 extern "C" int rebxamd_apply_targets(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, int mode,
                                      int64_t target_lo, double* sums, void* stream) {
     if (!ctx) return REBXAMD_ERR_ARG;
+    REFUSE_DURING_RUN("rebxamd_apply_targets");
     if (!view || nops <= 0 || nops > REBXAMD_MAX_OPS || !ops || !sums || view->n < 0 || target_lo < 0)
         return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_apply_targets: bad argument");
     for (int k = 0; k < nops; k++)
@@ -610,6 +622,7 @@ extern "C" int rebxamd_apply_targets(rebxamd_ctx* ctx, const rebxamd_view* view,
 
 extern "C" int rebxamd_add_pushes(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, const double* sums, void* stream) {
     if (!ctx) return REBXAMD_ERR_ARG;
+    REFUSE_DURING_RUN("rebxamd_add_pushes");
     if (!view || nops <= 0 || nops > REBXAMD_MAX_OPS || !ops || !sums) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_add_pushes: bad argument");
     HIP_TRY(hipSetDevice(ctx->device));
     return run_streaming(ctx, view, ops, 0, nops, REBXAMD_MODE_FAST, (hipStream_t)stream, 0, const_cast<double*>(sums), true);
@@ -663,6 +676,7 @@ extern "C" int rebxamd_drift(rebxamd_ctx* ctx, const rebxamd_view* view, double 
 
 extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, int integrator,
                                        double dt, int mode, int* iterations, void* stream) {
+    if (ctx) REFUSE_DURING_RUN("rebxamd_integrate_force");
     if (iterations) *iterations = 0;
     int rc = check_step_view(ctx, view, "rebxamd_integrate_force: bad argument", true, true);
     if (rc != REBXAMD_OK) return rc;
@@ -868,6 +882,7 @@ extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* vie
 // ------------------------------------------------------------------ Wisdom-Holman steps, one dominant mass + massless bodies
 
 extern "C" int rebxamd_wh_drift(rebxamd_ctx* ctx, const rebxamd_view* view, double dt, int mode, void* stream) {
+    if (ctx) REFUSE_DURING_RUN("rebxamd_wh_drift");
     const int rc = check_step_view(ctx, view, "rebxamd_wh_drift: bad argument", true, false);
     if (rc != REBXAMD_OK || view->n == 0) return rc;
     if (!view->m) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_drift: mass column missing");
@@ -892,6 +907,7 @@ static int ensure_wh_batch(rebxamd_ctx* ctx) {
 
 extern "C" int rebxamd_wh_batch(rebxamd_ctx* ctx, int steps_per_pass) {
     if (!ctx) return REBXAMD_ERR_ARG;
+    REFUSE_DURING_RUN("rebxamd_wh_batch");
     if (steps_per_pass < 1 || steps_per_pass > kMaxWhBatch) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_batch: between 1 and 64 steps per pass");
     ctx->wh_batch = steps_per_pass;
     return REBXAMD_OK;
@@ -899,6 +915,7 @@ extern "C" int rebxamd_wh_batch(rebxamd_ctx* ctx, int steps_per_pass) {
 
 extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, double dt, int64_t nsteps,
                                 int mode, void* stream) {
+    if (ctx) REFUSE_DURING_RUN("rebxamd_wh_steps");
     int rc = check_step_view(ctx, view, "rebxamd_wh_steps: bad argument", true, true);
     if (rc != REBXAMD_OK) return rc;
     if (nsteps < 0 || nops < 0 || (nops > 0 && !ops)) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_steps: bad argument");
@@ -1083,7 +1100,6 @@ extern "C" int rebxamd_wh_steps(rebxamd_ctx* ctx, const rebxamd_view* view, cons
 // runs one leading drift ahead of the others while the run is open; its records keep what the end of the run needs.
 
 extern "C" int rebxamd_wh_run_begin(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, double dt, int mode, void* stream) {
-    (void)stream;
     int rc = check_step_view(ctx, view, "rebxamd_wh_run_begin: bad argument", true, true);
     if (rc != REBXAMD_OK) return rc;
     if (ctx->run.open) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_run_begin: a run is already open on this context (close it with rebxamd_wh_run_end)");
@@ -1101,7 +1117,7 @@ extern "C" int rebxamd_wh_run_begin(rebxamd_ctx* ctx, const rebxamd_view* view, 
         }
         if (!fits)
             return fail(ctx, REBXAMD_ERR_UNSUPPORTED, "rebxamd_wh_run_begin behind several massive bodies handles a head of at most 64 of them followed by massless ones (tail_massless = 1, acceleration columns present) under a stack that is one streaming run of forces whose sources are head bodies; use rebxamd_wh_steps otherwise");
-        ctx->run.open = true; ctx->run.k = 0; ctx->run.dt = dt; ctx->run.mode = mode; ctx->run.K = Kh;
+        ctx->run.open = true; ctx->run.stream = stream; ctx->run.k = 0; ctx->run.dt = dt; ctx->run.mode = mode; ctx->run.K = Kh;
         ctx->run.view = *view;
         ctx->run.ops.assign(ops, ops + nops);
         return REBXAMD_OK;
@@ -1114,7 +1130,7 @@ extern "C" int rebxamd_wh_run_begin(rebxamd_ctx* ctx, const rebxamd_view* view, 
     }
     if (!ok)
         return fail(ctx, REBXAMD_ERR_UNSUPPORTED, "rebxamd_wh_run_begin handles one massive body followed by massless ones (n_head = 1, tail_massless = 1) under a non-empty stack that is one streaming run of forces whose source is body 0 (no gr_full, no barycentric modify_orbits_forces); use rebxamd_wh_steps otherwise");
-    ctx->run.open = true; ctx->run.k = 0; ctx->run.dt = dt; ctx->run.mode = mode; ctx->run.K = 1;
+    ctx->run.open = true; ctx->run.stream = stream; ctx->run.k = 0; ctx->run.dt = dt; ctx->run.mode = mode; ctx->run.K = 1;
     ctx->run.view = *view;
     ctx->run.ops.assign(ops, ops + nops);
     return REBXAMD_OK;
@@ -1129,6 +1145,7 @@ static double* run_pre(rebxamd_ctx* ctx, int64_t k) { return ctx->whead + 8 * RE
 extern "C" int rebxamd_wh_run_steps(rebxamd_ctx* ctx, int64_t nsteps, void* stream) {
     if (!ctx) return REBXAMD_ERR_ARG;
     if (!ctx->run.open) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_run_steps: no open run");
+    if (stream != ctx->run.stream) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_run_steps: a run stays on the stream it was opened on");
     if (nsteps < 0) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_run_steps: bad argument");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
@@ -1177,6 +1194,7 @@ extern "C" int rebxamd_wh_run_steps(rebxamd_ctx* ctx, int64_t nsteps, void* stre
 extern "C" int rebxamd_wh_run_end(rebxamd_ctx* ctx, void* stream) {
     if (!ctx) return REBXAMD_ERR_ARG;
     if (!ctx->run.open) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_run_end: no open run");
+    if (stream != ctx->run.stream) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_wh_run_end: a run stays on the stream it was opened on");
     ctx->run.open = false;
     if (ctx->run.k == 0) return REBXAMD_OK;            // nothing was launched: the columns are as they were
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1360,6 +1378,7 @@ extern "C" int rebxamd_direct_chain(rebxamd_ctx* ctx, int max_rounds, int* last_
 
 extern "C" int rebxamd_modify_orbits_direct(rebxamd_ctx* ctx, const rebxamd_view* view, int coordinates, int primary, const double* p_param,
                                             const double* tau_omega, const double* tau_Omega, double dt, void* stream) {
+    if (ctx) REFUSE_DURING_RUN("rebxamd_modify_orbits_direct");
     const int rc = check_step_view(ctx, view, "rebxamd_modify_orbits_direct: bad argument", true, false);
     if (rc != REBXAMD_OK || view->n == 0) return rc;
     if (!view->m) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_modify_orbits_direct: mass column missing");
@@ -1398,6 +1417,7 @@ extern "C" int rebxamd_modify_orbits_direct(rebxamd_ctx* ctx, const rebxamd_view
 
 extern "C" int rebxamd_potentials(rebxamd_ctx* ctx, const rebxamd_view* view, const rebxamd_op* ops, int nops, double* out, void* stream) {
     if (!ctx) return REBXAMD_ERR_ARG;
+    REFUSE_DURING_RUN("rebxamd_potentials");
     if (!view || view->n < 0 || nops < 0 || nops > REBXAMD_MAX_OPS || (nops > 0 && (!ops || !out)))
         return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_potentials: bad argument");
     for (int k = 0; k < nops; k++) out[k] = 0.;

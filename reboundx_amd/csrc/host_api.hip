@@ -93,9 +93,9 @@ struct ValueRef { int i, k; const double* p; };        // particle, dense column
 struct SourceJ { int idx; const double *J, *Req; };
 struct SourceC { int idx; const double *A, *gamma; };
 
-// what a NaN-valued parameter is uploaded as: a NaN that is not the "not set" marker, so that it
-// propagates through the kernels as it does through the reference's arithmetic
-constexpr unsigned long long kNaNValueBits = 0x7FF8000000000001ull;
+// what a NaN-valued parameter is uploaded as: the one NaN the kernels do not read as "not set", so that it
+// propagates through them as it does through the reference's arithmetic
+constexpr unsigned long long kNaNValueBits = REBXAMD_NAN_VALUE_BITS;
 inline unsigned long long bits_of(double v) { return __builtin_bit_cast(unsigned long long, v); }
 inline double as_column_value(double v) { return v == v ? v : __builtin_bit_cast(double, kNaNValueBits); }
 

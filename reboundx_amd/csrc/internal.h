@@ -6,12 +6,12 @@
 
 namespace rebxamd {
 
-// "Not set on this particle" in a per-particle parameter column: the quiet NaN with an empty payload
-// (REBXAMD_UNSET_BITS: what C's NAN, numpy.nan and std::nan("") hold) and no other value.  A NaN with
-// any other bit pattern is a value: it runs through the arithmetic and poisons what it touches, as a
-// NaN-valued parameter does in the reference.
+// "Not set on this particle" in a per-particle parameter column: any NaN -- the quiet NaN of C's NAN and
+// numpy.nan, its negative, the 0/0 of host arithmetic, whatever a computed column carries -- except the one
+// pattern REBXAMD_NAN_VALUE_BITS, which stands for a parameter that is set and whose value is NaN: that one
+// runs through the arithmetic and poisons what it touches, as a NaN-valued parameter does in the reference.
 __host__ __device__ __forceinline__ bool is_set(double v) {
-    return __builtin_bit_cast(unsigned long long, v) != REBXAMD_UNSET_BITS;
+    return v == v || __builtin_bit_cast(unsigned long long, v) == REBXAMD_NAN_VALUE_BITS;
 }
 __host__ __device__ __forceinline__ double unset_value() { return __builtin_bit_cast(double, (unsigned long long)REBXAMD_UNSET_BITS); }
 

@@ -173,7 +173,7 @@ __device__ __forceinline__ void head_body(const View& v, const Program& prog, He
         acc.x = v.ax[t]; acc.y = v.ay[t]; acc.z = v.az[t];
         load_src(v, t, sh.hp[t]);
     }
-    __syncthreads();
+    wave_sync();
     // tables for the tail pass: every op's source (all inside the head) and the massive head bodies
     if (t < prog.nops) {
         int s = prog.ops[t].src;
@@ -204,7 +204,7 @@ __device__ __forceinline__ void head_body(const View& v, const Program& prog, He
                 }
                 sh.na[t][0] = nx; sh.na[t][1] = ny; sh.na[t][2] = nz;
             }
-            __syncthreads();
+            wave_sync();
             // --- inertial -> Jacobi (sequential prefix recurrence), lane 0
             if (t == 0) {
 #pragma clang fp contract(off)
@@ -231,7 +231,7 @@ __device__ __forceinline__ void head_body(const View& v, const Program& prog, He
                 hc->gr_mu = G * sh.hp[0].m;
                 sh.com[0].m = eta;      // total mass, start of the reverse recurrence
             }
-            __syncthreads();
+            wave_sync();
             // --- post-Newtonian term per Jacobi body
             if (valid && t >= 1) {
                 Jac j;
@@ -245,7 +245,7 @@ __device__ __forceinline__ void head_body(const View& v, const Program& prog, He
                 if (q == 10) atomicOr(status, WARN_GR_ITER);
                 sh.pj[t][6] = corr.x; sh.pj[t][7] = corr.y; sh.pj[t][8] = corr.z;
             }
-            __syncthreads();
+            wave_sync();
             // --- Jacobi -> inertial accelerations (sequential reverse recurrence), lane 0
             if (t == 0) {
 #pragma clang fp contract(off)
@@ -266,9 +266,9 @@ __device__ __forceinline__ void head_body(const View& v, const Program& prog, He
                 const double mi0 = 1. / eta;
                 sh.na[0][0] = s0 * mi0; sh.na[0][1] = s1 * mi0; sh.na[0][2] = s2 * mi0;
             }
-            __syncthreads();
+            wave_sync();
             if (valid) { acc.x += sh.na[t][0]; acc.y += sh.na[t][1]; acc.z += sh.na[t][2]; }
-            __syncthreads();
+            wave_sync();
         } else if (op.kind == REBXAMD_OP_MOF && op.iarg != REBX_COORDINATES_PARTICLE) {
             const bool jacobi = (op.iarg == REBX_COORDINATES_JACOBI);
             // --- centres of mass: com[K] = all head bodies; Jacobi: com[i] = bodies 0..i-1
@@ -283,7 +283,7 @@ __device__ __forceinline__ void head_body(const View& v, const Program& prog, He
                 }
                 hc->nbary = jacobi ? 0 : K;
             }
-            __syncthreads();
+            wave_sync();
             // --- each body's own force and its mass-weighted reaction
             const bool acts = valid && (jacobi ? t >= 1 : true);
             V3 a = {0., 0., 0.};
@@ -303,7 +303,7 @@ __device__ __forceinline__ void head_body(const View& v, const Program& prog, He
                     hc->bary[K - 1 - t][2] = sh.br[t][2];
                 }
             }
-            __syncthreads();
+            wave_sync();
             // --- reference order: i descending; body j gains its own force at i==j and loses
             //     w_i a_i for every i >= j (Jacobi, i>=1) or for every i (barycentric)
             if (valid) {
@@ -314,7 +314,7 @@ __device__ __forceinline__ void head_body(const View& v, const Program& prog, He
                     acc.x -= sh.br[i][0]; acc.y -= sh.br[i][1]; acc.z -= sh.br[i][2];
                 }
             }
-            __syncthreads();
+            wave_sync();
         } else {
             // --- forces with one source / reference particle
             const int src = op.src;
@@ -335,7 +335,7 @@ __device__ __forceinline__ void head_body(const View& v, const Program& prog, He
             }
             sh.br[t][0] = br.x; sh.br[t][1] = br.y; sh.br[t][2] = br.z;
             sh.brf[t] = acted ? 1 : 0;
-            __syncthreads();
+            wave_sync();
             if (valid && t == src && op.kind != REBXAMD_OP_RADIATION) {
 #pragma clang fp contract(off)
                 if (op.kind == REBXAMD_OP_MOF) {        // the reference walks this loop backwards
@@ -346,7 +346,7 @@ __device__ __forceinline__ void head_body(const View& v, const Program& prog, He
                         if (sh.brf[i]) { acc.x += sh.br[i][0]; acc.y += sh.br[i][1]; acc.z += sh.br[i][2]; }
                 }
             }
-            __syncthreads();
+            wave_sync();
         }
     }
     if (star != nullptr) {
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(BLOCK, stream_min_blocks(EXACT, BACKREACT, COLS, SI
                     head_body<EXACT>(v, prog, step.next_hc + j, status, nullptr, 0., hsh, tid);
                     wh_head_step_body<EXACT>(v, step.wh_head, prog.G, step.dtk, j + 1 < step.next_nsub ? step.h_sub : step.next_h, step.jac,
                                              step.next_star + 16 * j, wsh, tid);
-                    __syncthreads();
+                    wave_sync();
                 }
             } else {
                 Src S;
@@ -770,7 +770,8 @@ __global__ __launch_bounds__(BLOCK, stream_min_blocks(EXACT, BACKREACT, COLS, SI
             if (step.wh_head > 1) {
                 // star + planets: the general head pass (additional forces on the head bodies, tables), then the head's own
                 // step -- gravity among its bodies, Jacobi kick, drift to the force evaluation after the next -- by the same
-                // wavefront; the other wavefronts of the workgroup leave first, so its barriers count one wavefront
+                // wavefront; the other wavefronts of the workgroup leave first (the head code synchronises with wave_sync(), which
+                // holds no workgroup barrier)
                 __shared__ HeadShared hsh;
                 __shared__ WhHeadShared wsh;
                 if (tid >= 64) return;
@@ -1233,12 +1234,12 @@ __global__ __launch_bounds__(64) void wh_head_batch_kernel(View v, Program prog,
     const int t = threadIdx.x;
     if (lead != nullptr) {
         wh_head_begin_body<EXACT>(v, K, prog.G, h_lead, jac, lead, wsh, t);
-        __syncthreads();
+        wave_sync();
     }
     for (int j = 0; j < nsub; j++) {
         head_body<EXACT>(v, prog, hc + j, status, nullptr, 0., hsh, t);
         wh_head_step_body<EXACT>(v, K, prog.G, dtk, j + 1 < nsub ? h : h_last, jac, star + 16 * j, wsh, t, pre);
-        __syncthreads();
+        wave_sync();
     }
 }
 

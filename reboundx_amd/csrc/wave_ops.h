@@ -51,6 +51,16 @@ __device__ __forceinline__ double wave_incl_scan_rev(double v, int lane) {
 // of memory round trips; use this one when the barrier protects LDS contents alone.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Barrier of code that runs as ONE wavefront (the head passes: 64 lanes, lane = head body).  It orders the wavefront's
+// LDS and global traffic exactly as __syncthreads() does -- a workgroup-scope fence, so every lane's writes have landed
+// before any lane reads them -- but leaves out the workgroup barrier instruction.  One wavefront needs none (its lanes
+// run in lockstep), and the head code also runs in the extra workgroup of a stepping pass after the other wavefronts of
+// that workgroup have returned, where a workgroup barrier that not every thread reaches would be undefined behaviour.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Sum over the wavefront (the same value in every lane).
 __device__ __forceinline__ double wave_total(double v, int lane) { return lane_value(wave_incl_scan(v, lane), 63); }
 

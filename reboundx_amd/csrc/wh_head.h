@@ -2,6 +2,7 @@
 // as device functions for one wavefront: shared by the kernels of step_kernels.hip and by the pass over
 // the massless bodies, whose extra workgroup runs the head's next step (stream_kernels.hip).
 #pragma once
+#include "wave_ops.h"
 #include "internal.h"
 #include "kepler.h"
 
@@ -98,17 +99,17 @@ __device__ __forceinline__ void wh_head_begin_body(const View& v, int K, double 
         sh.q[t][0] = v.x[t]; sh.q[t][1] = v.y[t]; sh.q[t][2] = v.z[t]; sh.q[t][3] = v.vx[t]; sh.q[t][4] = v.vy[t]; sh.q[t][5] = v.vz[t];
         sh.m[t] = v.m[t];
     }
-    __syncthreads();
+    wave_sync();
     if (t == 0) {
         wh_head_to_jacobi(sh, K);
         const double none[3] = {0., 0., 0.};
         wh_head_record(sh, K, G, h0, none, lead);
     }
-    __syncthreads();
+    wave_sync();
     wh_head_drift<EXACT>(sh, K, G, h0, t);
-    __syncthreads();
+    wave_sync();
     if (t == 0) wh_head_to_inertial(sh, K);
-    __syncthreads();
+    wave_sync();
     wh_head_store(v, sh, K, t, jac);
 }
 
@@ -126,7 +127,7 @@ __device__ __forceinline__ void wh_head_step_body(const View& v, int K, double G
         sh.eta[t] = jac[6 * REBXAMD_MAX_HEAD + t];
         for (int c = 0; c < 6; c++) sh.j[t][c] = jac[6 * t + c];
     }
-    __syncthreads();
+    wave_sync();
     if (t < K) {
 #pragma clang fp contract(off)
         // direct gravity among the head bodies, partners ascending, without the pair (0,1); on top of it what the head
@@ -141,7 +142,7 @@ __device__ __forceinline__ void wh_head_step_body(const View& v, int K, double G
         }
         sh.a[t][0] = ax + v.ax[t]; sh.a[t][1] = ay + v.ay[t]; sh.a[t][2] = az + v.az[t];
     }
-    __syncthreads();
+    wave_sync();
     if (t == 0) {
 #pragma clang fp contract(off)
         // inertial -> Jacobi accelerations; slot 0: acceleration of the centre of mass (what the massless bodies subtract)
@@ -158,7 +159,7 @@ __device__ __forceinline__ void wh_head_step_body(const View& v, int K, double G
         const double acom[3] = {s[0] * Mi, s[1] * Mi, s[2] * Mi};
         wh_head_record(sh, K, G, h, acom, rec);
     }
-    __syncthreads();
+    wave_sync();
     if (t >= 1 && t < K) {
 #pragma clang fp contract(off)
         double* j = sh.j[t];
@@ -169,15 +170,15 @@ __device__ __forceinline__ void wh_head_step_body(const View& v, int K, double G
             j[3] += pre3 * j[0]; j[4] += pre3 * j[1]; j[5] += pre3 * j[2];
         }
     }
-    __syncthreads();
+    wave_sync();
     if (pre != nullptr && t < K) {
         for (int c = 0; c < 6; c++) pre[6 * t + c] = sh.j[t][c];
         pre[6 * REBXAMD_MAX_HEAD + t] = sh.eta[t];
     }
     wh_head_drift<EXACT>(sh, K, G, h, t);
-    __syncthreads();
+    wave_sync();
     if (t == 0) wh_head_to_inertial(sh, K);
-    __syncthreads();
+    wave_sync();
     wh_head_store(v, sh, K, t, jac);
 }
 
@@ -198,11 +199,11 @@ __device__ __forceinline__ void wh_head_close_body(const View& v, int K, double 
         for (int c = 0; c < 3; c++) { rec_close[6 + c] = rec_last[c] + h * rec_last[3 + c]; rec_close[9 + c] = rec_last[9 + c]; }
         rec_close[12] = rec_last[12];
     }
-    __syncthreads();
+    wave_sync();
     wh_head_drift<EXACT>(sh, K, G, h, t);
-    __syncthreads();
+    wave_sync();
     if (t == 0) wh_head_to_inertial(sh, K);
-    __syncthreads();
+    wave_sync();
     wh_head_store(v, sh, K, t, jac);
 }
 

@@ -501,6 +501,39 @@ def test_particles_without_beta_are_untouched(ctx):
         assert np.array_equal(got[k, 0:1], cols[name][0:1])        # the source itself
 
 
+@pytest.mark.parametrize("mode", [EXACT, FAST])
+def test_nans_that_host_arithmetic_produces_mean_not_set(ctx, mode):
+    """Parameter columns computed on the host carry NaNs of other bit patterns than numpy.nan: the negated
+    marker (-tau with unset entries), 0/0 and inf - inf (sign bit set on x86), NaNs with a payload.  All of
+    them mean "not set"; only the one pattern reserved for a NaN-valued parameter is a value."""
+    n = 3000
+    cols, pp, _ = synthetic.disk(n, 2, dust_mass=1e-12)
+    pp["primary"] = np.zeros(n, dtype=np.uint8); pp["primary"][0] = 1
+    rng = np.random.default_rng(4)
+    for key in ("beta", "tau_a", "tau_e", "tau_inc", "R_tides", "k1"):
+        pp[key] = pp[key].copy()
+        pp[key][rng.choice(np.arange(1, n), size=n // 3, replace=False)] = np.nan
+    stack = C5_STACK + [("modify_orbits_forces", {})]
+    want = run_oracle(zero_acc(cols), pp, stack)
+    odd = dict(pp)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        zero_over_zero = np.zeros(1) / np.zeros(1)
+        odd["tau_a"] = -np.where(np.isnan(pp["tau_a"]), np.nan, -pp["tau_a"])
+        odd["tau_e"] = np.where(np.isnan(pp["tau_e"]), zero_over_zero[0], pp["tau_e"])
+        odd["beta"] = np.where(np.isnan(pp["beta"]), np.inf - np.inf, pp["beta"])
+        payload = np.array([0x7FF8000000000123], dtype=np.uint64).view(np.float64)[0]
+        odd["tau_inc"] = np.where(np.isnan(pp["tau_inc"]), payload, pp["tau_inc"])
+        signalling = np.array([0xFFF0000000000001], dtype=np.uint64).view(np.float64)[0]
+        odd["k1"] = np.where(np.isnan(pp["k1"]), signalling, pp["k1"])
+    patterns = {int(v) for k in ("tau_a", "tau_e", "beta", "tau_inc", "k1") for v in np.unique(odd[k][np.isnan(odd[k])].view(np.uint64))}
+    assert len(patterns) >= 3 and any(p >> 63 for p in patterns)   # several patterns, a sign-flipped NaN among them
+    assert np.array_equal(run_oracle(zero_acc(cols), odd, stack), want)     # the checker reads them the same way
+    got, _ = run_device(ctx, zero_acc(cols), odd, stack, 1.0, mode)
+    same, _ = run_device(ctx, zero_acc(cols), pp, stack, 1.0, mode)
+    assert np.isfinite(got).all()
+    assert np.array_equal(got, same)
+
+
 def test_unaligned_columns_take_the_scalar_path(ctx):
     """Views that start 8 bytes into an allocation cannot use 16-byte accesses."""
     import torch

@@ -377,6 +377,47 @@ def test_open_run_contract(ctx):
     assert np.isfinite(state_of(dp)).all()
 
 
+@pytest.mark.parametrize("n_planets", [0, 2])
+def test_open_run_keeps_its_tables_to_itself(ctx, n_planets):
+    """While a run is open, the entry points that would overwrite the context's tables and records are refused (and leave
+    nothing behind: the run ends bit for bit where an undisturbed one ends), the run stays on its stream, and a second
+    context serves the same calls meanwhile."""
+    import torch
+    from reboundx_amd.device import Context, RebxAmdError
+    cols, pp, _ = synthetic.disk(3000, n_planets)
+    stack = [("radiation_forces", {"c": C})] if n_planets else C5_STACK
+    ops = build_ops(stack, pp)
+    kw = dict(n_head=1 + n_planets, tail_massless=True)
+    host = dict(cols)
+    for k in ("beta", "R_tides", "k1", "tau_a", "tau_e", "tau_inc"):
+        host[k] = pp[k]
+    quiet = DeviceParticles.from_host(host, device="cuda:0", **kw)
+    ctx.wh_run_begin(quiet.view(), ops, 0.03)
+    ctx.wh_run_steps(5)
+    ctx.wh_run_end()
+    dp = DeviceParticles.from_host(host, device="cuda:0", **kw)
+    other = DeviceParticles.from_host(host, device="cuda:0", **kw)
+    ctx.wh_run_begin(dp.view(), ops, 0.03)
+    ctx.wh_run_steps(2)
+    for call in (lambda: ctx.apply(other.view(), ops, 0), lambda: ctx.wh_steps(other.view(), ops, 0.03, 1), lambda: ctx.wh_drift(other.view(), 0.03),
+                 lambda: ctx.integrate_force(other.view(), ops, "rk2", 0.01), lambda: ctx.wh_batch(4)):
+        with pytest.raises(RebxAmdError) as ei:
+            call()
+        assert ei.value.code == 1 and "run is open" in str(ei.value)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for call in (lambda: ctx.wh_run_steps(1), ctx.wh_run_end):
+            with pytest.raises(RebxAmdError) as ei:
+                call()
+            assert ei.value.code == 1 and "stream" in str(ei.value)
+    second = Context(0)
+    second.apply(other.view(), ops, 0)                            # a second context is free to work meanwhile
+    second.close()
+    ctx.wh_run_steps(3)
+    ctx.wh_run_end()
+    assert np.array_equal(state_of(dp), state_of(quiet))
+
+
 @pytest.mark.parametrize("mode", [1, 0])
 @pytest.mark.parametrize("forces", [C5_STACK, C2_STACK, [("gr", {"c": C})]], ids=["five-effects", "rad+harmonics+gr", "gr"])
 @pytest.mark.parametrize("n", [2, 3, 1500, 4099])

@@ -78,6 +78,103 @@ def test_static_scratch_entry_point_matches_rebxamd_apply_on_two_calls_in_a_row(
             n, int((want.view(np.int64) != got.view(np.int64)).sum()))
 
 
+def test_static_scratch_entry_point_takes_no_device_memory(ctx):
+    """Free device memory as the driver reports it (hipMemGetInfo) is the same before and after calls on growing
+    inputs, all-massive layout included (its partial sums live in the fixed array)."""
+    sizes = (4099, 150001, 1_200_001)
+    prepared = []
+    for n in sizes:
+        cols, pp, host = particles(n, 0, 1e-14)
+        prepared.append((DeviceParticles.from_host(host), build_ops(C3_STACK, pp, 0)))
+    rc, msg = apply_static(prepared[0][0].view(), prepared[0][1], 0)          # first call on the device: address look-up
+    assert rc == _lib.OK, msg
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for dp, ops in prepared:
+        for mode in (0, 1):
+            rc, msg = apply_static(dp.view(), ops, mode)
+            assert rc == _lib.OK, msg
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+
+
+@pytest.mark.parametrize("stack,n_planets,dust_mass", [(C2_STACK, 2, 0.0), (C3_STACK, 0, 1e-15)], ids=["c2-massless-tail", "c3-all-massive"])
+def test_static_scratch_entry_point_under_stream_capture(ctx, stack, n_planets, dust_mass):
+    """The call is captured into a HIP graph (capture mode global: a hipMalloc, hipFree or a wait for the stream inside
+    it would fail the capture) and the graph replayed twice; the accelerations equal those of rebxamd_apply called
+    twice.  The look-up of the array's address happens on the first call on the device, made outside the capture."""
+    n = 60001
+    cols, pp, host = particles(n, n_planets, dust_mass)
+    ops = build_ops(stack, pp, 0)
+    warm = DeviceParticles.from_host(host)
+    rc, msg = apply_static(warm.view(), ops, 0)
+    assert rc == _lib.OK, msg
+    want = DeviceParticles.from_host(host)
+    ctx.apply(want.view(), ops, 0)
+    ctx.apply(want.view(), ops, 0)
+    dp = DeviceParticles.from_host(host)
+    before = np.array(dp.acc_host())
+    word = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=torch.cuda.Stream()):
+        rc, msg = apply_static(dp.view(), ops, 0, warnings=word)
+    assert rc == _lib.OK, msg
+    torch.cuda.synchronize()
+    assert np.array_equal(np.array(dp.acc_host()), before)            # captured, not run
+    graph.replay()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(np.array(dp.acc_host()), np.array(want.acc_host()))
+
+
+def test_static_scratch_entry_point_serves_host_threads_in_turn(ctx):
+    """Several host threads call at the same time, all on ONE stream (which orders their work on the GPU), each with its
+    own particles and warning word.  The host side of a call is serialised inside the library, so the launches of one
+    call stay together in the stream: every call's warning bits land in its own word and every result equals
+    rebxamd_apply's.  (Were the launches of two calls to interleave, one call's head pass would overwrite the tables
+    the other's streaming pass is about to read.)"""
+    import threading
+    n = 20011
+    cols, pp, host = particles(n, 1, 0.0)
+    loud, calm = build_ops([("gr", {"c": 3.0})], pp, 0), build_ops([("gr", {"c": C})], pp, 0)
+    ref = {}
+    for name, ops in (("loud", loud), ("calm", calm)):
+        a = DeviceParticles.from_host(host)
+        ctx.apply(a.view(), ops, 0)
+        ref[name] = (np.array(a.acc_host()), ctx.fetch_warnings())
+    assert ref["loud"][1] != 0 and ref["calm"][1] == 0
+    shared = torch.cuda.Stream()
+    errors, results = [], []
+
+    def worker(name, ops):
+        try:
+            with torch.cuda.stream(shared):
+                mine = []
+                for _ in range(25):
+                    dp = DeviceParticles.from_host(host)
+                    word = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+                    rc, msg = apply_static(dp.view(), ops, 0, warnings=word)
+                    assert rc == _lib.OK, msg
+                    mine.append((dp, word))
+                results.append((name, mine))
+        except Exception as e:              # noqa: BLE001
+            errors.append((name, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(nm, ops)) for nm, ops in (("loud", loud), ("calm", calm), ("loud", loud), ("calm", calm))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    shared.synchronize()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for name, mine in results:
+        for dp, word in mine:
+            assert int(word.item()) == ref[name][1], (name, int(word.item()))
+            assert np.array_equal(np.array(dp.acc_host()), ref[name][0])
+
+
 def test_static_scratch_entry_point_against_the_checker(ctx):
     n = 30011
     cols, pp, host = particles(n, 0, 1e-12)
