@@ -46,7 +46,7 @@ def make_shard(rank, world, n_per_gpu):
     return cols, pp, idx
 
 
-def cpu_baseline(cols, pp, reps, threads):
+def cpu_baseline(cols, pp, reps, threads, stack=None):
     """The CPU checker (a port of the reference algorithm) on the same particles, on `threads`
     host threads: the particles behind the star are cut into `threads` slices, every thread
     evaluates the stack on [star | its slice] (the ctypes calls release the interpreter lock).
@@ -61,10 +61,12 @@ def cpu_baseline(cols, pp, reps, threads):
         idx = np.concatenate([[0], np.arange(bounds[k], bounds[k + 1])])
         sims.append((oracle.Sim({c: v[idx] for c, v in cols.items()}), {c: v[idx] for c, v in pp.items()}))
 
+    stack = STACK if stack is None else stack
+
     def work(item):
         sim, p = item
         for _ in range(reps):
-            oracle.apply_forces(sim, STACK, p)
+            oracle.apply_forces(sim, stack, p)
 
     t0 = time.perf_counter()
     work(sims[0])
@@ -76,18 +78,72 @@ def cpu_baseline(cols, pp, reps, threads):
     return (n - 1) * reps / dt, dt, single
 
 
+def grfull_cpu_baseline(n, sweeps, rows=1024):
+    """The CPU checker's gr_full phases (potential sums, constant part, one sweep: oracle/rebx_oracle.c, the reference's
+    loops restated in O(N^2)) on `rows` of the n rows of the same cluster, on all host threads the box grants (OpenMP inside
+    the checker), extrapolated to a whole evaluation with `sweeps` sweeps: every row costs the same n - 1 pairs per phase."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes
+    import oracle
+    cl = synthetic.cluster(n)
+    for k, src in (("ax", "x"), ("ay", "y"), ("az", "z")):
+        cl[k] = -cl[src]
+    sim = oracle.Sim(cl)
+    rows = min(rows, n)
+    z = lambda: np.zeros(n)
+    pot, ac, an, ao, out = z(), [z(), z(), z()], [cl["ax"].copy(), cl["ay"].copy(), cl["az"].copy()], [z(), z(), z()], [z(), z(), z()]
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    ref, c = ctypes.byref(sim.s), ctypes.c_double(1.0e4)
+    times = {}
+    t0 = time.perf_counter()
+    oracle.lib.orc_gr_full_pot(ref, c, 0, rows, P(pot))
+    times["pot"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    oracle.lib.orc_gr_full_const(ref, c, 0, rows, P(pot), *[P(a) for a in ac])
+    times["const"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    oracle.lib.orc_gr_full_sweep(ref, c, 0, rows, *[P(a) for a in an], *[P(a) for a in ao], *[P(a) for a in ac], *[P(a) for a in out])
+    times["sweep"] = time.perf_counter() - t0
+    per_eval = (times["pot"] + times["const"] + sweeps * times["sweep"]) * n / rows
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+    return {"value": n * (n - 1.0) * (2 + sweeps) / per_eval, "unit": "pair-interactions/s", "cores": threads, "kind": "port",
+            "sample": "the checker's three gr_full phases on %d of the %d rows (%.2f + %.2f + %.2f s for potential sums, constant part, one sweep), "
+                      "scaled by %d/%d rows and to %d sweeps: %.0f s per evaluation" % (rows, n, times["pot"], times["const"], times["sweep"], n, rows, sweeps, per_eval)}
+
+
+def load_profile(name):
+    """A committed profile summary under profiles/ (counter passes cannot run inside this script's timed run)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def grfull_section(ctx, n, mode=0, dist=None, device="cuda:0"):
     """Secondary metric: gr_full pair-interactions/s at n bodies; rows sharded over the ranks
     of the job (all-gather of the new accelerations per sweep over RCCL), or one GPU."""
     from reboundx_amd.dist import HipGrFullEngine, grfull_sharded
-    cl = synthetic.cluster(n)
-    dp = DeviceParticles.from_host(cl, device=device, n_head=n, tail_massless=False)
-    # incoming accelerations: Newtonian gravity is part of REBOUND, not of this path; any smooth
-    # field of the right size exercises the same arithmetic
-    for k, s in (("ax", "x"), ("ay", "y"), ("az", "z")):
-        dp.cols[k].copy_(-dp.cols[s])
-    eng = HipGrFullEngine(ctx, dp, mode)
     world = dist.get_world_size() if dist is not None else 1
+    eng = failure = None
+    try:
+        cl = synthetic.cluster(n)
+        dp = DeviceParticles.from_host(cl, device=device, n_head=n, tail_massless=False)
+        # incoming accelerations: Newtonian gravity is part of REBOUND, not of this path; any smooth
+        # field of the right size exercises the same arithmetic
+        for k, s in (("ax", "x"), ("ay", "y"), ("az", "z")):
+            dp.cols[k].copy_(-dp.cols[s])
+        eng = HipGrFullEngine(ctx, dp, mode)
+        torch.cuda.synchronize()
+    except Exception as e:  # noqa: BLE001
+        failure = "%s: %s" % (type(e).__name__, e)
+    if dist is not None:
+        # the ranks agree that every one of them is set up before the first collective of the evaluation
+        ok = torch.tensor([0.0 if failure else 1.0], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) == 0.0 and failure is None:
+            failure = "another rank failed to set up"
+    if failure:
+        return {"error": failure}
 
     def sync():
         torch.cuda.synchronize()
@@ -109,25 +165,68 @@ def grfull_section(ctx, n, mode=0, dist=None, device="cuda:0"):
     pairs = n * (n - 1.0) * (2 + sweeps)
     flops = n * (n - 1.0) * (70 + 36 * sweeps)
     peak = FP64_PEAK_TFLOPS * world
-    return {"n": n, "n_gpus": world, "sweeps": sweeps, "ms_per_eval": dt * 1e3, "pair_interactions_per_s": pairs / dt,
-            "sharding": "rows i over ranks; all-gather of a_new per sweep" if world > 1 else "single GPU",
-            "roofline": {"bound": "fp64-valu", "achieved": flops / dt / 1e12, "peak": peak, "unit": "TFLOP/s",
-                         "frac": flops / dt / 1e12 / peak}}
+    out = {"n": n, "n_gpus": world, "sweeps": sweeps, "ms_per_eval": dt * 1e3, "pair_interactions_per_s": pairs / dt,
+           "sharding": "rows i over ranks; all-gather of a_new per sweep" if world > 1 else "single GPU",
+           "roofline": {"bound": "fp64-valu", "achieved": flops / dt / 1e12, "peak": peak, "unit": "TFLOP/s",
+                        "frac": flops / dt / 1e12 / peak}}
+    # the clock the chip holds under these kernels, from a committed counter pass (GRBM_GUI_ACTIVE / 8 XCDs / duration of the
+    # millisecond-long dispatches): the vector peak actually on offer is 78.6 TF x clock / 2.4 GHz
+    prof = load_profile(CLOCK_PROFILE)
+    if prof is not None:
+        clocks = [k["effective_clock_GHz"] for name, k in prof.get("kernels", {}).items()
+                  if "grfull_fast" in name and k.get("effective_clock_GHz") and k.get("duration_us", 0) >= 1000.]
+        if clocks:
+            clock = sum(clocks) / len(clocks)
+            out["effective_clock_GHz"] = clock
+            out["frac_at_held_clock"] = out["roofline"]["frac"] * 2.4 / clock
+            out["clock_source"] = "profiles/%s (committed counter pass, not measured in this run)" % CLOCK_PROFILE
+    return out
 
 
+TRAFFIC_SOURCE = ("profiles/traffic.json (committed: TCC counters of separate rocprofv3 --pmc passes over this command, "
+                  "2 x FETCH_SIZE + WRITE_SIZE per launch; not measured in this run)")
+CLOCK_PROFILE = "r03_clock_valu.json"
+WH_PROFILE = "r03_wh_valu.json"     # VALU instructions per wavefront and step of the batched stepping passes (scripts/pmc_wh.sh)
 WH_BATCH = 32                       # the library's default steps per pass of a queued Wisdom-Holman run
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4     # wave64 vector instructions per second: 1024 SIMDs, one instruction per 4 cycles at 2.4 GHz
 
 
-def valu_issue_roofline(instructions_per_wave_step, n, seconds_per_step):
-    """Vector-issue roofline of a stepping pass that keeps its bodies in registers over a batch of steps."""
+def valu_issue_roofline(key, n, seconds_per_step):
+    """Vector-issue roofline of a stepping pass that keeps its bodies in registers over a batch of steps.  The instruction
+    count per wavefront (128 grains) and step is not measured by this run: it comes from the committed counter pass
+    profiles/<WH_PROFILE> (SQ_INSTS_VALU / SQ_WAVES of a 32-step pass), and the figure is labelled so."""
+    prof = load_profile(WH_PROFILE)
+    if prof is None or key not in prof:
+        return None
+    per_wave_step = prof[key]["valu_per_wave_and_step"]
     waves = (n + 127) // 128
-    achieved = instructions_per_wave_step * waves / seconds_per_step
+    achieved = per_wave_step * waves / seconds_per_step
     return {"bound": "fp64-valu-issue", "achieved": achieved / 1e9, "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave-instructions/s",
-            "frac": achieved / VALU_ISSUE_PEAK, "instructions_per_wave_and_step": instructions_per_wave_step}
+            "frac": achieved / VALU_ISSUE_PEAK, "instructions_per_wave_and_step": per_wave_step,
+            "instructions_source": "profiles/%s (committed counter pass%s; not measured in this run)" % (
+                WH_PROFILE, ", taken at commit " + prof["commit"] if prof.get("commit") else "")}
 
 
-def c5_section(ctx, n, steps, mode, device):
+def sampled_deviation(before, after, cols, pp, sample, stack, dt, steps):
+    """Correctness check of the queued device-resident run (not part of any timed figure): the CPU checker's Wisdom-Holman
+    restatement takes the star and the sampled grains from their state before the run through the same `steps` steps.
+    Massless grains feel the star and not one another, and nothing they do reaches the star, so the sample's trajectory
+    is the same alone as among all grains."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    sub = {k: (before[k].copy() if k in before else np.ascontiguousarray(v[sample])) for k, v in cols.items()}
+    ref = oracle.Sim(sub)
+    t0 = time.perf_counter()
+    oracle.whfast_steps(ref, dt, steps, stack, {k: np.ascontiguousarray(v[sample]) for k, v in pp.items()})
+    want = np.array([ref.cols[k] for k in ("x", "y", "z", "vx", "vy", "vz")])
+    r = np.sqrt((want[:3] ** 2).sum(axis=0))
+    dev = float((np.abs(after - want).max(axis=0) / np.maximum(r, 1.)).max())
+    return {"grains": int(len(sample) - 1), "steps": int(steps), "max_deviation": dev, "bound": 2e-10, "within_bound": bool(dev <= 2e-10),
+            "measure": "max |device - checker| over positions and velocities of the sampled grains after the queued run, each grain's divided by max(1, its distance from the star)",
+            "checker_seconds": time.perf_counter() - t0}
+
+
+def c5_section(ctx, n, steps, mode, device, check_sample=True):
     """Secondary metric: end-to-end device-resident run -- star + n massless grains, five stacked
     effects in the kick of a Wisdom-Holman step, particle and parameter columns resident in HBM.
     Reports the per-step latency with the host waiting for every step (one stream
@@ -150,42 +249,50 @@ def c5_section(ctx, n, steps, mode, device):
     from reboundx_amd._lib import Op, lib
     arr = (Op * len(ops))(*ops)
     vref, stream = ctypes.byref(view), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    def check(rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed: %d (%s)" % (what, rc, lib.rebxamd_last_error(ctx._h).decode(errors="replace")))
+
     t0 = time.perf_counter()
     for _ in range(steps):
-        rc = lib.rebxamd_wh_steps(ctx._h, vref, arr, len(ops), dt, 1, mode, stream)
+        check(lib.rebxamd_wh_steps(ctx._h, vref, arr, len(ops), dt, 1, mode, stream), "rebxamd_wh_steps")
         torch.cuda.current_stream().synchronize()
-    synced = (time.perf_counter() - t0) / steps
-    if rc != 0:
-        raise RuntimeError("rebxamd_wh_steps failed: %d" % rc)
+    synced = (time.perf_counter() - t0) / max(steps, 1)
+    # a sample of grains is kept aside before the queued run: the checker takes (star + sample) through the same steps afterwards
+    pick = torch.from_numpy(np.sort(np.concatenate([[0], 1 + np.random.default_rng(5).choice(n, size=min(256, n), replace=False)]))).to(device)
+    state_cols = ("x", "y", "z", "vx", "vy", "vz")
+    before = {k: dp.cols[k][pick].cpu().numpy() for k in state_cols}
     t0 = time.perf_counter()
     ctx.wh_steps(view, ops, dt, steps, mode)
     torch.cuda.synchronize()
     queued = (time.perf_counter() - t0) / steps
+    after = np.array([dp.cols[k][pick].cpu().numpy() for k in state_cols])
+    sample_check = None
+    if check_sample:
+        sample_check = sampled_deviation(before, after, cols, pp, pick.cpu().numpy(), stack, dt, steps)
     # the same with the run left open between the host's waits (rebxamd_wh_run_*: the trailing half drift of a step is merged
     # with the next step's leading one, as REBOUND's WHFast does with safe_mode = 0): one launch and one wait per step
-    rc = lib.rebxamd_wh_run_begin(ctx._h, vref, arr, len(ops), dt, mode, stream)
+    check(lib.rebxamd_wh_run_begin(ctx._h, vref, arr, len(ops), dt, mode, stream), "rebxamd_wh_run_begin")
     t0 = time.perf_counter()
     for _ in range(steps):
-        rc = rc or lib.rebxamd_wh_run_steps(ctx._h, 1, stream)
+        check(lib.rebxamd_wh_run_steps(ctx._h, 1, stream), "rebxamd_wh_run_steps")
         torch.cuda.current_stream().synchronize()
-    synced_open = (time.perf_counter() - t0) / steps
-    rc = rc or lib.rebxamd_wh_run_end(ctx._h, stream)
+    synced_open = (time.perf_counter() - t0) / max(steps, 1)
+    check(lib.rebxamd_wh_run_end(ctx._h, stream), "rebxamd_wh_run_end")
     torch.cuda.synchronize()
-    if rc != 0:
-        raise RuntimeError("rebxamd_wh_run_*: %d" % rc)
     x = dp.cols["x"]
     finite = bool(torch.isfinite(x).all().item())
     # Queued steps run in batches (rebxamd_wh_batch, 32 by default): one pass takes every grain through the steps of a batch in
     # registers -- positions, velocities, beta and the three timescales read (80 B) and positions and velocities written
     # (48 B) once per BATCH, i.e. 4 B per grain and step -- so the pass is bound by fp64 vector issue, not by memory.
-    # Instructions per wavefront (128 grains) and step from SQ_INSTS_VALU / SQ_WAVES of a 32-step pass (scripts/pmc_wh.sh 1000000 128):
-    # 22 100 / 32 = 690 for this stack.
+    # Instructions per wavefront (128 grains) and step: SQ_INSTS_VALU / SQ_WAVES of a 32-step pass (scripts/pmc_wh.sh 1000000 128),
+    # read from the committed summary of that counter pass.
     # A wave64 vector instruction occupies its SIMD for 4 cycles (more for the quarter-rate reciprocals and square roots).
     out = {"n": n, "steps": steps, "effects": 5, "steps_per_pass": WH_BATCH, "us_per_step_host_synced": synced * 1e6,
            "us_per_step_host_synced_open_run": synced_open * 1e6, "us_per_step_queued": queued * 1e6,
-           "particle_steps_per_s": n / queued, "state_finite": finite,
+           "particle_steps_per_s": n / queued, "state_finite": finite, "sampled_grains_vs_checker": sample_check,
            "hbm_bytes_per_particle_step": 128. / WH_BATCH,
-           "roofline": valu_issue_roofline(690, n, queued)}
+           "roofline": valu_issue_roofline("five_effects", n, queued)}
     # the shape of BASELINE configuration 1 (star + planet + grains under radiation forces) at this size: the massive head steps in
     # Jacobi coordinates in one wavefront (three small launches per step), the grains in the same kind of pass, which also adds the
     # pull of both head bodies; positions, velocities and beta read (56 B), positions and velocities written (48 B)
@@ -209,25 +316,23 @@ def c5_section(ctx, n, steps, mode, device):
     steps2 = max(1, steps // 10)
     t0 = time.perf_counter()
     for _ in range(steps2):
-        rc = lib.rebxamd_wh_steps(ctx._h, v1ref, arr1, len(ops1), dt, 1, mode, stream)
+        check(lib.rebxamd_wh_steps(ctx._h, v1ref, arr1, len(ops1), dt, 1, mode, stream), "rebxamd_wh_steps behind star + planet")
         torch.cuda.current_stream().synchronize()
     s1 = (time.perf_counter() - t0) / steps2
-    rc = rc or lib.rebxamd_wh_run_begin(ctx._h, v1ref, arr1, len(ops1), dt, mode, stream)
+    check(lib.rebxamd_wh_run_begin(ctx._h, v1ref, arr1, len(ops1), dt, mode, stream), "rebxamd_wh_run_begin behind star + planet")
     t0 = time.perf_counter()
     for _ in range(steps2):
-        rc = rc or lib.rebxamd_wh_run_steps(ctx._h, 1, stream)
+        check(lib.rebxamd_wh_run_steps(ctx._h, 1, stream), "rebxamd_wh_run_steps behind star + planet")
         torch.cuda.current_stream().synchronize()
     so1 = (time.perf_counter() - t0) / steps2
-    rc = rc or lib.rebxamd_wh_run_end(ctx._h, stream)
+    check(lib.rebxamd_wh_run_end(ctx._h, stream), "rebxamd_wh_run_end behind star + planet")
     torch.cuda.synchronize()
-    if rc != 0:
-        raise RuntimeError("rebxamd_wh_run_* behind star + planet: %d" % rc)
     out["star_planet_grains"] = {"n": n, "steps": steps1, "effects": 1, "us_per_step_queued": q1 * 1e6, "particle_steps_per_s": n / q1,
                                  "us_per_step_host_synced": s1 * 1e6, "us_per_step_host_synced_open_run": so1 * 1e6,
                                  "state_finite": bool(torch.isfinite(dq.cols["x"]).all().item()),
                                  "steps_per_pass": WH_BATCH, "hbm_bytes_per_particle_step": 104. / WH_BATCH,
-                                 # (20 337 / 32 = 635 instructions per wavefront and step: radiation + the pull of both head bodies + the Jacobi term + the drift)
-                                 "roofline": valu_issue_roofline(635, n, q1)}
+                                 # (radiation + the pull of both head bodies + the Jacobi term + the drift)
+                                 "roofline": valu_issue_roofline("star_planet_radiation", n, q1)}
     return out
 
 
@@ -267,6 +372,19 @@ def c3_section(ctx, n, mode, device):
     return out
 
 
+def massive_stack_cpu_baseline(n, threads, reps=4):
+    """The CPU checker on the all-massive stack in PARTICLE coordinates (tides_precession + modify_orbits_forces +
+    gr_potential; the star collects the pushes), n grains of the same synthetic disk sliced over `threads` host threads."""
+    cols, pp, _ = synthetic.disk(n, 0, dust_mass=1e-15)
+    pp["primary"] = np.zeros(n, dtype=np.uint8)
+    pp["primary"][0] = 1
+    stack = [("tides_precession", {}), ("modify_orbits_forces", {"coordinates": 2}), ("gr_potential", {"c": C})]
+    v, secs, single = cpu_baseline(cols, pp, reps, threads, stack)
+    return {"value": v, "unit": "evals/s", "cores": threads, "kind": "port",
+            "sample": "%d evaluations of a %d-grain slice of the same disk (PARTICLE coordinates), grains sliced over %d threads (%.1f s); "
+                      "one thread alone: %.3g evals/s" % (reps, n, threads, secs, single)}
+
+
 def timed_evals(ctx, view, ops, mode, reps, warm=2):
     """Seconds per rebxamd_apply (wall clock around `reps` queued evaluations) and the HIP-event time of its
     streaming passes per evaluation."""
@@ -303,25 +421,47 @@ def ooc_section(ctx, n, mode, device):
         except Exception:  # noqa: BLE001
             traffic = None
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "particles": n, "kernel": "stream_kernel (tail pass)", "kernel_us": kernel_s * 1e6, "us_per_eval_wall": dt * 1e6,
+            "traffic_source": TRAFFIC_SOURCE if traffic is not None else None, "particles": n, "kernel": "stream_kernel (tail pass)", "kernel_us": kernel_s * 1e6, "us_per_eval_wall": dt * 1e6,
             "algorithmic_bytes_per_launch": BYTES_PER_EVAL * n,
             "note": "same kernel and stack as the headline line; at 1e7 grains the three acceleration columns (240 MB) stay in the last-level cache between evaluations, here nothing does"}
 
 
-def c3_big_section(ctx, n_total, mode, dist, device, rank, world, red_dev):
+def c3_big_setup(n_total, device, rank, world):
     """BASELINE configuration 3 at its full size: tides_precession + modify_orbits_forces + gr_potential on n_total
     grains of 1e-15 solar masses (every body massive), generated on the device.  One GPU: the whole disk through
     rebxamd_apply.  Several: the grains sharded by index over the ranks (every rank holds [star | its slice]); the
     pushes on the star are summed with one all-reduce of 3 doubles per force, and in Jacobi coordinates the prefix
     and suffix sums cross ranks through two all-gathers of 7 and 3 doubles (reboundx_amd.dist).  Strong scaling: the
     total size is fixed; the time is the slowest rank's, collectives included."""
-    from reboundx_amd.dist import apply_forces_sharded, particle_shard
+    from reboundx_amd.dist import particle_shard
     lo, hi = particle_shard(n_total, 1, world, rank)
     cols = synthetic.disk_device(1 + (hi - lo), device, dust_mass=1e-15, seed=3 + rank)
     keep = ("x", "y", "z", "vx", "vy", "vz", "m", "ax", "ay", "az", "R_tides", "k1", "tau_a", "tau_e", "tau_inc")
     dp = DeviceParticles({k: cols[k] for k in keep}, n_head=1, tail_massless=False)
     del cols
     sp = synthetic.star_params()
+    return dp, sp
+
+
+def c3_big_section(ctx, n_total, mode, dist, device, rank, world, red_dev):
+    # Every rank sets up its slice first; the ranks then agree (one all-reduce of a flag) whether all of them succeeded,
+    # and only then enter the timed collectives: a rank that failed alone (out of memory at 1e8 bodies, say) must not
+    # leave the others waiting at a barrier.
+    dp = sp = None
+    failure = None
+    try:
+        dp, sp = c3_big_setup(n_total, device, rank, world)
+        torch.cuda.synchronize()
+    except Exception as e:  # noqa: BLE001
+        failure = "%s: %s" % (type(e).__name__, e)
+    if dist is not None:
+        ok = torch.tensor([0.0 if failure else 1.0], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) == 0.0 and failure is None:
+            failure = "another rank failed to set up its slice"
+    if failure:
+        return {"error": failure}
+    from reboundx_amd.dist import apply_forces_sharded
     out = {"n_total": n_total, "n_gpus": world, "bytes_per_eval": 144, "scaling": "strong",
            "sharding": "one GPU, rebxamd_apply" if world == 1 else "grains by index over ranks; all-reduce of the pushes on the star, all-gathers of the prefix/suffix sums"}
     reps = 5
@@ -465,7 +605,7 @@ def main():
                                    "gravitational_harmonics(J2,J4) + gr fused, device-resident fp64 columns",
                        "particles_per_gpu": args.n_per_gpu, "arithmetic": args.mode, "sharding": "particle index, no communication"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "stream_kernel (tail pass; the HIP-event time per step also holds the one-wavefront head pass launched in front of it)",
+                         "traffic": traffic, "traffic_source": TRAFFIC_SOURCE if traffic is not None else None, "kernel": "stream_kernel (tail pass; the HIP-event time per step also holds the one-wavefront head pass launched in front of it)",
                          "kernel_us": kernel_s * 1e6,
                          "algorithmic_bytes_per_launch": BYTES_PER_EVAL * tail},
         }
@@ -497,7 +637,7 @@ def main():
                 out["roofline_out_of_cache"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if args.c5_n > 0:
             try:
-                out["resident_run"] = c5_section(ctx, args.c5_n, args.c5_steps, mode, "cuda:%d" % local_rank)
+                out["resident_run"] = c5_section(ctx, args.c5_n, args.c5_steps, mode, "cuda:%d" % local_rank, check_sample=not args.no_cpu)
             except Exception as e:  # noqa: BLE001
                 out["resident_run"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if args.c3_n > 0:
@@ -507,6 +647,19 @@ def main():
                 out["massive_stack"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if gr is not None:
             out["gr_full"] = gr
+        if not args.no_cpu and world == 1:
+            threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+            if gr is not None and "error" not in gr:
+                try:
+                    gr["cpu_baseline"] = grfull_cpu_baseline(args.grfull_n, gr["sweeps"])
+                except Exception as e:  # noqa: BLE001
+                    gr["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            ms = out.get("massive_stack")
+            if ms is not None and "error" not in ms:
+                try:
+                    ms["cpu_baseline"] = massive_stack_cpu_baseline(min(args.c3_n, 1_000_000), threads)
+                except Exception as e:  # noqa: BLE001
+                    ms["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(out), flush=True)
     barrier()
     ctx.close()

@@ -32,4 +32,30 @@ for k, d in acc.items():
         m["SQ_WAVES"], m["SQ_INSTS_VALU"] / m["SQ_WAVES"], m["SQ_INSTS_SALU"] / m["SQ_WAVES"], m["GRBM_GUI_ACTIVE"] / 8 / m["dur"],
         m["SQ_ACTIVE_INST_VALU"] / m["SQ_BUSY_CYCLES"], m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]))
     print("   raw", {c: v for c, v in m.items()})
+# Summary for bench.py (copied to profiles/<round>_wh_valu.json): the passes that carry a whole batch of steps are the
+# dispatches with the most instructions per wavefront of their kernel instance; the first such instance the bench runs is the
+# five-effect stack behind the star, the second the radiation stack behind star + planet.
+import json, subprocess
+BATCH = 32
+first, best = {}, {}
+for (k, disp), d in per.items():
+    if ", 7>" not in k:            # (the last template argument: 7 = the pass that carries a batch of steps)
+        continue
+    first[k] = min(first.get(k, 1 << 62), int(disp))
+    v = d["SQ_INSTS_VALU"] / d["SQ_WAVES"]
+    if v > best.get(k, (0., None))[0]:
+        best[k] = (v, d)
+names = sorted(best, key=lambda k: first[k])
+summary = {"source": "rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVES ... --kernel-trace on `bench.py --steps 2 --warmup 1 --no-cpu --grfull-n 0 --c3-n 0 "
+                     "--c3-big-n 0 --ooc-n 0 --c5-n N --c5-steps STEPS` (scripts/pmc_wh.sh); per kernel instance the dispatches that carry a whole batch of %d steps" % BATCH,
+           "steps_per_pass": BATCH}
+try:
+    summary["commit"] = subprocess.check_output(["git", "-C", out + "/..", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+except Exception:
+    pass
+for key, k in zip(("five_effects", "star_planet_radiation"), names):
+    v, d = best[k]
+    summary[key] = {"kernel": k[:90], "valu_per_wave_per_pass": v, "valu_per_wave_and_step": v / BATCH, "waves": d["SQ_WAVES"], "duration_us": d["dur"] / 1e3}
+json.dump(summary, open(out + "/wh_valu.json", "w"), indent=1)
+print(json.dumps(summary, indent=1))
 P

@@ -24,15 +24,18 @@ for r in rows:
             acc[k[:60]]["dur_ns"].append(dur)
 import json
 summary = {"source": "rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --kernel-trace on "
-                     "`bench.py --steps 3 --warmup 1 --no-cpu --c5-n 0 --c3-n 0 --c3-big-n 0 --ooc-n 0`; clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel duration", "kernels": {}}
+                     "`bench.py --steps 3 --warmup 1 --no-cpu --c5-n 0 --c3-n 0 --c3-big-n 0 --ooc-n 0`; clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel duration, for dispatches of at least a millisecond", "kernels": {}}
 for k, d in acc.items():
     m = {c: sum(v) / len(v) for c, v in d.items()}
+    # the clock is derived only for dispatches of a millisecond or more: on a 150 us kernel the counter's window and the
+    # kernel's timestamps do not line up well enough (it read 2.78 GHz on a chip whose maximum is 2.4)
+    long_enough = "dur_ns" in m and m["dur_ns"] >= 1e6
     summary["kernels"][k] = {"dispatches": len(d["SQ_WAVES"]), "duration_us": m.get("dur_ns", 0) / 1e3,
-                             "effective_clock_GHz": (m["GRBM_GUI_ACTIVE"] / 8 / m["dur_ns"]) if "dur_ns" in m else None,
+                             "effective_clock_GHz": (m["GRBM_GUI_ACTIVE"] / 8 / m["dur_ns"]) if long_enough else None,
                              "waves": m["SQ_WAVES"], "valu_instructions": m["SQ_INSTS_VALU"], "valu_per_wave": m["SQ_INSTS_VALU"] / m["SQ_WAVES"]}
     line = "%-62s n=%d" % (k, len(d["SQ_WAVES"]))
     if "dur_ns" in m:
-        line += "  dur %.1f us  clock %.2f GHz" % (m["dur_ns"] / 1e3, m["GRBM_GUI_ACTIVE"] / 8 / m["dur_ns"])
+        line += "  dur %.1f us" % (m["dur_ns"] / 1e3) + ("  clock %.2f GHz" % (m["GRBM_GUI_ACTIVE"] / 8 / m["dur_ns"]) if long_enough else "  (too short for a clock figure)")
     line += "  VALU/wave %.0f" % (m["SQ_INSTS_VALU"] / m["SQ_WAVES"])
     print(line)
 json.dump(summary, open(out + "/clock_valu.json", "w"), indent=1)

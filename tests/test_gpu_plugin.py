@@ -736,3 +736,90 @@ def test_two_simulations_stepping_on_two_host_threads_share_the_helper_threads()
     again = []
     evaluate(sims[0], 3, again)
     assert np.array_equal(again[0], alone[0])
+
+
+def debris_disk_example():
+    """examples/rad_forces_debris_disk/problem.c:21-74 with its literal numbers: SI units (G = 6.674e-11), a star of
+    1.99e30 kg, 1000 massless grains on coplanar orbits with a in [100, 120] AU (AU = 1.5e11 m), e = 0.1, pericentre and
+    true anomaly drawn with the C library's rand() after srand(3) in the example's order, then the shift to the centre of
+    mass; radiation_forces with c = 3e8 and beta = 0.1 on every grain.  The orbit -> Cartesian step restates REBOUND's
+    reb_tools_orbit2d_to_particle for a planar orbit about a star at rest at the origin."""
+    libc = ctypes.CDLL(None)
+    libc.rand.restype = ctypes.c_int
+    rand_max = 2147483647.0
+    AU, G, M, e, ndust = 1.5e11, 6.674e-11, 1.99e30, 0.1, 1000
+    amin, awidth = 100. * AU, 20. * AU
+    libc.srand(3)
+    rows = [(0., 0., 0., 0., 0., 0., M)]
+    for _ in range(ndust):
+        a = amin + awidth * libc.rand() / rand_max
+        pomega = 2 * np.pi * libc.rand() / rand_max
+        f = 2 * np.pi * libc.rand() / rand_max
+        r = a * (1 - e * e) / (1 + e * np.cos(f))
+        v0 = np.sqrt(G * M / a / (1. - e * e))
+        rows.append((r * np.cos(pomega + f), r * np.sin(pomega + f), 0.,
+                     v0 * (-np.sin(pomega + f) - e * np.sin(pomega)), v0 * (np.cos(pomega + f) + e * np.cos(pomega)), 0., 0.))
+    p = np.array(rows)
+    cols = {k: p[:, j].copy() for j, k in enumerate(("x", "y", "z", "vx", "vy", "vz", "m"))}
+    # reb_move_to_com: only the star has mass, and it sits at the origin at rest -- the shift is exactly zero
+    for k in ("ax", "ay", "az"):
+        cols[k] = np.zeros(ndust + 1)
+    beta = np.full(ndust + 1, np.nan)
+    beta[1:] = 0.1
+    return cols, G, beta
+
+
+@pytest.mark.parametrize("incoming", ["zero", "gravity"])
+def test_debris_disk_example_with_its_literal_si_parameters(incoming):
+    """BASELINE config 1 as the reference's example states it -- squared distances of 2e26 m^2, accelerations of 7e-8 m/s^2,
+    velocities of 3e3 m/s against c = 3e8 -- through the sim->additional_forces hook with the parameters set one by one
+    (1000 x rebx_set_param_double), and through rebxamd_apply on columns; both arithmetic modes against the checker:
+    0 ulp in reference order, 1e-12 per component in the default arithmetic."""
+    from gpu_common import run_device
+    from reboundx_amd.device import Context
+    cols, G, beta = debris_disk_example()
+    n = len(beta)
+    assert 1.8e26 < (cols["x"][1:] ** 2 + cols["y"][1:] ** 2).min() and (cols["x"][1:] ** 2 + cols["y"][1:] ** 2).max() < 4e26
+    if incoming == "gravity":
+        s = oracle.Sim(cols, G)
+        oracle.newtonian_gravity(s)
+        cols["ax"], cols["ay"], cols["az"] = [a.copy() for a in s.acc]
+    stack, pp = [("radiation_forces", {"c": 3.e8})], {"beta": beta}
+    ref = oracle.Sim(cols, G)
+    oracle.apply_forces(ref, stack, pp)
+    want = np.array(ref.acc)
+    base = np.array([cols["ax"], cols["ay"], cols["az"]])
+    assert 1e-8 < np.abs(want - base)[:, 1:].max() < 1e-6              # beta G M / r^2 ~ 7e-8 m/s^2
+
+    sim = sim_from(cols, G)
+    sim.integrator = 1                                                  # WHFast, as in the example
+    sim.N_active = 1
+    rebx = Extras(sim)
+    rad = rebx.load_force("radiation_forces")
+    rebx.add_force(rad)
+    rad.params["c"] = 3.e8
+    ps = sim.particles
+    for i in range(1, n):
+        ps[i].params["beta"] = 0.1
+    for mode in ("exact", "fast"):
+        rebx.set_mode(mode)
+        for i in range(n):
+            ps[i].ax, ps[i].ay, ps[i].az = cols["ax"][i], cols["ay"][i], cols["az"][i]
+        sim.call_additional_forces()
+        got = acc_of(ps, n)
+        if mode == "exact":
+            assert ulp_diff(got, want).max() == 0
+        else:
+            # the default arithmetic leaves the accelerations on the host and adds the summed forces once
+            assert rel_err(got - base, want - base).max() <= TOL
+            assert rel_err(got, want).max() <= TOL
+    sim.free_particle_params()
+
+    ctx = Context(0)
+    try:
+        exact, _ = run_device(ctx, cols, pp, stack, G, 1)
+        fast, _ = run_device(ctx, cols, pp, stack, G, 0)
+    finally:
+        ctx.close()
+    assert ulp_diff(exact, want).max() == 0
+    assert rel_err(fast - base, want - base).max() <= TOL and rel_err(fast, want).max() <= TOL

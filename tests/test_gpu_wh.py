@@ -503,3 +503,32 @@ def test_batches_on_a_grid_large_enough_for_the_xcd_tile_order(ctx, n_planets):
     assert np.array_equal(out[0], out[1])
     start = np.array([cols[k] for k in ("x", "y", "z", "vx", "vy", "vz")])
     assert np.abs(out[0] - start).max() > 0.1
+
+
+def sampled_run_deviation(ctx, n, steps, dt, mode, nsample=256, seed=5):
+    """BASELINE configuration 5: star + n massless grains under the five stacked effects for `steps` Wisdom-Holman steps
+    on the device (batches of steps per pass), and the same run of (star + a sample of grains) by the checker.  Massless
+    grains feel the star and not one another, and nothing they do reaches the star, so the sample's trajectory is the same
+    in both runs.  Returns max |device - checker| over the sample's positions and velocities, each grain's divided by
+    max(1, its distance from the star)."""
+    cols, pp, _ = synthetic.disk(n + 1, 0)
+    sample = np.sort(np.concatenate([[0], 1 + np.random.default_rng(seed).choice(n, size=min(nsample, n), replace=False)]))
+    dp = device_particles(cols, pp)
+    ctx.wh_steps(dp.view(), build_ops(C5_STACK, {k: v[:1] for k, v in pp.items()}), dt, steps, mode)
+    pick = torch.from_numpy(sample).to("cuda:0")
+    got = np.array([dp.cols[k][pick].cpu().numpy() for k in ("x", "y", "z", "vx", "vy", "vz")])
+    assert bool(torch.isfinite(dp.cols["x"]).all().item()) and bool(torch.isfinite(dp.cols["vx"]).all().item())
+    ref = oracle.Sim({k: v[sample].copy() for k, v in cols.items()})
+    oracle.whfast_steps(ref, dt, steps, C5_STACK, {k: v[sample].copy() for k, v in pp.items()})
+    want = np.array([ref.cols[k] for k in ("x", "y", "z", "vx", "vy", "vz")])
+    r = np.sqrt((want[:3] ** 2).sum(axis=0))
+    return (np.abs(got - want).max(axis=0) / np.maximum(r, 1.)).max()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_a_million_grains_over_ten_thousand_steps_end_where_the_checker_puts_a_sample(ctx, mode):
+    """Configuration 5 at its real length: 1e6 grains x 1e4 steps of dt = P/100 (100 orbits), 256 sampled grains against
+    the checker.  Bound: 2e-10 -- the 1e-12 of the 40-step tests grown linearly with the number of steps, as roundoff in
+    the orbital phase grows (measured: 2.3e-11 in both arithmetic modes)."""
+    dev = sampled_run_deviation(ctx, 1_000_000, 10_000, 2 * np.pi / 100.0, mode)
+    assert dev <= 2e-10, dev
