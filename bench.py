@@ -78,7 +78,7 @@ def cpu_baseline(cols, pp, reps, threads, stack=None):
     return (n - 1) * reps / dt, dt, single
 
 
-def grfull_cpu_baseline(n, sweeps, rows=1024):
+def grfull_cpu_baseline(n, sweeps, rows=8192):
     """The CPU checker's gr_full phases (potential sums, constant part, one sweep: oracle/rebx_oracle.c, the reference's
     loops restated in O(N^2)) on `rows` of the n rows of the same cluster, on all host threads the box grants (OpenMP inside
     the checker), extrapolated to a whole evaluation with `sweeps` sweeps: every row costs the same n - 1 pairs per phase."""
@@ -372,7 +372,7 @@ def c3_section(ctx, n, mode, device):
     return out
 
 
-def massive_stack_cpu_baseline(n, threads, reps=4):
+def massive_stack_cpu_baseline(n, threads, reps=200):
     """The CPU checker on the all-massive stack in PARTICLE coordinates (tides_precession + modify_orbits_forces +
     gr_potential; the star collects the pushes), n grains of the same synthetic disk sliced over `threads` host threads."""
     cols, pp, _ = synthetic.disk(n, 0, dust_mass=1e-15)
