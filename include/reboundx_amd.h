@@ -314,9 +314,11 @@ enum rebxamd_mode {
 /* gr and Jacobi/barycentric modify_orbits_forces accumulate body by body in the reference (src/gr.c:80-167 through
  * REBOUND's Jacobi recurrences; src/rebxtools.c:45-126).  With the massive bodies in a prefix of at most
  * REBXAMD_MAX_HEAD particles followed by massless ones, REBXAMD_MODE_EXACT walks the prefix in that order.  On every
- * other mass layout REBXAMD_MODE_EXACT walks the same recurrences in the reference's order as long as the view holds
- * at most REBXAMD_SEQ_MAX_BODIES particles (chains on one workgroup: milliseconds at the limit; every body then carries
- * the bits of the sequential evaluation); larger views, REBXAMD_MODE_FAST on such layouts and the particle-shard
+ * other mass layout REBXAMD_MODE_EXACT walks the same recurrences in the reference's order as long as they cover at
+ * most REBXAMD_SEQ_MAX_BODIES particles: the whole view, or -- with view->tail_massless set -- its first n_head
+ * particles, the massless ones behind them (any number) being measured from the sums those leave (chains on one
+ * workgroup: milliseconds at the limit; every body then carries the bits of the sequential evaluation); longer
+ * chains, REBXAMD_MODE_FAST on such layouts and the particle-shard
  * entry points (rebxamd_shard_*) evaluate the sums as parallel prefix sums, whose results stay within 5e-14 of a body's
  * largest acceleration component of the exactly rounded value but are NOT the sequential order's bits (the sequential
  * order itself drifts from the exact value as the number of bodies grows: 1e-12 at 6000 bodies, 5e-11 at 300 000). */

@@ -443,9 +443,11 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
             }
             if (scan) {
                 TimedLaunch tl(ctx, st);
-                // reference-order arithmetic: up to REBXAMD_SEQ_MAX_BODIES bodies the recurrences are walked in the
-                // reference's own order (the checker's bits on every body); beyond that, parallel prefix sums
-                if (v.n <= REBXAMD_SEQ_MAX_BODIES && ctx->seq_exact) HIP_TRY(launch_seq_op(v, prog.ops[k - lo], prog.G, ctx->scan, ctx->status, st));
+                // reference-order arithmetic: with at most REBXAMD_SEQ_MAX_BODIES bodies up to the last massive one the recurrences
+                // are walked in the reference's own order (the checker's bits on every body); beyond that, parallel prefix sums
+                // (massless bodies behind the last massive one add zeros to the recurrences: the chains stop there)
+                const long long nseq = (u->tail_massless != 0 && K >= 1) ? K : v.n;
+                if (nseq <= REBXAMD_SEQ_MAX_BODIES && ctx->seq_exact) HIP_TRY(launch_seq_op(v, prog.ops[k - lo], prog.G, ctx->scan, ctx->status, st, nseq));
                 else HIP_TRY(launch_scan_op(v, prog.ops[k - lo], prog.G, exact, ctx->scan, ctx->status, st));
             }
             a = k + 1;

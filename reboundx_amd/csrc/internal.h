@@ -174,7 +174,8 @@ hipError_t launch_gr_hamiltonian(const View& v, double G, double c, double* ws, 
 hipError_t launch_scan_op(const View& v, const DevOp& op, double G, bool exact, double* ws, unsigned* status, hipStream_t st, ScanTail* tail = nullptr);
 // the same two forces in the reference's own order of operations (seq_kernels.hip): reference-order arithmetic,
 // at most REBXAMD_SEQ_MAX_BODIES bodies; ws as for launch_scan_op
-hipError_t launch_seq_op(const View& v, const DevOp& op, double G, double* ws, unsigned* status, hipStream_t st);
+// nseq: bodies the chains walk (the index behind the last massive body when the bodies after it are massless, else v.n)
+hipError_t launch_seq_op(const View& v, const DevOp& op, double G, double* ws, unsigned* status, hipStream_t st, long long nseq);
 int stream_bodies_per_block();     // bodies one workgroup of the streaming pass covers
 int scan_segment_bodies();         // bodies one wavefront of the prefix-sum passes covers
 

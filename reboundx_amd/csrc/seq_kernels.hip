@@ -16,6 +16,10 @@
 // application of the reactions, whose order is fixed per body) runs in parallel around them.  The
 // results carry the bits of the sequential evaluation.  Cost: about 50-150 clock cycles per body in
 // the chains (a division sits inside the centre-of-mass chain), i.e. milliseconds at 65 536 bodies.
+// Massless bodies behind the last massive one (the caller's promise view->tail_massless) need no chain:
+// they add zeros to every running sum, so each of them sees the sums as the last massive body left them
+// and hands nothing back; the chains then cover the bodies up to the last massive one only, however
+// many massless bodies follow (they are evaluated in parallel against those final sums).
 #include "internal.h"
 #include "effects.h"
 
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(QT) void seq_newton(View v, double G, const double*
 // acceleration), one lane per sum; then, for the bodies of the tile in parallel, Jacobi state and
 // post-Newtonian term.  aj <- the term (zero for body 0); mtot[0] <- the total mass as the chain leaves it.
 __global__ __launch_bounds__(QT) void seq_gr_forward(View v, DevOp op, double G, const double* nax, const double* nay, const double* naz,
-                                                     double* ajx, double* ajy, double* ajz, double* mtot, unsigned* status) {
+                                                     double* ajx, double* ajy, double* ajz, double* mtot, unsigned* status, double* sums10) {
 #pragma clang fp contract(off)
     __shared__ double q[10][QT];        // m, x, y, z, vx, vy, vz, newtonian ax, ay, az of the tile
     __shared__ double pre[10][QT];      // the sums over every body before each body of the tile
@@ -117,6 +121,25 @@ __global__ __launch_bounds__(QT) void seq_gr_forward(View v, DevOp op, double G,
         __syncthreads();
     }
     if (tid == 0) mtot[0] = s;
+    if (tid < 10) sums10[tid] = s;       // what every massless body behind these bodies is measured from
+}
+
+// ---- gr for the massless bodies [first, n) behind the last massive one: their Jacobi state is taken from the final running
+// sums (they add zeros to them), their post-Newtonian term comes back unchanged (the reverse recurrence carries zero past them)
+__global__ __launch_bounds__(QT) void seq_gr_tail(View v, DevOp op, double G, long long first, const double* nax, const double* nay, const double* naz,
+                                                  const double* sums10, unsigned* status) {
+#pragma clang fp contract(off)
+    const long long i = first + (long long)blockIdx.x * QT + threadIdx.x;
+    if (i >= v.n) return;
+    const double ei = 1. / sums10[0];
+    Jac j;
+    j.x = v.x[i] - sums10[1] * ei;  j.y = v.y[i] - sums10[2] * ei;  j.z = v.z[i] - sums10[3] * ei;
+    j.vx = v.vx[i] - sums10[4] * ei; j.vy = v.vy[i] - sums10[5] * ei; j.vz = v.vz[i] - sums10[6] * ei;
+    j.ax = nax[i] - sums10[7] * ei; j.ay = nay[i] - sums10[8] * ei; j.az = naz[i] - sums10[9] * ei;
+    V3 a;
+    if (gr_term_exact(j, G * v.m[0], op.c, op.iarg, a) == 10) atomicOr(status, WARN_GR_ITER);
+    // (the reference adds the recurrence's running value, a zero here, before it adds the term to the particle)
+    v.ax[i] += a.x + 0.; v.ay[i] += a.y + 0.; v.az[i] += a.z + 0.;
 }
 
 // ---- gr, backwards: Jacobi -> inertial accelerations (REBOUND's reverse recurrence), added to the
@@ -167,8 +190,12 @@ __global__ __launch_bounds__(QT) void seq_gr_reverse(View v, const double* ajx, 
 // every body of the tile evaluated against the centre of mass of the bodies before it.  Six lanes walk
 // the six components; each carries the mass along.
 // Jacobi: a <- force per body, r <- massratio * force, mr <- massratio (zeros for body 0).
-// Barycentric: com7 <- the centre of mass (x y z vx vy vz m); the per-body pass follows in seq_mof_bary_terms.
-__global__ __launch_bounds__(QT) void seq_mof_com(View v, int jacobi, double* com7, double* ax_, double* ay_, double* az_,
+// com7 <- the centre of mass of all bodies (x y z vx vy vz m): barycentric coordinates measure every body from it
+// (seq_mof_terms_about), Jacobi coordinates the massless bodies behind `v`.
+// ntail: massless bodies that follow the bodies of `v` in the caller's array.  The reference folds them in as well and takes them
+// out again one by one; with zero mass each such step only re-rounds the centre of mass, x <- (x m) / m, a monotone map that
+// settles after a step or two: it is applied until it does (at most as often as the reference applies it), com7 <- the result.
+__global__ __launch_bounds__(QT) void seq_mof_com(View v, int jacobi, long long ntail, double* com7, double* ax_, double* ay_, double* az_,
                                                   double* rx, double* ry, double* rz, double* mr) {
 #pragma clang fp contract(off)
     __shared__ double q[7][QT];         // x y z vx vy vz m of the tile
@@ -196,11 +223,17 @@ __global__ __launch_bounds__(QT) void seq_mof_com(View v, int jacobi, double* co
         }
         __syncthreads();
     }
-    if (!jacobi) {
-        if (tid < 6) com7[tid] = x;
-        if (tid == 0) com7[6] = mm;
-        return;
+    if (tid < 6 && mm > 0.) {
+        const long long most = 2 * ntail < 128 ? 2 * ntail : 128;
+        for (long long k = 0; k < most; k++) {
+            const double xn = (x * mm + 0.) / mm;
+            if (xn == x) break;
+            x = xn;
+        }
     }
+    if (tid < 6) com7[tid] = x;
+    if (tid == 0) com7[6] = mm;
+    if (!jacobi) return;
     for (long long t0 = ((v.n - 1) / QT) * QT; t0 >= 0; t0 -= QT) {
         stage(t0);
         __syncthreads();
@@ -238,11 +271,12 @@ __global__ __launch_bounds__(QT) void seq_mof_com(View v, int jacobi, double* co
     }
 }
 
-// barycentric coordinates: every body against the one centre of mass
-__global__ __launch_bounds__(QT) void seq_mof_bary_terms(View v, const double* com7, double* ax_, double* ay_, double* az_,
-                                                         double* rx, double* ry, double* rz, double* mr) {
+// bodies [first, n) against the one centre of mass: every body in barycentric coordinates; in Jacobi coordinates the massless
+// bodies behind the last massive one (their mass ratio, and with it their reaction, is zero either way)
+__global__ __launch_bounds__(QT) void seq_mof_terms_about(View v, long long first, const double* com7, double* ax_, double* ay_, double* az_,
+                                                          double* rx, double* ry, double* rz, double* mr) {
 #pragma clang fp contract(off)
-    const long long i = (long long)blockIdx.x * QT + threadIdx.x;
+    const long long i = first + (long long)blockIdx.x * QT + threadIdx.x;
     if (i >= v.n) return;
     Part p;
     p.x = v.x[i]; p.y = v.y[i]; p.z = v.z[i]; p.vx = v.vx[i]; p.vy = v.vy[i]; p.vz = v.vz[i]; p.m = v.m[i];
@@ -262,8 +296,10 @@ __global__ __launch_bounds__(QT) void seq_mof_bary_terms(View v, const double* c
 // down; at i == j the body gains its own force, and it loses massratio_i a_i for every i >= j (Jacobi:
 // i >= 1) or for every i (barycentric); a zero mass ratio subtracts nothing.  One thread per body j;
 // the reactions of a tile of bodies i are staged in LDS and read by broadcast.
+// nsrc: only bodies [0, nsrc) react (those behind are massless); a body at or behind nsrc gains its own force first -- the
+// reference reaches it before any body that reacts.
 template <bool JACOBI>
-__global__ __launch_bounds__(QT) void seq_mof_apply(View v, const double* ax_, const double* ay_, const double* az_,
+__global__ __launch_bounds__(QT) void seq_mof_apply(View v, long long nsrc, const double* ax_, const double* ay_, const double* az_,
                                                     const double* rx, const double* ry, const double* rz, const double* mr) {
 #pragma clang fp contract(off)
     __shared__ double r[4][QT];
@@ -273,13 +309,14 @@ __global__ __launch_bounds__(QT) void seq_mof_apply(View v, const double* ax_, c
     double acx = 0., acy = 0., acz = 0., ox = 0., oy = 0., oz = 0.;
     if (live) { acx = v.ax[j]; acy = v.ay[j]; acz = v.az[j]; ox = ax_[j]; oy = ay_[j]; oz = az_[j]; }
     const long long lowest = JACOBI ? (j > 1 ? j : 1) : 0;
-    const long long last_tile = (v.n - 1) / QT, first_tile = JACOBI ? (long long)blockIdx.x : 0;
+    const long long last_tile = (nsrc - 1) / QT, first_tile = JACOBI ? (long long)blockIdx.x : 0;
+    if (live && j >= nsrc) { acx += ox; acy += oy; acz += oz; }
     for (long long t = last_tile; t >= first_tile; t--) {
         const long long i0 = t * QT, i = i0 + tid;
-        const bool have = i < v.n;
+        const bool have = i < nsrc;
         r[0][tid] = have ? rx[i] : 0.; r[1][tid] = have ? ry[i] : 0.; r[2][tid] = have ? rz[i] : 0.; r[3][tid] = have ? mr[i] : 0.;
         __syncthreads();
-        const int cnt = (int)((v.n - i0) < QT ? (v.n - i0) : QT);
+        const int cnt = (int)((nsrc - i0) < QT ? (nsrc - i0) : QT);
         if (t > (long long)blockIdx.x) {
             // every body of the tile lies behind every body of this workgroup
             for (int k = cnt - 1; k >= 0; k--)
@@ -298,35 +335,43 @@ __global__ __launch_bounds__(QT) void seq_mof_apply(View v, const double* ax_, c
 }
 
 // ------------------------------------------------------------------ host driver
-// ws: the workspace of the prefix-sum passes (scan_workspace_doubles(n) doubles); n <= REBXAMD_SEQ_MAX_BODIES.
-hipError_t launch_seq_op(const View& v, const DevOp& op, double G, double* ws, unsigned* status, hipStream_t st) {
+// ws: the workspace of the prefix-sum passes (scan_workspace_doubles(v.n) doubles).  nseq: the bodies the chains walk -- v.n, or the
+// index behind the last massive body when massless bodies follow it; nseq <= REBXAMD_SEQ_MAX_BODIES.
+hipError_t launch_seq_op(const View& v, const DevOp& op, double G, double* ws, unsigned* status, hipStream_t st, long long nseq) {
     const long long n = v.n;
     if (n <= 0) return hipSuccess;
+    if (nseq > n || nseq < 1) nseq = n;
     const long long ns = (n + 1) & ~1LL;
     double* c0 = ws; double* c1 = c0 + ns; double* c2 = c1 + ns;
     double* c3 = c2 + ns; double* c4 = c3 + ns; double* c5 = c4 + ns;
     double* c6 = c5 + ns; double* c7 = c6 + ns; double* c8 = c7 + ns; double* c9 = c8 + ns;
     long long* cidx = reinterpret_cast<long long*>(c9 + ns);
-    double* small = reinterpret_cast<double*>(cidx + ns);       // 16 doubles of results of the one-workgroup kernels
-    const dim3 g((unsigned)((n + QT - 1) / QT)), one(1), b(QT);
+    double* small = reinterpret_cast<double*>(cidx + ns);       // 32 doubles of results of the one-workgroup kernels
+    View head = v;
+    head.n = nseq;
+    const long long ntail = n - nseq;
+    const dim3 g((unsigned)((n + QT - 1) / QT)), gh((unsigned)((nseq + QT - 1) / QT)), gt((unsigned)((ntail + QT - 1) / QT)), one(1), b(QT);
     if (op.kind == REBXAMD_OP_GR) {
         long long* count = reinterpret_cast<long long*>(small);
         double* mtot = small + 1;
-        hipLaunchKernelGGL(seq_compact, one, b, 0, st, v, c6, c7, c8, c9, cidx, count);
+        double* sums10 = small + 2;
+        hipLaunchKernelGGL(seq_compact, one, b, 0, st, head, c6, c7, c8, c9, cidx, count);
         hipLaunchKernelGGL(seq_newton, g, b, 0, st, v, G, (const double*)c6, (const double*)c7, (const double*)c8, (const double*)c9,
                            (const long long*)cidx, (const long long*)count, c0, c1, c2);
-        hipLaunchKernelGGL(seq_gr_forward, one, b, 0, st, v, op, G, (const double*)c0, (const double*)c1, (const double*)c2, c3, c4, c5, mtot, status);
-        hipLaunchKernelGGL(seq_gr_reverse, one, b, 0, st, v, (const double*)c3, (const double*)c4, (const double*)c5, (const double*)mtot);
+        hipLaunchKernelGGL(seq_gr_forward, one, b, 0, st, head, op, G, (const double*)c0, (const double*)c1, (const double*)c2, c3, c4, c5, mtot, status, sums10);
+        if (ntail > 0) hipLaunchKernelGGL(seq_gr_tail, gt, b, 0, st, v, op, G, nseq, (const double*)c0, (const double*)c1, (const double*)c2, (const double*)sums10, status);
+        hipLaunchKernelGGL(seq_gr_reverse, one, b, 0, st, head, (const double*)c3, (const double*)c4, (const double*)c5, (const double*)mtot);
         return hipGetLastError();
     }
     const bool jacobi = op.iarg == REBX_COORDINATES_JACOBI;
-    hipLaunchKernelGGL(seq_mof_com, one, b, 0, st, v, jacobi ? 1 : 0, small, c0, c1, c2, c3, c4, c5, c6);
+    hipLaunchKernelGGL(seq_mof_com, one, b, 0, st, head, jacobi ? 1 : 0, ntail, small, c0, c1, c2, c3, c4, c5, c6);
     if (jacobi) {
-        hipLaunchKernelGGL(seq_mof_apply<true>, g, b, 0, st, v, (const double*)c0, (const double*)c1, (const double*)c2,
+        if (ntail > 0) hipLaunchKernelGGL(seq_mof_terms_about, gt, b, 0, st, v, nseq, (const double*)small, c0, c1, c2, c3, c4, c5, c6);
+        hipLaunchKernelGGL(seq_mof_apply<true>, g, b, 0, st, v, nseq, (const double*)c0, (const double*)c1, (const double*)c2,
                            (const double*)c3, (const double*)c4, (const double*)c5, (const double*)c6);
     } else {
-        hipLaunchKernelGGL(seq_mof_bary_terms, g, b, 0, st, v, (const double*)small, c0, c1, c2, c3, c4, c5, c6);
-        hipLaunchKernelGGL(seq_mof_apply<false>, g, b, 0, st, v, (const double*)c0, (const double*)c1, (const double*)c2,
+        hipLaunchKernelGGL(seq_mof_terms_about, g, b, 0, st, v, 0LL, (const double*)small, c0, c1, c2, c3, c4, c5, c6);
+        hipLaunchKernelGGL(seq_mof_apply<false>, g, b, 0, st, v, nseq, (const double*)c0, (const double*)c1, (const double*)c2,
                            (const double*)c3, (const double*)c4, (const double*)c5, (const double*)c6);
     }
     return hipGetLastError();

@@ -235,7 +235,11 @@ def scan_check(ctx, cols, pp, forces, mode, scans=False, **kw):
     finally:
         ctx.sequential_exact(True)
     assert np.isfinite(got).all()
-    if mode == EXACT and not scans and got.shape[1] <= SEQ_MAX and all(is_prefix_sum_force(f) for f in forces):
+    massive = np.nonzero(cols["m"])[0]
+    chain = kw.get("n_head") or (int(massive[-1]) + 1 if len(massive) else 1)      # (massless bodies behind the last massive one ride free)
+    if kw.get("tail_massless") is False:
+        chain = got.shape[1]
+    if mode == EXACT and not scans and chain <= SEQ_MAX and all(is_prefix_sum_force(f) for f in forces):
         u = ulp_diff(got, ref).max(axis=0)
         assert u.max() == 0, "reference-order arithmetic: %d bodies differ from the checker, first %d" % (int((u > 0).sum()), int(np.nonzero(u)[0][0]))
         return got, ref
@@ -287,15 +291,33 @@ def test_reference_order_route_with_incoming_accelerations_and_odd_sizes(ctx, fo
 
 
 def test_reference_order_route_stops_at_its_size_limit(ctx):
-    """Above SEQ_MAX bodies reference-order arithmetic uses the prefix sums (derived bound); at the limit it
-    still carries the checker's bits."""
+    """With the last massive body above index SEQ_MAX - 1 reference-order arithmetic uses the prefix sums (derived
+    bound); at the limit it still carries the checker's bits."""
     force = ("modify_orbits_forces", {})
     for n, bits in ((SEQ_MAX, True), (SEQ_MAX + 1, False)):
         cols, pp, _ = synthetic.disk(n, 2)
         rng = np.random.default_rng(n)
         cols["m"][rng.choice(np.arange(3, n), size=40, replace=False)] = 1e-6
+        cols["m"][n - 1] = 1e-6                 # (the chains reach up to the last massive body)
         got, ref = scan_check(ctx, zero_acc(cols), pp, [force], EXACT)
         assert (ulp_diff(got, ref).max() == 0) == bits
+
+
+@pytest.mark.parametrize("force", SCAN_FORCES)
+def test_reference_order_route_with_massless_grains_behind_the_last_massive_body(ctx, force):
+    """Massive bodies scattered over a prefix (beyond the 64-body head of the fused path), then massless grains,
+    more of them than the chains' size limit: the chains cover the prefix, the grains are measured from the
+    final running sums, and every body carries the checker's bits.  A one-grain and a two-grain tail check
+    the count of re-roundings of the centre of mass; accelerations are already in the columns."""
+    for n, prefix, massive in ((SEQ_MAX + 3000, 700, 90), (1301, 1300, 1300), (1302, 1300, 200), (5000, 257, 257)):
+        cols, pp, _ = synthetic.disk(n, 2)
+        rng = np.random.default_rng(n)
+        cols["m"][rng.choice(np.arange(3, prefix - 1), size=massive - 4, replace=False)] = 10.0 ** rng.uniform(-9, -5, massive - 4)
+        cols["m"][prefix - 1] = 3e-7
+        cols["m"][prefix:] = 0.
+        synthetic.add_newtonian(cols, n_head=prefix)
+        got, ref = scan_check(ctx, cols, pp, [force], EXACT)
+        assert ulp_diff(got, ref).max() == 0
 
 
 def exact_value_check(ctx, cols, pp, force, mode, label, **kw):
