@@ -36,6 +36,33 @@ for label, n, planets, dust, scatter, kw in (("all-massive", 70, 2, 1e-9, False,
             u = ulp_diff(got, ref)
             print(label, n, "newton" if newton else "zero", force[0], force[1], "max ulp", int(u.max()), "bodies off", int((u.max(axis=0) > 0).sum()), flush=True)
             bad += int(u.max() > 0)
+# random prefixes of massive and massless bodies followed by massless grains: the chains stop at the last massive body
+rng = np.random.default_rng(11)
+for case in range(int(os.environ.get("SEQ_TAIL_CASES", "120"))):
+    prefix = int(rng.choice([66, 255, 256, 257, 300, 1025, 2500]))
+    tail = int(rng.choice([1, 2, 3, 255, 256, 1000, 20000, 70000]))
+    n = prefix + tail
+    cols, pp, _ = synthetic.disk(n, 2, seed=int(rng.integers(1, 100)))
+    massive = int(rng.integers(3, prefix - 3))
+    cols["m"][rng.choice(np.arange(3, prefix - 1), size=massive, replace=False)] = 10.0 ** rng.uniform(-10, -4, massive)
+    cols["m"][prefix - 1] = 10.0 ** rng.uniform(-10, -4)
+    cols["m"][prefix:] = 0.
+    if rng.random() < 0.6:
+        synthetic.add_newtonian(cols, n_head=prefix)
+    else:
+        cols = zero_acc(cols)
+    k = int(rng.integers(0, len(SCAN_FORCES)))
+    stack = [SCAN_FORCES[k]]
+    if rng.random() < 0.4:
+        stack.append(SCAN_FORCES[2 if k < 2 else 0])        # gr and a centre-of-mass drag one after the other
+    ref = run_oracle(cols, pp, stack)
+    got, _ = run_device(ctx, cols, pp, stack, 1.0, 1)
+    u = ulp_diff(got, ref)
+    if u.max() > 0:
+        bad += 1
+        print("tail case", case, "prefix", prefix, "tail", tail, "massive", massive, [f[0] + str(f[1]) for f in stack], "max ulp", int(u.max()),
+              "bodies off", int((u.max(axis=0) > 0).sum()), "first", int(np.nonzero(u.max(axis=0))[0][0]), flush=True)
+print("tail cases done, off so far:", bad, flush=True)
 for n in (65536,):
     cols, pp, _ = synthetic.disk(n, 2, dust_mass=1e-9)
     for force in SCAN_FORCES:
