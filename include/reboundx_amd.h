@@ -308,7 +308,9 @@ enum rebxamd_status {
 
 enum rebxamd_mode {
     REBXAMD_MODE_FAST = 0,          /* shared reciprocals, FMA contraction allowed; <=1e-12 relative */
-    REBXAMD_MODE_EXACT = 1          /* reference expression order, no contraction */
+    REBXAMD_MODE_EXACT = 1          /* reference expression order, no contraction: the bits of a CPU build of the reference without FMA
+                                     * contraction on every body but those that collect the pushes of many others (sources, primaries:
+                                     * parallel sums) -- central_force apart, whose pow() is the device library's (<= 4 ulp from glibc's) */
 };
 
 /* gr and Jacobi/barycentric modify_orbits_forces accumulate body by body in the reference (src/gr.c:80-167 through
