@@ -29,6 +29,7 @@ struct rebxamd_ctx {
     const unsigned* gf_stop = nullptr;  // caller's stop word for rebxamd_grfull_sweep (rebxamd_grfull_stop_word)
     double* chunk_sums = nullptr;       // second-stage scratch of the back-reaction reduction
     void* hpin = nullptr;               // 512 B of pinned host memory: small results come back through it (no staging copy inside the runtime)
+    unsigned* hpin_dev = nullptr;       // the same memory as the device addresses it
     double* whead = nullptr;            // Jacobi state of a head of several massive bodies between Wisdom-Holman steps (8 x 64 doubles)
     double* star = nullptr;             // 6 x 16 doubles: records of body 0 around Wisdom-Holman drifts (two alternate between steps, one for the leading
                                         // half drift; an open run: two more for the leading drifts of alternate steps, one for the closing half drift)
@@ -122,6 +123,7 @@ extern "C" int rebxamd_create(int device, rebxamd_ctx** out) {
         hipMalloc((void**)&ctx->star, 96 * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&ctx->whead, 3 * 8 * REBXAMD_MAX_HEAD * sizeof(double)) != hipSuccess ||     // Jacobi state + two copies of the state between kick and drift
         hipHostMalloc(&ctx->hpin, 512, hipHostMallocDefault) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&ctx->hpin_dev, ctx->hpin, 0) != hipSuccess ||
         hipMalloc((void**)&ctx->chunk_sums, sizeof(double) * REBXAMD_MAX_OPS * 64 * 3) != hipSuccess ||
         hipMemset(ctx->hc, 0, 4 * sizeof(HeadConsts)) != hipSuccess ||
         hipMemset(ctx->status, 0, sizeof(unsigned)) != hipSuccess) {
@@ -250,12 +252,18 @@ extern "C" int rebxamd_reset_accelerations(rebxamd_ctx* ctx, const rebxamd_view*
     return REBXAMD_OK;
 }
 
+// the warning word handed to the host's pinned memory and cleared, in one launch (a copy and a fill are two commands)
+__global__ void hand_over_warnings(unsigned* status, unsigned* host_word) {
+    host_word[0] = status[0];
+    status[0] = 0u;
+}
+
 extern "C" int rebxamd_fetch_warnings(rebxamd_ctx* ctx, uint32_t* bits, void* stream) {
     if (!ctx || !bits) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_fetch_warnings: bad argument");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemcpyAsync(ctx->hpin, ctx->status, sizeof(unsigned), hipMemcpyDeviceToHost, st));      // (pinned: one DMA)
-    HIP_TRY(hipMemsetAsync(ctx->status, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(hand_over_warnings, dim3(1), dim3(1), 0, st, ctx->status, ctx->hpin_dev);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
     unsigned h = 0;
     memcpy(&h, ctx->hpin, sizeof(h));

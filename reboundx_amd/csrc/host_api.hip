@@ -102,6 +102,7 @@ inline double as_column_value(double v) { return v == v ? v : __builtin_bit_cast
 struct Bridge {
     rebxamd_ctx* ctx = nullptr;
     int mode = REBXAMD_MODE_FAST;
+    bool in_place = true;                   // small systems are evaluated in the pinned host columns (rebxamd_set_in_place)
     unsigned long long generation = 1;      // bumped by every API call that can change a parameter list
     // staging
     size_t cap = 0;
@@ -109,6 +110,7 @@ struct Bridge {
     double* d_slab = nullptr;
     double* h_dyn[H_NDYN] = {};             // pinned host columns
     double* d_dyn[H_NDYN] = {};
+    double* hd_dyn[H_NDYN] = {};            // the pinned host columns as the device addresses them
     double* h_par[P_NPAR] = {};             // pageable host columns (rebuilt rarely)
     double* d_par[P_NPAR] = {};
     bool par_used[P_NPAR] = {};             // column has at least one value set
@@ -154,7 +156,7 @@ void release_buffers(Bridge* b) {
     if (b->h_slab) (void)hipHostFree(b->h_slab);
     if (b->d_slab) (void)hipFree(b->d_slab);
     b->h_slab = b->d_slab = nullptr;
-    for (int k = 0; k < H_NDYN; k++) b->h_dyn[k] = b->d_dyn[k] = nullptr;
+    for (int k = 0; k < H_NDYN; k++) b->h_dyn[k] = b->d_dyn[k] = b->hd_dyn[k] = nullptr;
     for (int k = 0; k < P_NPAR; k++) {
         free(b->h_par[k]);
         if (b->d_par[k]) (void)hipFree(b->d_par[k]);
@@ -757,6 +759,9 @@ extern "C" const double* rebxamd_get_param_column(struct rebx_extras* rebx, cons
 extern "C" void rebxamd_set_mode(struct rebx_extras* rebx, int mode) {
     if (Bridge* b = bridge_of(rebx, true)) b->mode = mode ? REBXAMD_MODE_EXACT : REBXAMD_MODE_FAST;
 }
+extern "C" void rebxamd_set_in_place(struct rebx_extras* rebx, int on) {
+    if (Bridge* b = bridge_of(rebx, true)) b->in_place = on != 0;
+}
 extern "C" void rebxamd_last_timings(struct rebx_extras* rebx, double out_ms[4]) {
     Bridge* b = bridge_of(rebx, false);
     for (int k = 0; k < 4; k++) out_ms[k] = b ? b->timings[k] : 0.;
@@ -785,7 +790,9 @@ bool ensure_capacity(struct rebx_extras* rebx, Bridge* b, size_t n) {
         release_buffers(b);
         return false;
     }
-    for (int k = 0; k < H_NDYN; k++) { b->h_dyn[k] = b->h_slab + k * cap; b->d_dyn[k] = b->d_slab + k * cap; }
+    double* mapped = nullptr;
+    if (hipHostGetDevicePointer((void**)&mapped, b->h_slab, 0) != hipSuccess) mapped = nullptr;
+    for (int k = 0; k < H_NDYN; k++) { b->h_dyn[k] = b->h_slab + k * cap; b->d_dyn[k] = b->d_slab + k * cap; b->hd_dyn[k] = mapped ? mapped + k * cap : nullptr; }
     for (int k = 0; k < P_NPAR; k++) {
         b->h_par[k] = (double*)malloc(cap * sizeof(double));
         if (!b->h_par[k] || hipMalloc((void**)&b->d_par[k], cap * sizeof(double)) != hipSuccess) {
@@ -959,9 +966,12 @@ bool ops_of_force(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* 
 // zero (the caller adds what comes back), which saves their 24 bytes per particle on the way up.
 // with_vel = false: the velocities stay behind too (the device columns keep whatever they held:
 // for callers whose kernels do not read them).
+// in_place (small systems only): nothing is uploaded -- the view addresses the pinned host columns themselves, which
+// the kernels then read and update over the link (a few round trips instead of two copy commands and their latencies).
 bool stage_in(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* b, const struct reb_particle* particles, const int N,
-              rebxamd_view& v, double t[3], const bool with_acc = true, const bool with_vel = true) {
+              rebxamd_view& v, double t[3], const bool with_acc = true, const bool with_vel = true, bool in_place = false) {
     if (!ensure_capacity(rebx, b, (size_t)N)) return false;
+    in_place = in_place && small_system(b, N) && b->hd_dyn[0] != nullptr;
     t[0] = now_ms();
     double* const* h = b->h_dyn;
     hipStream_t st = nullptr;
@@ -1006,8 +1016,13 @@ bool stage_in(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* b, c
             mass_moved |= chunk_mass[k];
         }
         pack_ms += now_ms() - tp;
-        if (small_system(b, N)) ok = hipMemcpyAsync(b->d_slab, b->h_slab, H_NDYN * b->cap * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess;
-        else for (int k = 0; k < H_NDYN && ok; k++) {
+        if (small_system(b, N)) {
+            // (one block.)  In place only behind a short massive prefix, where one pass reads every column once; the passes
+            // of the other mass layouts read them several times and are better served by device memory
+            in_place = in_place && last_massive + 1 <= REBXAMD_MAX_HEAD;
+            if (in_place) __builtin_ia32_sfence();      // (the streaming stores above must have left this core before a kernel reads them)
+            else ok = hipMemcpyAsync(b->d_slab, b->h_slab, H_NDYN * b->cap * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess;
+        } else for (int k = 0; k < H_NDYN && ok; k++) {
             if (k == H_M && !mass_moved) continue;
             if (k >= H_AX && !with_acc) continue;
             if (k >= H_VX && k <= H_VZ && !with_vel) continue;
@@ -1016,7 +1031,7 @@ bool stage_in(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* b, c
     }
     if (!with_acc && !small_system(b, N))
         for (int k = H_AX; k <= H_AZ && ok; k++) ok = hipMemsetAsync(b->d_dyn[k], 0, (size_t)N * sizeof(double), st) == hipSuccess;
-    b->mass_synced = ok ? (size_t)N : 0;
+    b->mass_synced = (ok && !in_place) ? (size_t)N : 0;
     const bool rebuild = b->built_generation != b->generation || b->built_n != N || b->built_checksum != sum;
     const double tf = now_ms();
     bool changed[P_NPAR];
@@ -1044,10 +1059,11 @@ bool stage_in(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* b, c
     v.n_head = last_massive + 1 < 1 ? 1 : last_massive + 1;
     v.tail_massless = 1;
     v.G = sim->G;
-    v.x = b->d_dyn[H_X]; v.y = b->d_dyn[H_Y]; v.z = b->d_dyn[H_Z];
-    v.vx = b->d_dyn[H_VX]; v.vy = b->d_dyn[H_VY]; v.vz = b->d_dyn[H_VZ];
-    v.m = b->d_dyn[H_M];
-    v.ax = b->d_dyn[H_AX]; v.ay = b->d_dyn[H_AY]; v.az = b->d_dyn[H_AZ];
+    double* const* cols = in_place ? b->hd_dyn : b->d_dyn;
+    v.x = cols[H_X]; v.y = cols[H_Y]; v.z = cols[H_Z];
+    v.vx = cols[H_VX]; v.vy = cols[H_VY]; v.vz = cols[H_VZ];
+    v.m = cols[H_M];
+    v.ax = cols[H_AX]; v.ay = cols[H_AY]; v.az = cols[H_AZ];
     v.beta = b->par_used[P_BETA] ? b->d_par[P_BETA] : nullptr;
     v.R_tides = b->par_used[P_RT] ? b->d_par[P_RT] : nullptr;
     v.k1 = b->par_used[P_K1] ? b->d_par[P_K1] : nullptr;
@@ -1055,6 +1071,13 @@ bool stage_in(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* b, c
     v.tau_e = b->par_used[P_TE] ? b->d_par[P_TE] : nullptr;
     v.tau_inc = b->par_used[P_TI] ? b->d_par[P_TI] : nullptr;
     return true;
+}
+
+// whether a call on N particles should try the in-place route (stage_in has the last word: it knows the masses)
+bool in_place_wanted(const Bridge* b, int N) {
+    static const bool allowed = [] { const char* e = getenv("REBXAMD_HOOK_IN_PLACE"); return !(e && e[0] == '0'); }();
+    static const int limit = [] { const char* e = getenv("REBXAMD_HOOK_IN_PLACE_LIMIT"); return e ? atoi(e) : 16384; }();
+    return allowed && b->in_place && N <= limit && small_system(b, N);
 }
 
 void report_warnings(struct reb_simulation* sim, uint32_t bits) {
@@ -1084,7 +1107,11 @@ void run_builtin(struct reb_simulation* sim, struct rebx_extras* rebx, const std
         reads_vel |= pf.builtin->type != REBX_FORCE_POS;
     }
     const bool delta = b->mode == REBXAMD_MODE_FAST && !reads_acc && large;
-    if (!stage_in(sim, rebx, b, particles, N, v, t, !delta, reads_vel || !large)) return;
+    // Small systems without gr_full (whose all-pairs passes read every column many times) are evaluated where they are
+    // packed: in the pinned host columns.  REBXAMD_HOOK_IN_PLACE=0 / rebxamd_set_in_place(rebx, 0) go back to one copy per direction.
+    const bool in_place = in_place_wanted(b, N) && !reads_acc;
+    if (!stage_in(sim, rebx, b, particles, N, v, t, !delta, reads_vel || !large, in_place)) return;
+    const bool evaluated_in_place = in_place && v.x == b->hd_dyn[H_X];
 
     // ---- ops (effect parameters are read on every call: they are a handful of list walks)
     std::vector<rebxamd_op> ops;
@@ -1109,7 +1136,7 @@ void run_builtin(struct reb_simulation* sim, struct rebx_extras* rebx, const std
     static_assert(H_AY == H_AX + 1 && H_AZ == H_AX + 2, "the acceleration columns are neighbours in the slab");
     uint32_t bits = 0;
     if (small_system(b, N)) {
-        ok = hipMemcpyAsync(b->h_dyn[H_AX], b->d_dyn[H_AX], (2 * b->cap + (size_t)N) * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess;
+        if (!evaluated_in_place) ok = hipMemcpyAsync(b->h_dyn[H_AX], b->d_dyn[H_AX], (2 * b->cap + (size_t)N) * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess;
         ok = ok && rebxamd_fetch_warnings(b->ctx, &bits, st) == REBXAMD_OK;     // synchronises the stream
         if (!ok) { rebx_error(rebx, "REBOUNDx (MI355X) Error: device to host copy failed.\n"); return; }
         for (int i = 0; i < N; i++) { particles[i].ax = h[H_AX][i]; particles[i].ay = h[H_AY][i]; particles[i].az = h[H_AZ][i]; }
@@ -1451,7 +1478,10 @@ extern "C" void rebx_integrate_force(struct reb_simulation* const sim, struct re
     Bridge* b = bridge_of(rebx, true);
     rebxamd_view v;
     double t[3];
-    if (!stage_in(sim, rebx, b, sim->particles, N, v, t)) return;
+    // (implicit midpoint makes a pass per round over the columns: it keeps them in device memory; gr_full reads them all the time)
+    const bool in_place = in_place_wanted(b, N) && integrator != REBXAMD_INTEGRATOR_IMPLICIT_MIDPOINT && force->update_accelerations != rebx_gr_full;
+    if (!stage_in(sim, rebx, b, sim->particles, N, v, t, true, true, in_place)) return;
+    const bool evaluated_in_place = in_place && v.x == b->hd_dyn[H_X];
     std::vector<rebxamd_op> ops;
     const Pending pf{force, bi};
     if (!ops_of_force(sim, rebx, b, pf, ops)) return;
@@ -1465,11 +1495,11 @@ extern "C" void rebx_integrate_force(struct reb_simulation* const sim, struct re
         reb_error(sim, str);
         return;
     }
-    bool ok = hipStreamSynchronize(st) == hipSuccess;
+    bool ok = evaluated_in_place || hipStreamSynchronize(st) == hipSuccess;
     const double t3 = now_ms();
     const size_t bytes = (size_t)N * sizeof(double);
     static const int back[6] = {H_VX, H_VY, H_VZ, H_AX, H_AY, H_AZ};
-    for (int k = 0; k < 6 && ok; k++) ok = hipMemcpyAsync(b->h_dyn[back[k]], b->d_dyn[back[k]], bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
+    for (int k = 0; k < 6 && ok && !evaluated_in_place; k++) ok = hipMemcpyAsync(b->h_dyn[back[k]], b->d_dyn[back[k]], bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
     uint32_t bits = 0;
     ok = ok && rebxamd_fetch_warnings(b->ctx, &bits, st) == REBXAMD_OK;
     if (!ok) { rebx_error(rebx, "REBOUNDx (MI355X) Error: device to host copy failed.\n"); return; }

@@ -382,6 +382,10 @@ class Extras(Structure):
     def set_mode(self, mode):
         lib.rebxamd_set_mode(byref(self), 1 if mode in (1, "exact") else 0)
 
+    def set_in_place(self, on=True):
+        """Small systems: evaluate in the pinned host columns (default) or through one copy per direction."""
+        lib.rebxamd_set_in_place(byref(self), 1 if on else 0)
+
     def last_timings(self):
         out = (c_double * 4)()
         lib.rebxamd_last_timings(byref(self), out)
@@ -511,6 +515,8 @@ lib.rebx_rad_calc_particle_radius.argtypes = [c_double] * 7
 lib.rebx_rad_calc_particle_radius.restype = c_double
 lib.rebxamd_invalidate_params.argtypes = [_P(Extras)]
 lib.rebxamd_set_mode.argtypes = [_P(Extras), c_int]
+lib.rebxamd_set_in_place.argtypes = [_P(Extras), c_int]
+lib.rebxamd_set_in_place.restype = None
 lib.rebxamd_set_param_column.argtypes = [_P(Extras), c_char_p, _P(c_double), c_int]
 lib.rebxamd_set_param_column.restype = c_int
 lib.rebxamd_get_param_column.argtypes = [_P(Extras), c_char_p, _P(c_int)]
@@ -562,6 +568,6 @@ PLUGIN_API_SYMBOLS = (
     "rebx_additional_forces", "rebx_reset_accelerations", "rebx_gr", "rebx_gr_full", "rebx_gr_potential",
     "rebx_radiation_forces", "rebx_modify_orbits_forces", "rebx_tides_precession", "rebx_central_force",
     "rebx_gravitational_harmonics", "rebx_ephemeris_forces", "rebx_rad_calc_beta", "rebx_rad_calc_particle_radius", "rebx_central_force_Acentral",
-    "rebxamd_invalidate_params", "rebxamd_set_mode", "rebxamd_last_timings", "rebxamd_set_param_column", "rebxamd_get_param_column",
+    "rebxamd_invalidate_params", "rebxamd_set_mode", "rebxamd_set_in_place", "rebxamd_last_timings", "rebxamd_set_param_column", "rebxamd_get_param_column",
     "rebx_build_str", "rebx_version_str", "rebx_githash_str",
 )

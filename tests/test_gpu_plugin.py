@@ -620,12 +620,14 @@ def test_parameter_columns_feed_the_operators_too():
     assert np.array_equal(states[0].view(np.uint64), states[1].view(np.uint64))
 
 
+@pytest.mark.parametrize("in_place", [True, False], ids=["in-place", "copies"])
 @pytest.mark.parametrize("integrator", ["euler", "rk2", "rk4", "implicit_midpoint"])
-def test_integrate_force_operator_with_a_builtin_force_runs_on_the_device(integrator):
+def test_integrate_force_operator_with_a_builtin_force_runs_on_the_device(integrator, in_place):
     """The reference's IntegrateForce setup (ipython_examples/IntegrateForce.ipynb: a
     velocity-dependent force applied as an operator): built-in force + integrate_force operator,
     stepped once through the operator's step function.  Reference-order arithmetic: the explicit
-    schemes are bitwise equal to the checker's restatement."""
+    schemes are bitwise equal to the checker's restatement -- evaluated in the pinned host columns
+    (the default for a system this small) and through one copy per direction alike."""
     from reboundx_amd.extras import REBX_INTEGRATORS
     n = 1500
     cols, pp, _ = synthetic.disk(n, 2)
@@ -633,6 +635,7 @@ def test_integrate_force_operator_with_a_builtin_force_runs_on_the_device(integr
     sim = sim_from(cols)
     rebx = Extras(sim)
     rebx.set_mode("exact")
+    rebx.set_in_place(in_place)
     force = rebx.load_force("modify_orbits_forces")
     op = rebx.load_operator("integrate_force")
     op.params["force"] = force
@@ -863,3 +866,59 @@ def test_reference_order_arithmetic_through_the_hook_on_a_scattered_mass_layout(
             upd = np.abs(want - base).max(axis=0)
             assert (np.abs(got - want).max(axis=0) <= TOL * np.maximum(upd, np.abs(want).max(axis=0) * 1e-3)).all()
     sim.free_particle_params()
+
+
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_small_systems_evaluated_in_the_pinned_host_columns_equal_the_copied_route_bit_for_bit(mode):
+    """The hook evaluates a small system where it packs it (kernels reading and updating pinned host memory over the
+    link) or, switched off, through one copy per direction: the same kernels on the same numbers, so the same bits --
+    over several calls in a row with the accelerations carried along, after a parameter and a position change, and
+    when a grain beyond the 64-body head gains mass (the route then falls back to the copies by itself)."""
+    n = 3000
+    cols, pp, _ = synthetic.disk(n, 2)
+    cols = gravity(cols)
+
+    def build():
+        sim = sim_from(cols)
+        rebx = Extras(sim)
+        rebx.set_mode(mode)
+        for name, ep in (("radiation_forces", {"c": C}), ("gr", {"c": C}), ("gravitational_harmonics", {}), ("modify_orbits_forces", {})):
+            f = rebx.load_force(name)
+            for k, v in ep.items():
+                f.params[k] = v
+            rebx.add_force(f)
+        ps = sim.particles
+        ps[0].params["J2"], ps[0].params["J4"], ps[0].params["R_eq"] = 1e-3, -2e-5, 2e-3
+        ps[0].params["radiation_source"] = 1
+        rebx.set_param_column("beta", pp["beta"])
+        rebx.set_param_column("tau_a", pp["tau_a"])
+        rebx.set_param_column("tau_e", pp["tau_e"])
+        return sim, rebx
+
+    (sim_a, rebx_a), (sim_b, rebx_b) = build(), build()
+    rebx_b.set_in_place(False)
+    want = oracle.Sim(cols)
+    stack = [("modify_orbits_forces", {}), ("gravitational_harmonics", {}), ("gr", {"c": C}), ("radiation_forces", {"c": C})]      # executed in reverse add order
+    par = {"beta": pp["beta"], "tau_a": pp["tau_a"], "tau_e": pp["tau_e"], "J2": pp["J2"] * 0 + np.nan, "J4": pp["J4"] * 0 + np.nan, "R_eq": pp["R_eq"] * 0 + np.nan}
+    par["J2"][0], par["J4"][0], par["R_eq"][0] = 1e-3, -2e-5, 2e-3
+    oracle.apply_forces(want, stack, par)
+    for step in range(5):
+        if step == 2:
+            for sim in (sim_a, sim_b):
+                sim.particles[7].x *= 1.01
+                sim.particles[0].params["J2"] = 2e-3
+        if step == 4:
+            for sim in (sim_a, sim_b):
+                sim.particles[n - 5].m = 1e-9
+        sim_a.call_additional_forces()
+        sim_b.call_additional_forces()
+        got_a, got_b = acc_of(sim_a.particles, n), acc_of(sim_b.particles, n)
+        assert np.isfinite(got_a).all()
+        assert ulp_diff(got_a, got_b).max() == 0, step
+        if step == 0:
+            if mode == "exact":
+                assert ulp_diff(got_a, np.array(want.acc)).max() == 0
+            else:
+                assert rel_err(got_a, np.array(want.acc)).max() <= TOL
+    for sim in (sim_a, sim_b):
+        sim.free_particle_params()
