@@ -1526,7 +1526,7 @@ double host_potential(struct rebx_extras* rebx, PotentialKind kind, double c) {
     Bridge* b = bridge_of(rebx, true);
     rebxamd_view v;
     double t[3];
-    if (!stage_in(sim, rebx, b, sim->particles, N, v, t)) return 0.;
+    if (!stage_in(sim, rebx, b, sim->particles, N, v, t, true, true, in_place_wanted(b, N))) return 0.;
     std::vector<rebxamd_op> ops;
     auto add = [&](int k, int src, double a, double bb) {
         rebxamd_op o; o.kind = k; o.src = src; o.iarg = 0; o.reserved = 0; o.a = a; o.b = bb; ops.push_back(o);
@@ -1583,7 +1583,7 @@ extern "C" double rebx_gr_hamiltonian(struct rebx_extras* const rebx, const stru
     Bridge* b = bridge_of(rebx, true);
     rebxamd_view v;
     double t[3];
-    if (!stage_in(sim, rebx, b, sim->particles, N, v, t)) return 0.;
+    if (!stage_in(sim, rebx, b, sim->particles, N, v, t, true, true, in_place_wanted(b, N))) return 0.;
     double H = 0.;
     if (rebxamd_gr_hamiltonian(b->ctx, &v, *c, &H, nullptr) != REBXAMD_OK) {
         char str[400];
@@ -1597,11 +1597,12 @@ extern "C" double rebx_gr_hamiltonian(struct rebx_extras* const rebx, const stru
 // ------------------------------------------------------------------ operators that change the state
 namespace {
 // device -> host for the listed dynamic columns, then columns -> array-of-structs
-bool state_back(struct rebx_extras* rebx, Bridge* b, struct reb_particle* ps, int N, bool with_mass) {
+// (in_place: the kernels updated the pinned host columns themselves; only the wait is left)
+bool state_back(struct rebx_extras* rebx, Bridge* b, struct reb_particle* ps, int N, bool with_mass, bool in_place) {
     hipStream_t st = nullptr;
     const size_t bytes = (size_t)N * sizeof(double);
     bool ok = true;
-    for (int k = H_X; k <= (with_mass ? H_M : H_VZ) && ok; k++) ok = hipMemcpyAsync(b->h_dyn[k], b->d_dyn[k], bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
+    for (int k = H_X; k <= (with_mass ? H_M : H_VZ) && ok && !in_place; k++) ok = hipMemcpyAsync(b->h_dyn[k], b->d_dyn[k], bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
     ok = ok && hipStreamSynchronize(st) == hipSuccess;
     if (!ok) { rebx_error(rebx, "REBOUNDx (MI355X) Error: device to host copy failed.\n"); return false; }
     double* const* h = b->h_dyn;
@@ -1637,9 +1638,9 @@ extern "C" void rebx_modify_mass(struct reb_simulation* const sim, struct rebx_o
     Bridge* b = bridge_of(rebx, true);
     rebxamd_view v;
     double t[3];
-    if (!stage_in(sim, rebx, b, sim->particles, N, v, t)) return;
+    if (!stage_in(sim, rebx, b, sim->particles, N, v, t, true, true, in_place_wanted(b, N))) return;
     if (rebxamd_modify_mass(b->ctx, &v, column_or_nan(b, P_TM, N), dt, nullptr) != REBXAMD_OK) { report_device_error(sim, b, "Masses were not updated."); return; }
-    state_back(rebx, b, sim->particles, N, true);
+    state_back(rebx, b, sim->particles, N, true, v.x == b->hd_dyn[H_X]);
 }
 
 extern "C" void rebx_modify_orbits_direct(struct reb_simulation* const sim, struct rebx_operator* const op, const double dt) {   // src/modify_orbits_direct.c:121-132
@@ -1652,7 +1653,7 @@ extern "C" void rebx_modify_orbits_direct(struct reb_simulation* const sim, stru
     Bridge* b = bridge_of(rebx, true);
     rebxamd_view v;
     double t[3];
-    if (!stage_in(sim, rebx, b, sim->particles, N, v, t)) return;
+    if (!stage_in(sim, rebx, b, sim->particles, N, v, t, true, true, in_place_wanted(b, N))) return;
     if (coordinates == REBX_COORDINATES_PARTICLE && b->first_primary < 0) {
         reb_error(sim, "Coordinates set to REBX_COORDINATES_PARTICLE, but primary param was not found in any particle.  Need to set parameter.\n");
         return;
@@ -1666,7 +1667,7 @@ extern "C" void rebx_modify_orbits_direct(struct reb_simulation* const sim, stru
         report_device_error(sim, b, "Orbits were not updated.");
         return;
     }
-    state_back(rebx, b, sim->particles, N, false);
+    state_back(rebx, b, sim->particles, N, false, v.x == b->hd_dyn[H_X]);
 }
 
 // reference src/core.h:74, src/ephemeris_forces.c: needs the JPL ephemeris readers and their data files, which are not on this

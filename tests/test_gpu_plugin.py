@@ -587,7 +587,8 @@ def test_gr_and_jacobi_drag_with_massive_bodies_anywhere_through_the_hook():
 
 def test_parameter_columns_feed_the_operators_too():
     """tau_mass (modify_mass) and tau_a / tau_e / tau_omega (modify_orbits_direct) given as columns: the operators' step
-    functions must do what they do with the same values in the particles' lists."""
+    functions must do what they do with the same values in the particles' lists -- and the same through one copy per
+    direction as evaluated in the pinned host columns (the default at this size)."""
     n = 3000
     cols, pp, _ = synthetic.disk(n, 2)
     rng = np.random.default_rng(4)
@@ -595,14 +596,15 @@ def test_parameter_columns_feed_the_operators_too():
     tau_omega = np.where(rng.random(n) < 0.3, 100. * (1 + rng.random(n)), np.nan)
     given = {"tau_mass": tau_mass, "tau_a": pp["tau_a"], "tau_e": pp["tau_e"], "tau_omega": tau_omega}
     states = []
-    for how in ("lists", "columns"):
+    for how in ("lists", "columns", "columns, copied"):
         sim, arr, view = big_array_sim(cols)
         sim.integrator = 1
         sim.dt = 0.1
         rebx = Extras(sim)
+        rebx.set_in_place(how != "columns, copied")
         mm = rebx.load_operator("modify_mass")
         mod = rebx.load_operator("modify_orbits_direct")
-        if how == "columns":
+        if how != "lists":
             for k, v in given.items():
                 assert rebx.set_param_column(k, v)
         else:
@@ -618,6 +620,7 @@ def test_parameter_columns_feed_the_operators_too():
     start = np.array([cols[k] for k in ("x", "y", "z", "vx", "vy", "vz", "m")]).T
     assert np.abs(states[0] - start).max() > 1e-7
     assert np.array_equal(states[0].view(np.uint64), states[1].view(np.uint64))
+    assert np.array_equal(states[1].view(np.uint64), states[2].view(np.uint64))
 
 
 @pytest.mark.parametrize("in_place", [True, False], ids=["in-place", "copies"])

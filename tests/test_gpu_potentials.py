@@ -52,15 +52,18 @@ def test_each_potential_every_particle_massive(ctx, n):
         assert abs(g - w) <= 1e-12 * max(s, abs(w)), (g, w)
 
 
-def test_potentials_through_the_plugin_api():
+@pytest.mark.parametrize("in_place", [True, False], ids=["in-place", "copies"])
+def test_potentials_through_the_plugin_api(in_place):
     """reboundx/test/test_conservation.py's building blocks: rebx.<force>_potential() on a
-    simulation with parameters in the linked lists."""
+    simulation with parameters in the linked lists (the kernels reading the pinned host columns, the
+    default for a small system, or device copies of them)."""
     from reboundx_amd.extras import Extras, Simulation
     cols = synthetic.twoplanets()
     sim = Simulation()
     for i in range(3):
         sim.add(m=cols["m"][i], x=cols["x"][i], y=cols["y"][i], z=cols["z"][i], vx=cols["vx"][i], vy=cols["vy"][i], vz=cols["vz"][i])
     rebx = Extras(sim)
+    rebx.set_in_place(in_place)
     ps = sim.particles
     ps[0].params["J2"], ps[0].params["J4"], ps[0].params["R_eq"] = 1e-3, 2e-3, 1e-2
     ps[0].params["Acentral"], ps[0].params["gammacentral"] = 1e-3, -1.0
@@ -105,13 +108,15 @@ def test_gr_hamiltonian(ctx, layout):
     assert abs(got - want) <= 1e-12 * scale, (got, want, scale)
 
 
-def test_gr_hamiltonian_through_the_plugin_api():
+@pytest.mark.parametrize("in_place", [True, False], ids=["in-place", "copies"])
+def test_gr_hamiltonian_through_the_plugin_api(in_place):
     from reboundx_amd.extras import Extras, Simulation
     cols = synthetic.twoplanets()
     sim = Simulation()
     for i in range(3):
         sim.add(m=cols["m"][i], x=cols["x"][i], y=cols["y"][i], z=cols["z"][i], vx=cols["vx"][i], vy=cols["vy"][i], vz=cols["vz"][i])
     rebx = Extras(sim)
+    rebx.set_in_place(in_place)
     gr = rebx.load_force("gr")
     with pytest.raises(RuntimeError, match="speed of light"):
         rebx.gr_hamiltonian(gr)
