@@ -315,8 +315,9 @@ enum rebxamd_status {
 enum rebxamd_mode {
     REBXAMD_MODE_FAST = 0,          /* shared reciprocals, FMA contraction allowed; <=1e-12 relative */
     REBXAMD_MODE_EXACT = 1          /* reference expression order, no contraction: the bits of a CPU build of the reference without FMA
-                                     * contraction on every body but those that collect the pushes of many others (sources, primaries:
-                                     * parallel sums) -- central_force apart, whose pow() is the device library's (<= 4 ulp from glibc's) */
+                                     * contraction on every body while the chains below apply (sources and reference particles collect
+                                     * the pushes one by one in the reference's order; as parallel sums beyond REBXAMD_SEQ_MAX_BODIES) --
+                                     * central_force apart, whose pow() is the device library's (<= 4 ulp from glibc's) */
 };
 
 /* gr and Jacobi/barycentric modify_orbits_forces accumulate body by body in the reference (src/gr.c:80-167 through
@@ -325,7 +326,9 @@ enum rebxamd_mode {
  * other mass layout REBXAMD_MODE_EXACT walks the same recurrences in the reference's order as long as they cover at
  * most REBXAMD_SEQ_MAX_BODIES particles: the whole view, or -- with view->tail_massless set -- its first n_head
  * particles, the massless ones behind them (any number) being measured from the sums those leave (chains on one
- * workgroup: milliseconds at the limit; every body then carries the bits of the sequential evaluation); longer
+ * workgroup: milliseconds at the limit; every body then carries the bits of the sequential evaluation -- under the same
+ * limit the pushes of massive bodies beyond the REBXAMD_MAX_HEAD prefix on sources and reference particles are added
+ * one by one in the reference's order too); longer
  * chains, REBXAMD_MODE_FAST on such layouts and the particle-shard
  * entry points (rebxamd_shard_*) evaluate the sums as parallel prefix sums, whose results stay within 5e-14 of a body's
  * largest acceleration component of the exactly rounded value but are NOT the sequential order's bits (the sequential

@@ -486,7 +486,12 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
         TimedLaunch tl(ctx, st);
         HIP_TRY(launch_stream(v, prog, first, hc, ctx->partials, &nblocks, nslots > 0, exact, vec2, ctx->fixed_stacks, ctx->status, st, applies ? step : nullptr));
     }
-    if (nslots > 0 || sums_out) HIP_TRY(launch_finalize(v, prog, ctx->partials, nblocks, ctx->chunk_sums, sums_out, st));
+    // reference-order arithmetic with at most REBXAMD_SEQ_MAX_BODIES bodies up to the last massive one: the sources collect the
+    // pushes one by one in the order the reference visits the particles, instead of as sums per workgroup
+    const long long nchain = (u->tail_massless != 0 && K >= 1) ? K : v.n;
+    if (exact && nslots > 0 && target_lo < 0 && !sums_out && !step && ctx->seq_exact && nchain <= REBXAMD_SEQ_MAX_BODIES)
+        HIP_TRY(launch_source_replay(v, prog, hc, nchain, st));
+    else if (nslots > 0 || sums_out) HIP_TRY(launch_finalize(v, prog, ctx->partials, nblocks, ctx->chunk_sums, sums_out, st));
     return REBXAMD_OK;
 }
 

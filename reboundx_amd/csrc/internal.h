@@ -54,6 +54,7 @@ struct SrcRec { double x, y, z, vx, vy, vz, m, Rt, k1, inv_m; };
 //  - what the head pass hands to the tail pass.
 struct HeadConsts {
     SrcRec src[REBXAMD_MAX_OPS];
+    double src_acc[REBXAMD_MAX_OPS][3];     // acceleration of each op's source as the run of forces finds it (any-mass-layout pass)
     // gr: interior centre of mass seen by every body behind the head, i.e. (sum m*q) * (1/sum m)
     // for q in {pos, vel, Newtonian acc}, plus mu = G*m0.
     double gr_c[9];
@@ -152,6 +153,9 @@ hipError_t launch_stage(const View& v, const Program& prog, HeadConsts* hc, hipS
 // chunk_sums: scratch of REBXAMD_MAX_OPS * 64 * 3 doubles
 // sums_out: nullptr = add the totals to the source particles; else store 3 doubles per op there
 hipError_t launch_finalize(const View& v, const Program& prog, const double* partials, int nblocks, double* chunk_sums, double* sums_out, hipStream_t st);
+// reference-order arithmetic, any mass layout: the accelerations of the ops' sources rebuilt in the reference's order (instead of launch_finalize)
+// (nchain: bodies that can push -- up to the last massive one)
+hipError_t launch_source_replay(const View& v, const Program& prog, const HeadConsts* hc, long long nchain, hipStream_t st);
 hipError_t launch_add_pushes(const View& v, const Program& prog, const double* sums, hipStream_t st);
 hipError_t launch_last_massive(const double* m, long long n, long long* out_dev, hipStream_t st);
 hipError_t launch_reset(const View& v, hipStream_t st);

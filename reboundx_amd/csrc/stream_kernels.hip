@@ -1105,7 +1105,10 @@ __global__ __launch_bounds__(64) void stage_kernel(View v, Program prog, HeadCon
     const int t = threadIdx.x;
     if (t < prog.nops) {
         int s = prog.ops[t].src;
-        if (s >= 0) { Src S; load_src(v, s, S); hc->src[t] = S; }
+        if (s >= 0) {
+            Src S; load_src(v, s, S); hc->src[t] = S;
+            hc->src_acc[t][0] = v.ax[s]; hc->src_acc[t][1] = v.ay[s]; hc->src_acc[t][2] = v.az[s];
+        }
     }
 }
 
@@ -1163,6 +1166,82 @@ __global__ __launch_bounds__(64) void finalize_stage2(View v, Program prog, cons
             }
         }
     }
+}
+
+// ------------------------------------------------------------------ sources in the reference's order
+// The reference walks a force's particles in index order, and every one of them pushes on the force's source as it is
+// visited: the source's acceleration is a chain of additions, interleaved -- force by force -- with what the source gains
+// as an ordinary particle of the other forces.  The streaming pass sums the pushes per wavefront and workgroup (another
+// order: a few ulp away).  Here ONE workgroup per source rebuilds that chain from the acceleration the run of forces found
+// (stage_kernel kept it): force after force, either the source's own update (one thread), or the pushes of all other
+// bodies -- evaluated 256 at a time in parallel, then added by one thread in the order the force visits them.  The result replaces what the
+// streaming pass left in the source's row.  A chain of n additions per force that pushes: bodies x ~10 clock cycles.
+static constexpr int RT = 256;
+
+__device__ __forceinline__ void load_part_all(const View& v, const Program& prog, long long i, Part& p) {
+    part_defaults(p);
+    p.x = v.x[i]; p.y = v.y[i]; p.z = v.z[i];
+    if (prog.need_vel) { p.vx = v.vx[i]; p.vy = v.vy[i]; p.vz = v.vz[i]; }
+    if (v.m) p.m = v.m[i];
+    if (prog.need_beta && v.beta) p.beta = v.beta[i];
+    if (prog.need_tides && v.Rt) p.Rt = v.Rt[i];
+    if (prog.need_tides && v.k1) p.k1 = v.k1[i];
+    if (prog.need_tau && v.ta) p.ta = v.ta[i];
+    if (prog.need_tau && v.te) p.te = v.te[i];
+    if (prog.need_tau && v.ti) p.ti = v.ti[i];
+}
+
+// nchain: the bodies that can push -- all of them, or those up to the last massive one (a massless body pushes with a zero)
+__global__ __launch_bounds__(RT) void source_replay_kernel(View v, Program prog, const HeadConsts* __restrict__ tab, long long nchain) {
+    __shared__ double push[3][RT];
+    const int first = blockIdx.x, tid = threadIdx.x;
+    const int s = prog.ops[first].src;
+    if (prog.ops[first].slot < 0 || s < 0) return;
+    for (int e = 0; e < first; e++)
+        if (prog.ops[e].slot >= 0 && prog.ops[e].src == s) return;      // (the first force that pushes on a body rebuilds that body)
+    V3 val = {tab->src_acc[first][0], tab->src_acc[first][1], tab->src_acc[first][2]};
+    Part self;
+    load_part_all(v, prog, s, self);
+    for (int k = 0; k < prog.nops; k++) {
+        const DevOp op = prog.ops[k];
+        if (op.src < 0) continue;
+        const Src S = tab->src[k];
+        Geo g;
+        g.src = -1; g.dx = g.dy = g.dz = g.ri = 0.;
+        if (op.src != s) {
+            // an ordinary particle of this force
+            double bx = 0., by = 0., bz = 0.;
+            if (tid == 0) general_op<true>(op.kind, op, S, prog.G, self, g, val, bx, by, bz);
+            continue;
+        }
+        if (op.slot < 0) continue;              // a source that nothing pushes on (radiation)
+        // (modify_orbits_forces visits its particles from the last to the first, src/rebxtools.c:71; the other forces ascend)
+        const bool descending = op.kind == REBXAMD_OP_MOF;
+        const long long ntiles = (nchain + RT - 1) / RT;
+        for (long long t = 0; t < ntiles; t++) {
+            const long long t0 = (descending ? ntiles - 1 - t : t) * RT;
+            const long long i = t0 + tid;
+            double bx = 0., by = 0., bz = 0.;
+            if (i < nchain && i != s) {
+                Part p;
+                load_part_all(v, prog, i, p);
+                V3 own = {0., 0., 0.};
+                general_op<true>(op.kind, op, S, prog.G, p, g, own, bx, by, bz);
+            }
+            push[0][tid] = bx; push[1][tid] = by; push[2][tid] = bz;
+            __syncthreads();
+            if (tid == 0) {
+                const int cnt = (int)((nchain - t0) < RT ? (nchain - t0) : RT);
+                for (int jj = 0; jj < cnt; jj++) {
+                    const int j = descending ? cnt - 1 - jj : jj;
+                    if (t0 + j == s) continue;
+                    val.x += push[0][j]; val.y += push[1][j]; val.z += push[2][j];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) { v.ax[s] = val.x; v.ay[s] = val.y; v.az[s] = val.z; }
 }
 
 // adds externally combined pushes (3 doubles per op) to the ops' source particles, in op order
@@ -1360,6 +1439,11 @@ hipError_t launch_finalize(const View& v, const Program& prog, const double* par
     static_assert(FIN_CHUNKS == 64, "stage 2 folds the chunk sums with one wavefront");
     if (prog.nslots > 0) hipLaunchKernelGGL(finalize_stage1, dim3(FIN_CHUNKS, prog.nslots), dim3(BLOCK), 0, st, partials, nblocks, chunk_sums);
     hipLaunchKernelGGL(finalize_stage2, dim3(1), dim3(64), 0, st, v, prog, chunk_sums, sums_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_source_replay(const View& v, const Program& prog, const HeadConsts* hc, long long nchain, hipStream_t st) {
+    hipLaunchKernelGGL(source_replay_kernel, dim3(prog.nops), dim3(RT), 0, st, v, prog, hc, nchain < v.n ? nchain : v.n);
     return hipGetLastError();
 }
 

@@ -426,6 +426,46 @@ def test_full_stack_with_planets_scattered(ctx, mode):
     scan_check(ctx, zero_acc(cols), pp, stack, mode)
 
 
+@pytest.mark.parametrize("layout", ["all-massive", "scattered-with-massless-tail", "too-long"])
+def test_sources_collect_their_pushes_in_the_order_of_the_reference(ctx, layout):
+    """Reference-order arithmetic, massive bodies beyond the 64-body head: the sources of gravitational_harmonics (two of
+    them), gr_potential and tides_precession and the reference particle of modify_orbits_forces collect the pushes of
+    every other body one by one -- ascending for the sourced forces, descending for modify_orbits_forces
+    (src/rebxtools.c:71) -- between their own updates as particles of the other forces, so every body, the sources
+    included, carries the checker's bits; the full stack with gr and Jacobi drag in the middle as well.  With the last
+    massive body above the size limit of the chains the pushes are summed per workgroup: the sources are then a few ulp
+    from the checker, the rest of the bodies still bitwise."""
+    if layout == "all-massive":
+        n = 6000
+        cols, pp, _ = synthetic.disk(n, 3, dust_mass=1e-10)
+    else:
+        n = SEQ_MAX + 2500
+        cols, pp, _ = synthetic.disk(n, 3)
+        rng = np.random.default_rng(5)
+        last = 900 if layout == "scattered-with-massless-tail" else n - 7
+        cols["m"][rng.choice(np.arange(70, last), size=60, replace=False)] = 10.0 ** rng.uniform(-9, -5, 60)
+        cols["m"][last] = 1e-7
+    pp = dict(pp)
+    for key, val in (("J2", 2e-3), ("J4", -1e-4), ("R_eq", 2e-3)):
+        pp[key] = pp[key].copy(); pp[key][1] = val
+    pp["primary"] = np.zeros(n, dtype=np.uint8)
+    pp["primary"][2] = 1
+    synthetic.add_newtonian(cols, n_head=4)
+    pushing = [("gravitational_harmonics", {}), ("modify_orbits_forces", {"coordinates": 2}), ("gr_potential", {"c": C}), ("tides_precession", {}),
+               ("radiation_forces", {"c": C})]
+    stacks = [pushing]
+    if layout != "too-long":
+        stacks.append(pushing[:2] + [("gr", {"c": C}), ("modify_orbits_forces", {})] + pushing[2:])
+    for stack in stacks:
+        ref = run_oracle(cols, pp, stack)
+        got, _ = run_device(ctx, cols, pp, stack, 1.0, EXACT)
+        u = ulp_diff(got, ref).max(axis=0)
+        if layout == "too-long":
+            assert u[3:].max() == 0 and 0 < u[:3].max() < 4096
+        else:
+            assert u.max() == 0, np.nonzero(u)[0][:8]
+
+
 RIDING_STACKS = {
     "tides+jacobi+gr_potential": [("tides_precession", {}), ("modify_orbits_forces", {}), ("gr_potential", {"c": C})],
     "harmonics+barycentric": [("gravitational_harmonics", {}), ("modify_orbits_forces", {"coordinates": 1})],
