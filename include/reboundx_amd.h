@@ -288,7 +288,7 @@ int rebxamd_set_param_column(struct rebx_extras* rebx, const char* name, const d
 const double* rebxamd_get_param_column(struct rebx_extras* rebx, const char* name, int* N);
 /* 0 = fast arithmetic (default), 1 = reference-order arithmetic, no FMA contraction. */
 void rebxamd_set_mode(struct rebx_extras* rebx, int mode);
-/* Small systems (at most 16384 particles, massive bodies within the first REBXAMD_MAX_HEAD, no gr_full in the batch) are
+/* Small systems (at most 32768 particles, massive bodies within the first REBXAMD_MAX_HEAD, no gr_full in the batch) are
  * evaluated in place: the kernels read and update the pinned host columns the particles were packed into, over the link,
  * instead of waiting for one copy command per direction (33 against 56 microseconds per call at 1000 particles; the
  * results are the same bits).  on = 0 goes back to the copies for this simulation; the environment variable

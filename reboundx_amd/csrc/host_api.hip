@@ -215,7 +215,11 @@ int pipeline_block(int N) {
 // separate the phases of rebxamd_last_timings (their enqueue times are reported instead: what
 // matters at this size is the latency of the call).
 // (Buffers that once held a large system keep their size: then the columns are copied one by one.)
-bool small_system(const Bridge* b, int N) { return N <= 16384 && b->cap <= 32768; }
+int small_limit() {
+    static const int limit = [] { const char* e = getenv("REBXAMD_SMALL_LIMIT"); const int v = e ? atoi(e) : 32768; return v < 1 ? 1 : v; }();
+    return limit;
+}
+bool small_system(const Bridge* b, int N) { return N <= small_limit() && b->cap <= 2 * (size_t)small_limit(); }
 
 // Helper threads of the conversions, started once and parked on a condition variable between calls (starting a thread
 // costs tens of microseconds, a conversion of 10^5 particles a hundred).  One job at a time: a caller that finds the
@@ -1076,7 +1080,7 @@ bool stage_in(struct reb_simulation* sim, struct rebx_extras* rebx, Bridge* b, c
 // whether a call on N particles should try the in-place route (stage_in has the last word: it knows the masses)
 bool in_place_wanted(const Bridge* b, int N) {
     static const bool allowed = [] { const char* e = getenv("REBXAMD_HOOK_IN_PLACE"); return !(e && e[0] == '0'); }();
-    static const int limit = [] { const char* e = getenv("REBXAMD_HOOK_IN_PLACE_LIMIT"); return e ? atoi(e) : 16384; }();
+    static const int limit = [] { const char* e = getenv("REBXAMD_HOOK_IN_PLACE_LIMIT"); return e ? atoi(e) : small_limit(); }();
     return allowed && b->in_place && N <= limit && small_system(b, N);
 }
 
@@ -1100,7 +1104,7 @@ void run_builtin(struct reb_simulation* sim, struct rebx_extras* rebx, const std
     // The exact arithmetic adds force after force onto the uploaded values, as the reference does.
     // (gr_full reads the incoming accelerations -- src/gr_full.c:70-74 -- so a batch that holds it uploads them.)
     // A batch of position-only forces (the reference's REBX_FORCE_POS, src/core.c:232-263) leaves the velocities behind too.
-    const bool large = !(N <= 16384 && b->cap <= 32768);
+    const bool large = !small_system(b, N);
     bool reads_acc = false, reads_vel = false;
     for (const Pending& pf : batch) {
         reads_acc |= pf.force->update_accelerations == rebx_gr_full;
