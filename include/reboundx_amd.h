@@ -628,6 +628,11 @@ int rebxamd_fixed_stacks(rebxamd_ctx* ctx, int on);
  * Jacobi/barycentric modify_orbits_forces with parallel prefix sums on every layout that has massive bodies beyond a
  * short prefix, also below REBXAMD_SEQ_MAX_BODIES particles (default: 1, the reference's order there). */
 int rebxamd_sequential_exact(rebxamd_ctx* ctx, int on);
+/* Kernel selection (no counterpart in the reference).  rebxamd_grfull on at most 256 bodies -- the sizes the reference's
+ * own O(N^3) loops are used at -- runs every pass and every sweep of the evaluation in ONE launch of one workgroup (the
+ * same per-row arithmetic in the same order as the queued passes: the same bits, an eighth of the latency).  on = 0
+ * makes this context queue the passes at every size (default: 1). */
+int rebxamd_grfull_one_launch(rebxamd_ctx* ctx, int on);
 /* Kernel selection for rebxamd_wh_steps and rebxamd_integrate_force (no counterpart in the
  * reference).  When the massive bodies are a short prefix, the bodies behind it massless and the
  * force stack one streaming run, the pass over the massless bodies carries the whole update:

@@ -77,6 +77,7 @@ _sig = {
     "rebxamd_fixed_stacks": (c_int, [c_void_p, c_int]),
     "rebxamd_carried_steps": (c_int, [c_void_p, c_int]),
     "rebxamd_sequential_exact": (c_int, [c_void_p, c_int]),
+    "rebxamd_grfull_one_launch": (c_int, [c_void_p, c_int]),
     "rebxamd_wh_batch": (c_int, [c_void_p, c_int]),
     "rebxamd_timing_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int)]),
     "rebxamd_grfull_newton": (c_int, [c_void_p, POINTER(View), c_int] + [c_void_p] * 6 + [c_void_p]),

@@ -49,6 +49,7 @@ struct rebxamd_ctx {
     bool timing = false;
     bool carried_steps = true;  // Wisdom-Holman runs: kick and drift ride in the force pass when the layout allows
     bool fixed_stacks = true;   // stacks with a kernel instance of their own use it
+    bool grfull_one_launch = true;      // gr_full of at most 256 bodies as one launch (rebxamd_grfull_one_launch)
     bool seq_exact = true;      // reference-order arithmetic: prefix-sum forces on at most REBXAMD_SEQ_MAX_BODIES bodies are walked in the reference's order
     int chain_rounds = 12;      // modify_orbits_direct on long chains: rounds of the fixed-point iteration before the sequential walk takes over
     int chain_last_rounds = 0;  // rounds the last such call took, -1 if it fell back to the sequential walk
@@ -168,6 +169,12 @@ extern "C" int rebxamd_timing_enable(rebxamd_ctx* ctx, int on) {
 extern "C" int rebxamd_fixed_stacks(rebxamd_ctx* ctx, int on) {
     if (!ctx) return REBXAMD_ERR_ARG;
     ctx->fixed_stacks = on != 0;
+    return REBXAMD_OK;
+}
+
+extern "C" int rebxamd_grfull_one_launch(rebxamd_ctx* ctx, int on) {
+    if (!ctx) return REBXAMD_ERR_ARG;
+    ctx->grfull_one_launch = on != 0;
     return REBXAMD_OK;
 }
 
@@ -1673,6 +1680,16 @@ extern "C" int rebxamd_grfull(rebxamd_ctx* ctx, const rebxamd_view* u, double c,
     double *aox = w + 7 * n, *aoy = w + 8 * n, *aoz = w + 9 * n;
     double *nwx = w + 10 * n, *nwy = w + 11 * n, *nwz = w + 12 * n;
     const View v = make_view(u);
+    if (n <= grfull_small_limit() && ctx->grfull_one_launch) {
+        // small systems: every pass and every sweep in one launch of one workgroup (same functions, same bits)
+        HIP_TRY(launch_grfull_small(v, u->G, c, gravity_ignore_10, w, ctx->gf_flag, ctx->status, !fused, st));
+        if (sweeps) {
+            unsigned h[2] = {0u, 0u};
+            { const int rb = read_back(ctx, h, ctx->gf_flag, sizeof(h), st); if (rb != REBXAMD_OK) return rb; }
+            *sweeps = (int)h[1];
+        }
+        return REBXAMD_OK;
+    }
     HIP_TRY(launch_grfull_prepare(v, u->G, gravity_ignore_10, anx, any_, anz, aox, aoy, aoz, st));
     double* const part4 = w + 13 * n;
     if (fused) {

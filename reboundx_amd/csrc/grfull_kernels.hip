@@ -70,11 +70,14 @@ struct Row {
 // 22 instructions per pair (3 differences, 3 for r^2, 5 for the refined reciprocal square root, 1 for
 // 1/r^2, 3 for the dot product with B_j/7, 1 product, 2 x 3 fused multiply-adds), the mass already inside
 // B_j and both B_j and B_j/7 staged, so that no per-pair scaling is left.
-template <int PASS, bool DIAG, int R>
-__device__ __forceinline__ void grfull_tile(const TileA* __restrict__ ta, const TileB* __restrict__ tb, const TileC* __restrict__ tc, Row (&row)[R]) {
+// SHORT: only the first `cnt` bodies of the tile (the one-launch evaluation of a small system: the bodies behind them are
+// padding, whose terms are zeros).
+template <int PASS, bool DIAG, int R, bool SHORT = false>
+__device__ __forceinline__ void grfull_tile(const TileA* __restrict__ ta, const TileB* __restrict__ tb, const TileC* __restrict__ tc, Row (&row)[R], const int cnt = GB) {
     constexpr bool SWEEP = PASS == PASS_SWEEP || PASS == PASS_SWEEP_POT;
+    const int lim = SHORT ? cnt : GB;
 #pragma unroll 4
-    for (int jj = 0; jj < GB; jj++) {
+    for (int jj = 0; jj < lim; jj++) {
         const TileA A = ta[jj];
         TileB B;
         TileC C;
@@ -125,6 +128,71 @@ __device__ __forceinline__ void grfull_tile(const TileA* __restrict__ ta, const 
     }
 }
 
+// what a row carries into a pass (i: its body)
+template <int PASS>
+__device__ __forceinline__ void grfull_row_init(const GrFullArgs& a, long long i, bool live, Row& w) {
+    w.xi = w.yi = w.zi = w.ax = w.ay = w.az = w.bx = w.by = w.bz = w.p4 = 0.;
+    w.s0 = w.s1 = w.s2 = w.sp = w.t0 = w.t1 = w.t2 = 0.;
+    w.self = -1;
+    if (live) {
+        w.xi = a.x[i]; w.yi = a.y[i]; w.zi = a.z[i];
+        if (PASS == PASS_CONST) {
+            const double vxi = a.vx[i], vyi = a.vy[i], vzi = a.vz[i];
+            const double vi2 = vxi * vxi + vyi * vyi + vzi * vzi;
+            w.p4 = 4. * a.pot[i] * a.C2 - vi2;      // work in units where 1/c^2 is applied once at the end
+            w.bx = 4. * vxi; w.by = 4. * vyi; w.bz = 4. * vzi;
+            w.ax = w.bx * INV_K; w.ay = w.by * INV_K; w.az = w.bz * INV_K;
+        }
+    }
+}
+
+// body j (behind j1: padding) into slot `slot` of the tile
+template <int PASS>
+__device__ __forceinline__ void grfull_stage(const GrFullArgs& a, long long j, long long j1, int slot, TileA* ta, TileB* tb, TileC* tc) {
+    constexpr bool SWEEP = PASS == PASS_SWEEP || PASS == PASS_SWEEP_POT;
+    if (j < j1) {
+        TileA A; A.x = a.x[j]; A.y = a.y[j]; A.z = a.z[j]; A.gm = a.G * a.m[j];
+        ta[slot] = A;
+        if (PASS == PASS_CONST) {
+            const double vxj = a.vx[j], vyj = a.vy[j], vzj = a.vz[j];
+            TileB B; B.a = K_V * vxj; B.b = K_V * vyj; B.c = K_V * vzj;
+            B.d = a.pot[j] * a.C2 - 2. * (vxj * vxj + vyj * vyj + vzj * vzj);
+            tb[slot] = B;
+        }
+        if (SWEEP) {
+            // (the first sweep starts from a_old = 0 and does not read it)
+            const double tx = PASS == PASS_SWEEP ? a.anx[j] + a.aox[j] : a.anx[j];
+            const double ty = PASS == PASS_SWEEP ? a.any_[j] + a.aoy[j] : a.any_[j];
+            const double tz = PASS == PASS_SWEEP ? a.anz[j] + a.aoz[j] : a.anz[j];
+            const double g35 = 3.5 * A.gm, g05 = 0.5 * A.gm;
+            TileB B; B.a = g35 * tx; B.b = g35 * ty; B.c = g35 * tz; B.d = g05 * tx;
+            TileC C; C.b = g05 * ty; C.c = g05 * tz;
+            tb[slot] = B; tc[slot] = C;
+        }
+    } else {
+        // padding bodies: zero mass far away contributes exactly nothing
+        TileA A; A.x = 1.e100; A.y = 1.e100; A.z = 1.e100; A.gm = 0.;
+        TileB B; B.a = B.b = B.c = B.d = 0.;
+        ta[slot] = A; tb[slot] = B;
+        if (SWEEP) { TileC C; C.b = C.c = 0.; tc[slot] = C; }
+    }
+}
+
+// what the constant pass leaves per row:  + v_i sum(w2) - (1/k) sum(w2 k v_j);  row.b = 4 v_i
+__device__ __forceinline__ void grfull_const_result(const Row& w, double scale, double& o0, double& o1, double& o2) {
+    o0 = fma(0.25 * w.bx, w.sp, fma(-INV_K, w.t0, w.s0)) * scale;
+    o1 = fma(0.25 * w.by, w.sp, fma(-INV_K, w.t1, w.s1)) * scale;
+    o2 = fma(0.25 * w.bz, w.sp, fma(-INV_K, w.t2, w.s2)) * scale;
+}
+
+// the reference's stopping rule for one row (gr_full.c:206-220): signed ratio, NaN never counts, threshold 1e-30
+__device__ __forceinline__ bool grfull_row_unconverged(double s0, double s1, double s2, double o0, double o1, double o2) {
+    const double d0 = (fabs(s0) < 1.e-30) ? 0. : fabs(s0 - o0) / s0;
+    const double d1 = (fabs(s1) < 1.e-30) ? 0. : fabs(s1 - o1) / s1;
+    const double d2 = (fabs(s2) < 1.e-30) ? 0. : fabs(s2 - o2) / s2;
+    return (d0 >= 1.e-30) || (d1 >= 1.e-30) || (d2 >= 1.e-30);
+}
+
 // Workgroup = 256 threads, GB*R rows: thread t owns rows t, t + 256, ... of the workgroup's block.
 template <int PASS, int R>
 __global__ __launch_bounds__(GB) void grfull_fast_kernel(GrFullArgs a) {
@@ -147,52 +215,13 @@ __global__ __launch_bounds__(GB) void grfull_fast_kernel(GrFullArgs a) {
         const long long r = (long long)blockIdx.x * (GB * R) + q * GB + tid;
         ri_[q] = r;
         live[q] = r < nrows;
-        Row& w = row[q];
-        w.xi = w.yi = w.zi = w.ax = w.ay = w.az = w.bx = w.by = w.bz = w.p4 = 0.;
-        w.s0 = w.s1 = w.s2 = w.sp = w.t0 = w.t1 = w.t2 = 0.;
-        w.self = -1;
-        if (live[q]) {
-            const long long i = a.row0 + r;
-            w.xi = a.x[i]; w.yi = a.y[i]; w.zi = a.z[i];
-            if (PASS == PASS_CONST) {
-                const double vxi = a.vx[i], vyi = a.vy[i], vzi = a.vz[i];
-                const double vi2 = vxi * vxi + vyi * vyi + vzi * vzi;
-                w.p4 = 4. * a.pot[i] * a.C2 - vi2;      // work in units where 1/c^2 is applied once at the end
-                w.bx = 4. * vxi; w.by = 4. * vyi; w.bz = 4. * vzi;
-                w.ax = w.bx * INV_K; w.ay = w.by * INV_K; w.az = w.bz * INV_K;
-            }
-        }
+        grfull_row_init<PASS>(a, a.row0 + r, live[q], row[q]);
     }
 
     for (long long jt = j0; jt < j1; jt += GB) {
         const long long j = jt + tid;
         __syncthreads();
-        if (j < j1) {
-            TileA A; A.x = a.x[j]; A.y = a.y[j]; A.z = a.z[j]; A.gm = a.G * a.m[j];
-            ta[tid] = A;
-            if (PASS == PASS_CONST) {
-                const double vxj = a.vx[j], vyj = a.vy[j], vzj = a.vz[j];
-                TileB B; B.a = K_V * vxj; B.b = K_V * vyj; B.c = K_V * vzj;
-                B.d = a.pot[j] * a.C2 - 2. * (vxj * vxj + vyj * vyj + vzj * vzj);
-                tb[tid] = B;
-            }
-            if (SWEEP) {
-                // (the first sweep starts from a_old = 0 and does not read it)
-                const double tx = PASS == PASS_SWEEP ? a.anx[j] + a.aox[j] : a.anx[j];
-                const double ty = PASS == PASS_SWEEP ? a.any_[j] + a.aoy[j] : a.any_[j];
-                const double tz = PASS == PASS_SWEEP ? a.anz[j] + a.aoz[j] : a.anz[j];
-                const double g35 = 3.5 * A.gm, g05 = 0.5 * A.gm;
-                TileB B; B.a = g35 * tx; B.b = g35 * ty; B.c = g35 * tz; B.d = g05 * tx;
-                TileC C; C.b = g05 * ty; C.c = g05 * tz;
-                tb[tid] = B; tc[tid] = C;
-            }
-        } else {
-            // padding bodies: zero mass far away contributes exactly nothing
-            TileA A; A.x = 1.e100; A.y = 1.e100; A.z = 1.e100; A.gm = 0.;
-            TileB B; B.a = B.b = B.c = B.d = 0.;
-            ta[tid] = A; tb[tid] = B;
-            if (SWEEP) { TileC C; C.b = C.c = 0.; tc[tid] = C; }
-        }
+        grfull_stage<PASS>(a, j, j1, tid, ta, tb, tc);
         __syncthreads();
         if (jt < blk_hi && jt + GB > blk_lo) {      // workgroup-uniform: this tile overlaps our own rows
 #pragma unroll
@@ -215,12 +244,8 @@ __global__ __launch_bounds__(GB) void grfull_fast_kernel(GrFullArgs a) {
             double* o = a.part + ((long long)blockIdx.y * nrows + ri_[q]) * 4;
             o[0] = row[q].s0 * scale; o[1] = row[q].s1 * scale; o[2] = row[q].s2 * scale; o[3] = row[q].sp * scale;
         } else if (PASS == PASS_CONST) {
-            // + v_i sum(w2) - (1/k) sum(w2 k v_j);  row.b = 4 v_i
-            const Row& w = row[q];
             double* o = a.part + ((long long)blockIdx.y * nrows + ri_[q]) * 3;
-            o[0] = fma(0.25 * w.bx, w.sp, fma(-INV_K, w.t0, w.s0)) * scale;
-            o[1] = fma(0.25 * w.by, w.sp, fma(-INV_K, w.t1, w.s1)) * scale;
-            o[2] = fma(0.25 * w.bz, w.sp, fma(-INV_K, w.t2, w.s2)) * scale;
+            grfull_const_result(row[q], scale, o[0], o[1], o[2]);
         } else {
             double* o = a.part + ((long long)blockIdx.y * nrows + ri_[q]) * 3;
             o[0] = row[q].s0 * scale; o[1] = row[q].s1 * scale; o[2] = row[q].s2 * scale;
@@ -254,11 +279,7 @@ __global__ __launch_bounds__(256) void grfull_combine_kernel(const double* part,
             }
             if (PASS == PASS_SWEEP) {
                 s0 += acx[i]; s1 += acy[i]; s2 += acz[i];
-                // reference gr_full.c:206-220: signed ratio, NaN never counts, threshold 1e-30
-                const double d0 = (fabs(s0) < 1.e-30) ? 0. : fabs(s0 - aox[i]) / s0;
-                const double d1 = (fabs(s1) < 1.e-30) ? 0. : fabs(s1 - aoy[i]) / s1;
-                const double d2 = (fabs(s2) < 1.e-30) ? 0. : fabs(s2 - aoz[i]) / s2;
-                unconverged = (d0 >= 1.e-30) || (d1 >= 1.e-30) || (d2 >= 1.e-30);
+                unconverged = grfull_row_unconverged(s0, s1, s2, aox[i], aoy[i], aoz[i]);
             }
             o0[i] = s0; o1[i] = s1; o2[i] = s2;
         }
@@ -270,15 +291,13 @@ __global__ __launch_bounds__(256) void grfull_combine_kernel(const double* part,
 }
 
 // ------------------------------------------------------------------ exact passes (sequential j)
+// one row of a pass; returns whether the row fails the stopping rule (sweeps)
 template <int PASS>
-__global__ __launch_bounds__(GB) void grfull_exact_kernel(GrFullArgs a, const double* acx, const double* acy, const double* acz,
-                                                          double* o0, double* o1, double* o2, unsigned* flag) {
+__device__ __forceinline__ bool grfull_exact_row(const GrFullArgs& a, long long i, const double* acx, const double* acy, const double* acz,
+                                                 double* o0, double* o1, double* o2) {
 #pragma clang fp contract(off)
-    if (PASS == PASS_SWEEP && a.stop != nullptr && *a.stop != 0u) return;
-    const long long r = (long long)blockIdx.x * GB + threadIdx.x;
-    const long long i = a.row0 + r;
     bool unconverged = false;
-    if (i < a.row1) {
+    {
         const double G = a.G, C2 = a.C2;
         const double xi = a.x[i], yi = a.y[i], zi = a.z[i];
         if (PASS == PASS_POT) {
@@ -333,13 +352,21 @@ __global__ __launch_bounds__(GB) void grfull_exact_kernel(GrFullArgs a, const do
                 nz += (G * mj * dz / rij3) * (dx * tx + dy * ty + dz * tz) / (2. * C2) + (7. / (2. * C2)) * G * mj * tz / rr;
             }
             const double s0 = acx[i] + nx, s1 = acy[i] + ny, s2 = acz[i] + nz;
-            const double d0 = (fabs(s0) < 1.e-30) ? 0. : fabs(s0 - a.aox[i]) / s0;
-            const double d1 = (fabs(s1) < 1.e-30) ? 0. : fabs(s1 - a.aoy[i]) / s1;
-            const double d2 = (fabs(s2) < 1.e-30) ? 0. : fabs(s2 - a.aoz[i]) / s2;
-            unconverged = (d0 >= 1.e-30) || (d1 >= 1.e-30) || (d2 >= 1.e-30);
+            unconverged = grfull_row_unconverged(s0, s1, s2, a.aox[i], a.aoy[i], a.aoz[i]);
             o0[i] = s0; o1[i] = s1; o2[i] = s2;
         }
     }
+    return unconverged;
+}
+
+template <int PASS>
+__global__ __launch_bounds__(GB) void grfull_exact_kernel(GrFullArgs a, const double* acx, const double* acy, const double* acz,
+                                                          double* o0, double* o1, double* o2, unsigned* flag) {
+    if (PASS == PASS_SWEEP && a.stop != nullptr && *a.stop != 0u) return;
+    const long long r = (long long)blockIdx.x * GB + threadIdx.x;
+    const long long i = a.row0 + r;
+    bool unconverged = false;
+    if (i < a.row1) unconverged = grfull_exact_row<PASS>(a, i, acx, acy, acz, o0, o1, o2);
     if (PASS == PASS_SWEEP) {
         const unsigned long long any = __ballot(unconverged);
         if (any != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
@@ -348,21 +375,24 @@ __global__ __launch_bounds__(GB) void grfull_exact_kernel(GrFullArgs a, const do
 
 // a_newton = incoming acceleration (+ the 0-1 pair when REBOUND's gravity left it out,
 // reference gr_full.c:92-102); a_old = 0
+__device__ __forceinline__ void grfull_prepare_row(const View& v, double G, int ignore10, long long i, double* anx, double* any_, double* anz,
+                                                   double* a0x, double* a0y, double* a0z) {
+#pragma clang fp contract(off)
+    double ax = v.ax[i], ay = v.ay[i], az = v.az[i];
+    if (ignore10 && i < 2 && v.n > 1) {
+        const double dx = v.x[0] - v.x[1], dy = v.y[0] - v.y[1], dz = v.z[0] - v.z[1];
+        const double rr = sqrt(dx * dx + dy * dy + dz * dz);
+        const double prefact = -G / (rr * rr * rr);
+        if (i == 0) { const double p1 = prefact * v.m[1]; ax += p1 * dx; ay += p1 * dy; az += p1 * dz; }
+        else        { const double p0 = prefact * v.m[0]; ax -= p0 * dx; ay -= p0 * dy; az -= p0 * dz; }
+    }
+    anx[i] = ax; any_[i] = ay; anz[i] = az;
+    a0x[i] = 0.; a0y[i] = 0.; a0z[i] = 0.;
+}
 __global__ __launch_bounds__(256) void grfull_prepare_kernel(View v, double G, int ignore10, double* anx, double* any_, double* anz,
                                                              double* a0x, double* a0y, double* a0z) {
-#pragma clang fp contract(off)
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < v.n; i += (long long)gridDim.x * 256) {
-        double ax = v.ax[i], ay = v.ay[i], az = v.az[i];
-        if (ignore10 && i < 2 && v.n > 1) {
-            const double dx = v.x[0] - v.x[1], dy = v.y[0] - v.y[1], dz = v.z[0] - v.z[1];
-            const double rr = sqrt(dx * dx + dy * dy + dz * dz);
-            const double prefact = -G / (rr * rr * rr);
-            if (i == 0) { const double p1 = prefact * v.m[1]; ax += p1 * dx; ay += p1 * dy; az += p1 * dz; }
-            else        { const double p0 = prefact * v.m[0]; ax -= p0 * dx; ay -= p0 * dy; az -= p0 * dz; }
-        }
-        anx[i] = ax; any_[i] = ay; anz[i] = az;
-        a0x[i] = 0.; a0y[i] = 0.; a0z[i] = 0.;
-    }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < v.n; i += (long long)gridDim.x * 256)
+        grfull_prepare_row(v, G, ignore10, i, anx, any_, anz, a0x, a0y, a0z);
 }
 
 __global__ __launch_bounds__(256) void grfull_finish_kernel(View v, const double* ax, const double* ay, const double* az) {
@@ -391,6 +421,108 @@ __global__ __launch_bounds__(256) void grfull_finish_select_kernel(View v, const
         v.ax[i] += ax[i]; v.ay[i] += ay[i]; v.az[i] += az[i];
     }
 }
+
+// ------------------------------------------------------------------ small systems: one launch per evaluation
+// Up to 256 bodies -- what the reference's own O(N^3) loops and N x N stack arrays are used for -- one workgroup holds a row per
+// thread, and the whole evaluation (a_newton, potential sums shared with the first sweep, constant part, up to ten sweeps with
+// the stopping rule, the addition to the particles) runs in ONE launch, the passes separated by workgroup barriers, instead of
+// the three dozen launches of the queued passes (each a few microseconds of front-end time, whatever the size).  The rows go
+// through the same functions as in those passes, in the same order, with one j chunk: the results are the same bits.
+// w: 13 columns of n doubles (a_newton 3, pot 1, a_const 3, two iterates 3 + 3).  ctl[0] <- 1 when the rule was met,
+// ctl[1] <- sweeps run.
+template <bool EXACT>
+__global__ __launch_bounds__(GB) void grfull_small_kernel(View v, GrFullArgs a, int ignore10, double* w, unsigned* ctl, unsigned* status) {
+    __shared__ TileA ta[GB];
+    __shared__ TileB tb[GB];
+    __shared__ TileC tc[GB];
+    const int tid = threadIdx.x;
+    const long long n = a.n, i = tid;
+    const bool live = i < n;
+    double *anx = w, *any_ = w + n, *anz = w + 2 * n, *pot = w + 3 * n;
+    double *acx = w + 4 * n, *acy = w + 5 * n, *acz = w + 6 * n;
+    double* const b0[3] = {w + 7 * n, w + 8 * n, w + 9 * n};
+    double* const b1[3] = {w + 10 * n, w + 11 * n, w + 12 * n};
+    a.anx = anx; a.any_ = any_; a.anz = anz; a.pot = pot;
+    if (live) grfull_prepare_row(v, a.G, ignore10, i, anx, any_, anz, b0[0], b0[1], b0[2]);
+    __syncthreads();
+    const double scale = a.invC2;
+    double p0 = 0., p1 = 0., p2 = 0.;           // default arithmetic: the pair sums of the first sweep, formed with the potential sums
+    Row row;
+    if (EXACT) {
+        if (live) grfull_exact_row<PASS_POT>(a, i, nullptr, nullptr, nullptr, pot, nullptr, nullptr);
+    } else {
+        grfull_row_init<PASS_SWEEP_POT>(a, i, live, row);
+        grfull_stage<PASS_SWEEP_POT>(a, tid, n, tid, ta, tb, tc);
+        __syncthreads();
+        row.self = live ? tid : -1;
+        grfull_tile<PASS_SWEEP_POT, true, 1, true>(ta, tb, tc, reinterpret_cast<Row(&)[1]>(row), (int)n);
+        p0 = row.s0 * scale; p1 = row.s1 * scale; p2 = row.s2 * scale;
+        if (live) pot[i] = 0. + row.sp * scale;
+    }
+    __syncthreads();
+    if (EXACT) {
+        if (live) grfull_exact_row<PASS_CONST>(a, i, nullptr, nullptr, nullptr, acx, acy, acz);
+    } else {
+        grfull_row_init<PASS_CONST>(a, i, live, row);
+        grfull_stage<PASS_CONST>(a, tid, n, tid, ta, tb, tc);
+        __syncthreads();
+        row.self = live ? tid : -1;
+        grfull_tile<PASS_CONST, true, 1, true>(ta, tb, tc, reinterpret_cast<Row(&)[1]>(row), (int)n);
+        if (live) {
+            double c0, c1, c2;
+            grfull_const_result(row, scale, c0, c1, c2);
+            acx[i] = 0. + c0; acy[i] = 0. + c1; acz[i] = 0. + c2;
+        }
+    }
+    __syncthreads();
+    int sweeps = 0;
+    bool met = false;
+    for (int k = 0; k < 10 && !met; k++) {          // the reference's loop bound (gr_full.c:173)
+        double* const* src = (k & 1) ? b1 : b0;
+        double* const* dst = (k & 1) ? b0 : b1;
+        a.aox = src[0]; a.aoy = src[1]; a.aoz = src[2];
+        bool unconverged = false;
+        if (EXACT) {
+            if (live) unconverged = grfull_exact_row<PASS_SWEEP>(a, i, acx, acy, acz, dst[0], dst[1], dst[2]);
+        } else {
+            double s0 = p0, s1 = p1, s2 = p2;
+            if (k > 0) {
+                grfull_row_init<PASS_SWEEP>(a, i, live, row);
+                grfull_stage<PASS_SWEEP>(a, tid, n, tid, ta, tb, tc);
+                __syncthreads();
+                row.self = live ? tid : -1;
+                grfull_tile<PASS_SWEEP, true, 1, true>(ta, tb, tc, reinterpret_cast<Row(&)[1]>(row), (int)n);
+                s0 = row.s0 * scale; s1 = row.s1 * scale; s2 = row.s2 * scale;
+            }
+            if (live) {
+                s0 = (0. + s0) + acx[i]; s1 = (0. + s1) + acy[i]; s2 = (0. + s2) + acz[i];
+                unconverged = grfull_row_unconverged(s0, s1, s2, src[0][i], src[1][i], src[2][i]);
+                dst[0][i] = s0; dst[1][i] = s1; dst[2][i] = s2;
+            }
+        }
+        sweeps = k + 1;
+        met = __syncthreads_or(unconverged ? 1 : 0) == 0;      // (also the barrier between this sweep's rows and the next one's tile)
+    }
+    double* const* newest = (sweeps & 1) ? b1 : b0;
+    if (live) { v.ax[i] += newest[0][i]; v.ay[i] += newest[1][i]; v.az[i] += newest[2][i]; }
+    if (tid == 0) {
+        ctl[0] = met ? 1u : 0u; ctl[1] = (unsigned)sweeps; ctl[2] = 0u;
+        if (!met) atomicOr(status, WARN_GRFULL_SWEEPS);
+    }
+}
+
+hipError_t launch_grfull_small(const View& v, double G, double c, int gravity_ignore_10, double* w, unsigned* ctl, unsigned* status, bool exact, hipStream_t st) {
+    if (v.n <= 0 || v.n > GB) return hipErrorInvalidValue;
+    GrFullArgs a;
+    a.n = v.n; a.row0 = 0; a.row1 = v.n; a.jchunk = v.n;
+    a.G = G; a.C2 = c * c; a.invC2 = 1. / (c * c);
+    a.x = v.x; a.y = v.y; a.z = v.z; a.vx = v.vx; a.vy = v.vy; a.vz = v.vz; a.m = v.m;
+    a.pot = nullptr; a.anx = a.any_ = a.anz = a.aox = a.aoy = a.aoz = nullptr; a.part = nullptr; a.stop = nullptr;
+    if (exact) hipLaunchKernelGGL(grfull_small_kernel<true>, dim3(1), dim3(GB), 0, st, v, a, gravity_ignore_10, w, ctl, status);
+    else hipLaunchKernelGGL(grfull_small_kernel<false>, dim3(1), dim3(GB), 0, st, v, a, gravity_ignore_10, w, ctl, status);
+    return hipGetLastError();
+}
+int grfull_small_limit() { return GB; }
 
 // ------------------------------------------------------------------ Hamiltonian (gr_full.c:251-377)
 // Canonical velocities vtilde by fixed-point sweeps, then kinetic + Newtonian + post-Newtonian

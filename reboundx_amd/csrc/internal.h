@@ -249,6 +249,9 @@ hipError_t launch_grfull_vote(unsigned* ctl, hipStream_t st);
 hipError_t launch_grfull_finish_select(const View& v, double* const b0[3], double* const b1[3], const unsigned* ctl, unsigned* status, hipStream_t st);
 size_t grfull_hamiltonian_doubles(long long n);
 hipError_t launch_grfull_hamiltonian(const View& v, double G, double c, double* ws, double** out, hipStream_t st);
+// a whole gr_full evaluation of at most grfull_small_limit() bodies in one launch (w: 13 columns of n doubles; ctl: 3 words)
+hipError_t launch_grfull_small(const View& v, double G, double c, int gravity_ignore_10, double* w, unsigned* ctl, unsigned* status, bool exact, hipStream_t st);
+int grfull_small_limit();
 hipError_t launch_grfull_prepare(const View& v, double G, int gravity_ignore_10, double* anx, double* any_, double* anz,
                                  double* a0x, double* a0y, double* a0z, hipStream_t st);
 hipError_t launch_grfull_finish(const View& v, const double* ax, const double* ay, const double* az, hipStream_t st);

@@ -182,6 +182,10 @@ class Context:
         """Whether stacks with a kernel instance of their own use it (default) or walk the op list."""
         self._check(lib.rebxamd_fixed_stacks(self._h, 1 if on else 0))
 
+    def grfull_one_launch(self, on=True):
+        """gr_full on at most 256 bodies: the whole evaluation in one launch (default), or the queued passes (on=False)."""
+        self._check(lib.rebxamd_grfull_one_launch(self._h, 1 if on else 0))
+
     def sequential_exact(self, on=True):
         """Reference-order arithmetic on layouts with massive bodies anywhere: walk gr and Jacobi/barycentric
         modify_orbits_forces in the reference's order up to REBXAMD_SEQ_MAX_BODIES particles (default), or always

@@ -1,5 +1,5 @@
 """Latency of the drop-in call (sim->additional_forces, host array-of-structs in and out) on small systems.
-usage: python scripts/hook_latency.py [n ...]      (REBXAMD_HOOK_IN_PLACE=0: one copy per direction instead of in-place evaluation)"""
+usage: python scripts/hook_latency.py [grfull] [n ...]      (grfull: gr_full alone instead of gr + harmonics + radiation; REBXAMD_HOOK_IN_PLACE=0: one copy per direction instead of in-place evaluation)"""
 import ctypes
 import os
 import sys
@@ -12,9 +12,12 @@ sys.path.insert(0, ROOT)
 from reboundx_amd import synthetic  # noqa: E402
 from reboundx_amd.extras import Extras, Particle, Simulation  # noqa: E402
 
-sizes = [int(float(a)) for a in sys.argv[1:]] or [100, 1000, 4000, 10000]
+args = list(sys.argv[1:])
+stack = ("gr_full",) if "grfull" in args else ("gr", "gravitational_harmonics", "radiation_forces")
+args = [a for a in args if a != "grfull"]
+sizes = [int(float(a)) for a in args] or [100, 1000, 4000, 10000]
 for n in sizes:
-    cols, pp, _ = synthetic.disk(n, 1)
+    cols, pp, _ = synthetic.disk(n, 1, dust_mass=1e-9) if stack == ("gr_full",) else synthetic.disk(n, 1)
     sim = Simulation()
     arr = (Particle * n)()
     view = np.frombuffer(arr, dtype=np.float64).reshape(n, 16)
@@ -25,7 +28,7 @@ for n in sizes:
     sim.N = n
     arr[0]._sim = ctypes.pointer(sim)
     rebx = Extras(sim)
-    for name in ("gr", "gravitational_harmonics", "radiation_forces"):
+    for name in stack:
         f = rebx.load_force(name)
         if name != "gravitational_harmonics":
             f.params["c"] = synthetic.C_DEFAULT
@@ -37,7 +40,7 @@ for n in sizes:
     rebx.set_param_column("beta", pp["beta"])
     for _ in range(50):
         sim.call_additional_forces()
-    reps = 2000
+    reps = 2000 if stack != ("gr_full",) else 300
     t0 = time.perf_counter()
     for _ in range(reps):
         sim.call_additional_forces()

@@ -674,6 +674,30 @@ def test_gr_full_against_checker(ctx, n, ignore10, mode):
         assert rel_err(got, np.array(ref.acc)).max(initial=0.0) <= 1e-12
 
 
+@pytest.mark.parametrize("mode", [EXACT, FAST])
+def test_gr_full_in_one_launch_equals_the_queued_passes_bit_for_bit(ctx, mode):
+    """Up to 256 bodies rebxamd_grfull runs the whole evaluation in one launch of one workgroup: the same per-row
+    functions in the same order as the queued passes, so the same bits and the same sweep count -- for 1 ... 256
+    bodies, both settings of gravity_ignore_terms, a speed of light that takes all ten sweeps (with the reference's
+    warning) and one that converges early.  257 bodies take the queued passes either way."""
+    from reboundx_amd.device import DeviceParticles
+    for n in (1, 2, 3, 9, 64, 65, 200, 256, 257):
+        cl = cluster_with_gravity(n)
+        for c, ignore10 in ((1e2, 0), (1e4, 1), (3.0, 0)):
+            results = []
+            for one_launch in (True, False):
+                ctx.grfull_one_launch(one_launch)
+                try:
+                    dp = DeviceParticles.from_host(cl)
+                    sweeps = ctx.grfull(dp.view(), c, ignore10, mode)
+                    results.append((sweeps, np.array(dp.acc_host()), ctx.fetch_warnings()))
+                finally:
+                    ctx.grfull_one_launch(True)
+            assert results[0][0] == results[1][0], (n, c)
+            assert results[0][2] == results[1][2], (n, c)
+            assert np.array_equal(results[0][1].view(np.uint64), results[1][1].view(np.uint64)), (n, c)
+
+
 def test_gr_full_reference_test_system(ctx):
     """test_machine_independent.py:52-73: the three-body system, c = 1e4, after WHFast's
     Jacobi gravity (gravity_ignore_terms = 1 adds the 0-1 pair back, gr_full.c:92-102)."""
