@@ -124,13 +124,14 @@ extern "C" int rebxamd_create(int device, rebxamd_ctx** out) {
         hipMalloc((void**)&ctx->star, 96 * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&ctx->whead, 3 * 8 * REBXAMD_MAX_HEAD * sizeof(double)) != hipSuccess ||     // Jacobi state + two copies of the state between kick and drift
         hipHostMalloc(&ctx->hpin, 512, hipHostMallocDefault) != hipSuccess ||
-        hipHostGetDevicePointer((void**)&ctx->hpin_dev, ctx->hpin, 0) != hipSuccess ||
         hipMalloc((void**)&ctx->chunk_sums, sizeof(double) * REBXAMD_MAX_OPS * 64 * 3) != hipSuccess ||
         hipMemset(ctx->hc, 0, 4 * sizeof(HeadConsts)) != hipSuccess ||
         hipMemset(ctx->status, 0, sizeof(unsigned)) != hipSuccess) {
         rebxamd_destroy(ctx);
         return REBXAMD_ERR_HIP;
     }
+    // (a runtime that will not map the pinned buffer for the device: the warning word then travels by a copy command)
+    if (hipHostGetDevicePointer((void**)&ctx->hpin_dev, ctx->hpin, 0) != hipSuccess) { ctx->hpin_dev = nullptr; (void)hipGetLastError(); }
     *out = ctx;
     return REBXAMD_OK;
 }
@@ -272,8 +273,13 @@ extern "C" int rebxamd_fetch_warnings(rebxamd_ctx* ctx, uint32_t* bits, void* st
     if (!ctx || !bits) return fail(ctx, REBXAMD_ERR_ARG, "rebxamd_fetch_warnings: bad argument");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(hand_over_warnings, dim3(1), dim3(1), 0, st, ctx->status, ctx->hpin_dev);
-    HIP_TRY(hipGetLastError());
+    if (ctx->hpin_dev) {
+        hipLaunchKernelGGL(hand_over_warnings, dim3(1), dim3(1), 0, st, ctx->status, ctx->hpin_dev);
+        HIP_TRY(hipGetLastError());
+    } else {
+        HIP_TRY(hipMemcpyAsync(ctx->hpin, ctx->status, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemsetAsync(ctx->status, 0, sizeof(unsigned), st));
+    }
     HIP_TRY(hipStreamSynchronize(st));
     unsigned h = 0;
     memcpy(&h, ctx->hpin, sizeof(h));
