@@ -1725,6 +1725,14 @@ extern "C" int rebxamd_grfull(rebxamd_ctx* ctx, const rebxamd_view* u, double c,
                 rc = fail(ctx, REBXAMD_ERR_HIP, "gr_full: first sweep");
         } else rc = rebxamd_grfull_sweep(ctx, u, c, 0, n, anx, any_, anz, src[0], src[1], src[2], acx, acy, acz, dst[0], dst[1], dst[2], ctl + 2, mode, stream);
         if (rc == REBXAMD_OK && launch_grfull_vote(ctl, st) != hipSuccess) rc = fail(ctx, REBXAMD_ERR_HIP, "gr_full: vote kernel");
+        // Small systems, where a sweep takes less time than the launches of the sweeps queued behind it cost when they find the
+        // stop word set (three kernels each, a few microseconds apiece): the host looks at the stop word after every fourth sweep
+        // instead of queueing all ten at once.
+        if (rc == REBXAMD_OK && n <= 16384 && (k + 1) % 4 == 0 && k + 1 < 10) {
+            unsigned h[2] = {0u, 0u};
+            rc = read_back(ctx, h, ctl, sizeof(h), st);
+            if (rc == REBXAMD_OK && h[0] != 0u) break;
+        }
     }
     ctx->gf_stop = caller_stop;
     if (rc != REBXAMD_OK) return rc;

@@ -194,7 +194,9 @@ __device__ __forceinline__ bool grfull_row_unconverged(double s0, double s1, dou
 }
 
 // Workgroup = 256 threads, GB*R rows: thread t owns rows t, t + 256, ... of the workgroup's block.
-template <int PASS, int R>
+// SHORT: the j range of a workgroup is shorter than a tile (systems of a few hundred to a few thousand bodies, split finely
+// so that the pairs spread over many compute units): the tile loop stops at the bodies staged.
+template <int PASS, int R, bool SHORT = false>
 __global__ __launch_bounds__(GB) void grfull_fast_kernel(GrFullArgs a) {
     constexpr bool SWEEP = PASS == PASS_SWEEP || PASS == PASS_SWEEP_POT;
     __shared__ TileA ta[GB];
@@ -229,9 +231,9 @@ __global__ __launch_bounds__(GB) void grfull_fast_kernel(GrFullArgs a) {
                 const long long i = a.row0 + ri_[q];
                 row[q].self = (live[q] && i >= jt && i < jt + GB) ? (int)(i - jt) : -1;
             }
-            grfull_tile<PASS, true, R>(ta, tb, tc, row);
+            grfull_tile<PASS, true, R, SHORT>(ta, tb, tc, row, (int)((j1 - jt) < GB ? (j1 - jt) : GB));
         } else {
-            grfull_tile<PASS, false, R>(ta, tb, tc, row);
+            grfull_tile<PASS, false, R, SHORT>(ta, tb, tc, row, (int)((j1 - jt) < GB ? (j1 - jt) : GB));
         }
     }
     const double scale = a.invC2;
@@ -688,6 +690,15 @@ static GrFullPlan plan(long long n, long long nrows) {
     const long long tiles_per_chunk = (tiles + want - 1) / want;
     p.jchunk = tiles_per_chunk * GB;
     p.nchunks = (int)((n + p.jchunk - 1) / p.jchunk);
+    // A few hundred to a few thousand bodies: whole tiles leave most compute units idle (1000 bodies: 4 x 4 workgroups), and a
+    // workgroup takes ~10 us per tile whatever else happens.  There the j range is cut into pieces of 64 or 128 bodies (at most
+    // 64 pieces), which the tile loop of the SHORT kernels stops at.
+    if (n > GB && p.rows_per_thread == 1 && (long long)p.rowblocks * p.nchunks < 512) {
+        for (long long piece = 64; piece < GB; piece *= 2) {
+            const long long pieces = (n + piece - 1) / piece;
+            if (pieces <= 64) { p.jchunk = piece; p.nchunks = (int)pieces; break; }
+        }
+    }
     return p;
 }
 
@@ -728,16 +739,20 @@ hipError_t launch_grfull_pass(int pass, const View& v, double G, double c, long 
     const dim3 g((unsigned)p.rowblocks, (unsigned)p.nchunks), b(GB);
     const dim3 g2((unsigned)((nrows + 255) / 256)), b2(256);
     const bool two = p.rows_per_thread == 2;
+    const bool pieces = p.jchunk < GB;
     if (pass == PASS_POT) {
         if (two) hipLaunchKernelGGL((grfull_fast_kernel<PASS_POT, 2>), g, b, 0, st, a);
+        else if (pieces) hipLaunchKernelGGL((grfull_fast_kernel<PASS_POT, 1, true>), g, b, 0, st, a);
         else hipLaunchKernelGGL((grfull_fast_kernel<PASS_POT, 1>), g, b, 0, st, a);
         hipLaunchKernelGGL(grfull_combine_kernel<PASS_POT>, g2, b2, 0, st, part, p.nchunks, row0, row1, acx, acy, acz, aox, aoy, aoz, o0, o1, o2, flag, stop, 1);
     } else if (pass == PASS_CONST) {
         if (two) hipLaunchKernelGGL((grfull_fast_kernel<PASS_CONST, 2>), g, b, 0, st, a);
+        else if (pieces) hipLaunchKernelGGL((grfull_fast_kernel<PASS_CONST, 1, true>), g, b, 0, st, a);
         else hipLaunchKernelGGL((grfull_fast_kernel<PASS_CONST, 1>), g, b, 0, st, a);
         hipLaunchKernelGGL(grfull_combine_kernel<PASS_CONST>, g2, b2, 0, st, part, p.nchunks, row0, row1, acx, acy, acz, aox, aoy, aoz, o0, o1, o2, flag, stop, 3);
     } else {
         if (two) hipLaunchKernelGGL((grfull_fast_kernel<PASS_SWEEP, 2>), g, b, 0, st, a);
+        else if (pieces) hipLaunchKernelGGL((grfull_fast_kernel<PASS_SWEEP, 1, true>), g, b, 0, st, a);
         else hipLaunchKernelGGL((grfull_fast_kernel<PASS_SWEEP, 1>), g, b, 0, st, a);
         hipLaunchKernelGGL(grfull_combine_kernel<PASS_SWEEP>, g2, b2, 0, st, part, p.nchunks, row0, row1, acx, acy, acz, aox, aoy, aoz, o0, o1, o2, flag, stop, 3);
     }
@@ -757,6 +772,7 @@ hipError_t launch_grfull_sweep0_pot(const View& v, double G, double c, long long
     a.jchunk = p.jchunk; a.part = part4;
     const dim3 g((unsigned)p.rowblocks, (unsigned)p.nchunks), b(GB);
     if (p.rows_per_thread == 2) hipLaunchKernelGGL((grfull_fast_kernel<PASS_SWEEP_POT, 2>), g, b, 0, st, a);
+    else if (p.jchunk < GB) hipLaunchKernelGGL((grfull_fast_kernel<PASS_SWEEP_POT, 1, true>), g, b, 0, st, a);
     else hipLaunchKernelGGL((grfull_fast_kernel<PASS_SWEEP_POT, 1>), g, b, 0, st, a);
     return hipGetLastError();
 }
