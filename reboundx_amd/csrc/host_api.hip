@@ -1124,6 +1124,9 @@ void run_builtin(struct reb_simulation* sim, struct rebx_extras* rebx, const std
 
     // ---- kernels
     hipStream_t st = nullptr;
+    // (only gr and gr_full can raise a warning -- their iteration limits: a batch without them has no warning word to fetch)
+    bool may_warn = false;
+    for (const rebxamd_op& o : ops) may_warn |= o.kind == REBXAMD_OP_GR || o.kind == REBXAMD_OP_GR_FULL;
     const int rc = rebxamd_apply(b->ctx, &v, ops.data(), (int)ops.size(), b->mode, st);
     if (rc != REBXAMD_OK) {
         char str[400];
@@ -1141,7 +1144,8 @@ void run_builtin(struct reb_simulation* sim, struct rebx_extras* rebx, const std
     uint32_t bits = 0;
     if (small_system(b, N)) {
         if (!evaluated_in_place) ok = hipMemcpyAsync(b->h_dyn[H_AX], b->d_dyn[H_AX], (2 * b->cap + (size_t)N) * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess;
-        ok = ok && rebxamd_fetch_warnings(b->ctx, &bits, st) == REBXAMD_OK;     // synchronises the stream
+        if (may_warn) ok = ok && rebxamd_fetch_warnings(b->ctx, &bits, st) == REBXAMD_OK;     // synchronises the stream
+        else ok = ok && hipStreamSynchronize(st) == hipSuccess;
         if (!ok) { rebx_error(rebx, "REBOUNDx (MI355X) Error: device to host copy failed.\n"); return; }
         for (int i = 0; i < N; i++) { particles[i].ax = h[H_AX][i]; particles[i].ay = h[H_AY][i]; particles[i].az = h[H_AZ][i]; }
     } else {
