@@ -49,6 +49,7 @@ struct rebxamd_ctx {
     bool timing = false;
     bool carried_steps = true;  // Wisdom-Holman runs: kick and drift ride in the force pass when the layout allows
     bool fixed_stacks = true;   // stacks with a kernel instance of their own use it
+    bool head_one_launch = true;        // Euler / RK2 / RK4 updates of at most 64 bodies as one launch (off with rebxamd_carried_steps(ctx, 0))
     bool grfull_one_launch = true;      // gr_full of at most 256 bodies as one launch (rebxamd_grfull_one_launch)
     bool seq_exact = true;      // reference-order arithmetic: prefix-sum forces on at most REBXAMD_SEQ_MAX_BODIES bodies are walked in the reference's order
     int chain_rounds = 12;      // modify_orbits_direct on long chains: rounds of the fixed-point iteration before the sequential walk takes over
@@ -188,6 +189,7 @@ extern "C" int rebxamd_sequential_exact(rebxamd_ctx* ctx, int on) {
 extern "C" int rebxamd_carried_steps(rebxamd_ctx* ctx, int on) {
     if (!ctx) return REBXAMD_ERR_ARG;
     ctx->carried_steps = on != 0;
+    ctx->head_one_launch = on != 0;
     return REBXAMD_OK;
 }
 
@@ -308,10 +310,8 @@ static bool has_backreaction(const rebxamd_op& o) {
 // 0 is recorded and drifted after the head pass and the tail pass carries the kick and the drift
 // of every other body (no acceleration traffic); any other layout returns STEP_NOT_CARRIED untouched.
 static constexpr int STEP_NOT_CARRIED = -1000;
-static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_op* ops, int lo, int hi, int mode, hipStream_t st,
-                         long long target_lo = -1, double* sums_out = nullptr, bool pushes_only = false, const StepArgs* step = nullptr) {
-    const View v = make_view(u);
-    Program prog;
+// ops[lo,hi) as the program the kernels walk, checked against the columns of the view.  max_src <- the largest source index.
+static int build_program(rebxamd_ctx* ctx, const rebxamd_view* u, const View& v, const rebxamd_op* ops, int lo, int hi, Program& prog, int& max_src_out) {
     memset(&prog, 0, sizeof(prog));
     prog.nops = hi - lo;
     prog.G = u->G;
@@ -361,10 +361,21 @@ static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_
             return fail(ctx, REBXAMD_ERR_ARG, "op needs a source index");
         }
     }
+    max_src_out = max_src;
     if (v.n <= 0) return REBXAMD_OK;
     if (!v.x || !v.y || !v.z || !v.ax || !v.ay || !v.az) return fail(ctx, REBXAMD_ERR_ARG, "position/acceleration columns missing");
     if (prog.need_vel && (!v.vx || !v.vy || !v.vz)) return fail(ctx, REBXAMD_ERR_ARG, "velocity columns missing");
     if (need_m && !v.m) return fail(ctx, REBXAMD_ERR_ARG, "mass column missing");
+    return REBXAMD_OK;
+}
+
+static int run_streaming(rebxamd_ctx* ctx, const rebxamd_view* u, const rebxamd_op* ops, int lo, int hi, int mode, hipStream_t st,
+                         long long target_lo = -1, double* sums_out = nullptr, bool pushes_only = false, const StepArgs* step = nullptr) {
+    const View v = make_view(u);
+    Program prog;
+    int max_src = -1;
+    { const int rcp = build_program(ctx, u, v, ops, lo, hi, prog, max_src); if (rcp != REBXAMD_OK) return rcp; }
+    if (v.n <= 0) return REBXAMD_OK;
 
     const bool exact = (mode == REBXAMD_MODE_EXACT);
     // (a pass that carries an integrator's round also makes 16-byte accesses to the caller's columns in step->aux)
@@ -730,6 +741,27 @@ extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* vie
         const bool com = ops[k].kind == REBXAMD_OP_MOF && ops[k].iarg != REBX_COORDINATES_PARTICLE;
         const int src = (ops[k].kind == REBXAMD_OP_GR || ops[k].kind == REBXAMD_OP_GR_POTENTIAL) ? 0 : ops[k].src;
         if (!com && (src < 0 || src >= K)) carried = false;
+    }
+    // At most 64 bodies, all of them head (also the prefix of a carried update, which comes back here on a view of its own):
+    // every stage's pass and every update in one launch of one wavefront -- the same functions in the same order as below.
+    if (!carried && known && integrator != REBXAMD_INTEGRATOR_IMPLICIT_MIDPOINT && ctx->head_one_launch && n >= 1 && n <= REBXAMD_MAX_HEAD &&
+        (view->tail_massless != 0 || K == n) && K == n && one_streaming_run(ops, nops) && view->ax && view->ay && view->az) {
+        const View hv = make_view(view);
+        Program prog;
+        int max_src = -1;
+        rc = build_program(ctx, view, hv, ops, 0, nops, prog, max_src);
+        if (rc != REBXAMD_OK) return rc;
+        if (max_src < n) {
+            const size_t stride = ((size_t)n + 1) & ~(size_t)1;
+            rc = ensure(ctx, &ctx->integ, &ctx->integ_cap, 9 * stride * sizeof(double), st);
+            if (rc != REBXAMD_OK) return rc;
+            double c0 = dt, c1 = 0., c2 = 0.;
+            if (integrator == REBXAMD_INTEGRATOR_RK2) { c0 = 2. * dt / 3.; c1 = dt / 4.; c2 = 3. * dt / 4.; }
+            if (integrator == REBXAMD_INTEGRATOR_RK4) { c0 = dt / 2.; c1 = dt; c2 = dt / 6.; }
+            HIP_TRY(launch_head_integrate(hv, prog, ctx->hc, ctx->status, integrator, c0, c1, c2, ctx->integ, (long long)stride, exact, st));
+            ctx->hc_stage = 0;
+            return REBXAMD_OK;
+        }
     }
     if (!carried) {
         // integrate_force.c:46 -- the simulation's accelerations are cleared first, whatever the scheme

@@ -150,6 +150,9 @@ hipError_t launch_stream(const View& v, const Program& prog, long long lo, const
                          int* nblocks_out, bool backreact, bool exact, bool vec2, bool fixed, unsigned* status, hipStream_t st,
                          const StepArgs* step = nullptr);
 hipError_t launch_stage(const View& v, const Program& prog, HeadConsts* hc, hipStream_t st);
+// Euler / RK2 / RK4 update of at most REBXAMD_MAX_HEAD bodies (v.n of them) in one launch; hc: four tables, one per stage
+hipError_t launch_head_integrate(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, int scheme, double c0, double c1, double c2,
+                                 double* w, long long stride, bool exact, hipStream_t st);
 // chunk_sums: scratch of REBXAMD_MAX_OPS * 64 * 3 doubles
 // sums_out: nullptr = add the totals to the source particles; else store 3 doubles per op there
 hipError_t launch_finalize(const View& v, const Program& prog, const double* partials, int nblocks, double* chunk_sums, double* sums_out, hipStream_t st);

@@ -369,6 +369,73 @@ __global__ __launch_bounds__(64) void head_kernel(View v, Program prog, HeadCons
     head_body<EXACT>(v, prog, hc, status, star, h, sh, threadIdx.x);
 }
 
+// ------------------------------------------------------------------ force integrators on a head alone
+// Euler, RK2 and RK4 (integrator_euler.c:33-41, integrator_rk2.c:38-67, integrator_rk4.c:40-91) on at most 64 bodies: every
+// stage's head pass and every velocity update in ONE launch of one wavefront, instead of a launch per pass and per update
+// (a dozen for RK4).  The stages go through head_body and the update functions of updates.h exactly as the separate kernels
+// do, and stage s leaves its tables in hc[s] as they do -- for the pass over the massless bodies behind the head, which
+// evaluates all stages per body.  w: nine columns of `stride` doubles (stage velocities, two sets of stage accelerations).
+// c0, c1, c2: the scheme's coefficients as the host forms them (RK2: 2dt/3, dt/4, 3dt/4; RK4: dt/2, dt, dt/6; Euler: dt).
+template <bool EXACT>
+__global__ __launch_bounds__(64) void head_integrate_kernel(View v, Program prog, HeadConsts* hc, unsigned* status, int scheme, double c0, double c1, double c2,
+                                                            double* w, long long stride) {
+    __shared__ HeadShared sh;
+    const int t = threadIdx.x;
+    const int K = (int)(v.n_head < v.n ? v.n_head : v.n);
+    const bool valid = t < K;
+    double* const vx = const_cast<double*>(v.vx); double* const vy = const_cast<double*>(v.vy); double* const vz = const_cast<double*>(v.vz);
+    double* const sv[3] = {w, w + stride, w + 2 * stride};
+    double* const ka[3] = {w + 3 * stride, w + 4 * stride, w + 5 * stride};
+    double* const kb[3] = {w + 6 * stride, w + 7 * stride, w + 8 * stride};
+    // integrate_force.c:46: the accelerations are cleared first; the stage copies are made after that, so theirs start at zero
+    if (valid) {
+        v.ax[t] = 0.; v.ay[t] = 0.; v.az[t] = 0.;
+        for (int k = 0; k < 3; k++) { ka[k][t] = 0.; kb[k][t] = 0.; }
+    }
+    wave_sync();
+    head_body<EXACT>(v, prog, hc, status, nullptr, 0., sh, t);                      // k1 -> the accelerations of v
+    wave_sync();
+    if (scheme == REBXAMD_INTEGRATOR_EULER) {
+        if (valid) { vx[t] = axpy1<EXACT>(vx[t], c0, v.ax[t]); vy[t] = axpy1<EXACT>(vy[t], c0, v.ay[t]); vz[t] = axpy1<EXACT>(vz[t], c0, v.az[t]); }
+        return;
+    }
+    View sa = v, sb = v;                    // stage states share positions, masses, parameters
+    sa.vx = sv[0]; sa.vy = sv[1]; sa.vz = sv[2]; sa.ax = ka[0]; sa.ay = ka[1]; sa.az = ka[2];
+    sb.vx = sv[0]; sb.vy = sv[1]; sb.vz = sv[2]; sb.ax = kb[0]; sb.ay = kb[1]; sb.az = kb[2];
+    if (valid) { sv[0][t] = axpy1<EXACT>(vx[t], c0, v.ax[t]); sv[1][t] = axpy1<EXACT>(vy[t], c0, v.ay[t]); sv[2][t] = axpy1<EXACT>(vz[t], c0, v.az[t]); }
+    wave_sync();
+    head_body<EXACT>(sa, prog, hc + 1, status, nullptr, 0., sh, t);                 // k2 -> ka
+    wave_sync();
+    if (scheme == REBXAMD_INTEGRATOR_RK2) {
+        if (valid) {
+            vx[t] = rk2_combine<EXACT>(vx[t], c1, v.ax[t], c2, ka[0][t]);
+            vy[t] = rk2_combine<EXACT>(vy[t], c1, v.ay[t], c2, ka[1][t]);
+            vz[t] = rk2_combine<EXACT>(vz[t], c1, v.az[t], c2, ka[2][t]);
+        }
+        return;
+    }
+    if (valid) { sv[0][t] = axpy1<EXACT>(vx[t], c0, ka[0][t]); sv[1][t] = axpy1<EXACT>(vy[t], c0, ka[1][t]); sv[2][t] = axpy1<EXACT>(vz[t], c0, ka[2][t]); }
+    wave_sync();
+    head_body<EXACT>(sb, prog, hc + 2, status, nullptr, 0., sh, t);                 // k3 -> kb
+    wave_sync();
+    if (valid) {                            // stage velocity for k4 = v + dt k3;  kb = k3 + k2;  ka = 0
+        for (int k = 0; k < 3; k++) {
+            const double k3 = kb[k][t];
+            sv[k][t] = axpy1<EXACT>(k == 0 ? vx[t] : (k == 1 ? vy[t] : vz[t]), c1, k3);
+            kb[k][t] = k3 + ka[k][t];
+            ka[k][t] = 0.;
+        }
+    }
+    wave_sync();
+    head_body<EXACT>(sa, prog, hc + 3, status, nullptr, 0., sh, t);                 // k4 -> ka
+    wave_sync();
+    if (valid) {
+        vx[t] = rk4_combine<EXACT>(vx[t], c2, v.ax[t], ka[0][t], kb[0][t]);
+        vy[t] = rk4_combine<EXACT>(vy[t], c2, v.ay[t], ka[1][t], kb[1][t]);
+        vz[t] = rk4_combine<EXACT>(vz[t], c2, v.az[t], ka[2][t], kb[2][t]);
+    }
+}
+
 // The head pass when the head is ONE body (a star in front of massless bodies) and no op works in
 // barycentric coordinates: nothing acts on that body (every op has it as its source, and its
 // Jacobi frame is empty), so the pass only fills the tables -- with the arithmetic of head_kernel
@@ -1427,6 +1494,13 @@ hipError_t launch_stream(const View& v, const Program& prog, long long lo, const
         if (backreact) launch_stream_cols<false, true>(g, b, st, vec2, fixed, cols, v, prog, lo, base, hc, partials, status, step);
         else launch_stream_cols<false, false>(g, b, st, vec2, fixed, cols, v, prog, lo, base, hc, partials, status, step);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_head_integrate(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, int scheme, double c0, double c1, double c2,
+                                 double* w, long long stride, bool exact, hipStream_t st) {
+    if (exact) hipLaunchKernelGGL(head_integrate_kernel<true>, dim3(1), dim3(64), 0, st, v, prog, hc, status, scheme, c0, c1, c2, w, stride);
+    else hipLaunchKernelGGL(head_integrate_kernel<false>, dim3(1), dim3(64), 0, st, v, prog, hc, status, scheme, c0, c1, c2, w, stride);
     return hipGetLastError();
 }
 
