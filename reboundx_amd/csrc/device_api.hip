@@ -744,7 +744,7 @@ extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* vie
     }
     // At most 64 bodies, all of them head (also the prefix of a carried update, which comes back here on a view of its own):
     // every stage's pass and every update in one launch of one wavefront -- the same functions in the same order as below.
-    if (!carried && known && integrator != REBXAMD_INTEGRATOR_IMPLICIT_MIDPOINT && ctx->head_one_launch && n >= 1 && n <= REBXAMD_MAX_HEAD &&
+    if (!carried && known && ctx->head_one_launch && n >= 1 && n <= REBXAMD_MAX_HEAD &&
         (view->tail_massless != 0 || K == n) && K == n && one_streaming_run(ops, nops) && view->ax && view->ay && view->az) {
         const View hv = make_view(view);
         Program prog;
@@ -753,8 +753,19 @@ extern "C" int rebxamd_integrate_force(rebxamd_ctx* ctx, const rebxamd_view* vie
         if (rc != REBXAMD_OK) return rc;
         if (max_src < n) {
             const size_t stride = ((size_t)n + 1) & ~(size_t)1;
-            rc = ensure(ctx, &ctx->integ, &ctx->integ_cap, 9 * stride * sizeof(double), st);
+            rc = ensure(ctx, &ctx->integ, &ctx->integ_cap, (9 * stride + 1) * sizeof(double), st);
             if (rc != REBXAMD_OK) return rc;
+            if (integrator == REBXAMD_INTEGRATOR_IMPLICIT_MIDPOINT) {
+                int* const rounds = reinterpret_cast<int*>(ctx->integ + 9 * stride);
+                HIP_TRY(launch_head_implicit_midpoint(hv, prog, ctx->hc, ctx->status, dt, ctx->integ, (long long)stride, rounds, exact, st));
+                ctx->hc_stage = 0;
+                if (iterations) {
+                    int h = 0;
+                    { const int rb = read_back(ctx, &h, rounds, sizeof(h), st); if (rb != REBXAMD_OK) return rb; }
+                    *iterations = h;
+                }
+                return REBXAMD_OK;
+            }
             double c0 = dt, c1 = 0., c2 = 0.;
             if (integrator == REBXAMD_INTEGRATOR_RK2) { c0 = 2. * dt / 3.; c1 = dt / 4.; c2 = 3. * dt / 4.; }
             if (integrator == REBXAMD_INTEGRATOR_RK4) { c0 = dt / 2.; c1 = dt; c2 = dt / 6.; }

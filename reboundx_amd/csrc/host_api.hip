@@ -1494,8 +1494,8 @@ extern "C" void rebx_integrate_force(struct reb_simulation* const sim, struct re
     const Pending pf{force, bi};
     if (!ops_of_force(sim, rebx, b, pf, ops)) return;
     hipStream_t st = nullptr;
-    int iterations = 0;
-    const int rc = rebxamd_integrate_force(b->ctx, &v, ops.data(), (int)ops.size(), integrator, dt, b->mode, &iterations, st);
+    // (the round count of the implicit scheme is not asked for: its warning travels in the warning word)
+    const int rc = rebxamd_integrate_force(b->ctx, &v, ops.data(), (int)ops.size(), integrator, dt, b->mode, nullptr, st);
     if (rc != REBXAMD_OK) {
         char str[400];
         snprintf(str, sizeof(str), "REBOUNDx (MI355X) Error: %s. Velocities were not updated.\n", rebxamd_last_error(b->ctx));

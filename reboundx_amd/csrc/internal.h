@@ -150,6 +150,9 @@ hipError_t launch_stream(const View& v, const Program& prog, long long lo, const
                          int* nblocks_out, bool backreact, bool exact, bool vec2, bool fixed, unsigned* status, hipStream_t st,
                          const StepArgs* step = nullptr);
 hipError_t launch_stage(const View& v, const Program& prog, HeadConsts* hc, hipStream_t st);
+// implicit-midpoint update of at most REBXAMD_MAX_HEAD bodies in one launch (out[0] <- index of the round that met the test, 10: none)
+hipError_t launch_head_implicit_midpoint(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, double dt, double* w, long long stride, int* out,
+                                         bool exact, hipStream_t st);
 // Euler / RK2 / RK4 update of at most REBXAMD_MAX_HEAD bodies (v.n of them) in one launch; hc: four tables, one per stage
 hipError_t launch_head_integrate(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, int scheme, double c0, double c1, double c2,
                                  double* w, long long stride, bool exact, hipStream_t st);

@@ -436,6 +436,57 @@ __global__ __launch_bounds__(64) void head_integrate_kernel(View v, Program prog
     }
 }
 
+// Implicit midpoint (integrator_implicit_midpoint.c:83-124) on at most 64 bodies, every round in the same launch: forces at the
+// averaged velocities (head_body), the new estimate of the final velocities, the reference's test on the summed squared change
+// and squared size (compare(), :47-62) -- formed as the separate kernels form them for one workgroup: a wavefront's shuffle tree
+// -- and the averaged state for the next round; at most ten rounds.  out[0] <- the index of the round that met the test (10: none
+// did, and the warning is raised).  w: nine columns of `stride` doubles.
+template <bool EXACT>
+__global__ __launch_bounds__(64) void head_implicit_midpoint_kernel(View v, Program prog, HeadConsts* hc, unsigned* status, double dt, double* w, long long stride, int* out) {
+    __shared__ HeadShared sh;
+    const int t = threadIdx.x;
+    const int K = (int)(v.n_head < v.n ? v.n_head : v.n);
+    const bool valid = t < K;
+    double* const vx = const_cast<double*>(v.vx); double* const vy = const_cast<double*>(v.vy); double* const vz = const_cast<double*>(v.vz);
+    double* const sv[3] = {w, w + stride, w + 2 * stride};
+    double* const ka[3] = {w + 3 * stride, w + 4 * stride, w + 5 * stride};
+    double ox = 0., oy = 0., oz = 0., fx = 0., fy = 0., fz = 0.;
+    if (valid) {
+        v.ax[t] = 0.; v.ay[t] = 0.; v.az[t] = 0.;                      // integrate_force.c:46
+        ox = vx[t]; oy = vy[t]; oz = vz[t];
+        fx = ox; fy = oy; fz = oz;                                      // estimate of the final velocities
+        sv[0][t] = ox; sv[1][t] = oy; sv[2][t] = oz;                    // averaged velocities of the first round
+        ka[0][t] = 0.; ka[1][t] = 0.; ka[2][t] = 0.;
+    }
+    View sa = v;
+    sa.vx = sv[0]; sa.vy = sv[1]; sa.vz = sv[2]; sa.ax = ka[0]; sa.ay = ka[1]; sa.az = ka[2];
+    int it = 0;
+    for (it = 0; it < 10; it++) {
+        wave_sync();
+        head_body<EXACT>(sa, prog, hc, status, nullptr, 0., sh, t);
+        wave_sync();
+        double d2 = 0., t2 = 0.;
+        if (valid) {
+            const double nx = axpy1<EXACT>(ox, dt, ka[0][t]), ny = axpy1<EXACT>(oy, dt, ka[1][t]), nz = axpy1<EXACT>(oz, dt, ka[2][t]);
+            const double dx = nx - fx, dy = ny - fy, dz = nz - fz;
+            d2 = dx * dx + dy * dy + dz * dz;
+            t2 = nx * nx + ny * ny + nz * nz;
+            fx = nx; fy = ny; fz = nz;
+            sv[0][t] = 0.5 * (ox + nx); sv[1][t] = 0.5 * (oy + ny); sv[2][t] = 0.5 * (oz + nz);
+            ka[0][t] = 0.; ka[1][t] = 0.; ka[2][t] = 0.;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { d2 += __shfl_down(d2, off, 64); t2 += __shfl_down(t2, off, 64); }
+        const double s = __shfl(d2, 0, 64), tt = __shfl(t2, 0, 64);
+        if (s / tt < 2.220446049250313e-16 * 2.220446049250313e-16) break;
+    }
+    if (valid) { vx[t] = fx; vy[t] = fy; vz[t] = fz; }
+    if (t == 0) {
+        if (it == 10) atomicOr(status, WARN_IM_ITER);
+        out[0] = it;
+    }
+}
+
 // The head pass when the head is ONE body (a star in front of massless bodies) and no op works in
 // barycentric coordinates: nothing acts on that body (every op has it as its source, and its
 // Jacobi frame is empty), so the pass only fills the tables -- with the arithmetic of head_kernel
@@ -1501,6 +1552,13 @@ hipError_t launch_head_integrate(const View& v, const Program& prog, HeadConsts*
                                  double* w, long long stride, bool exact, hipStream_t st) {
     if (exact) hipLaunchKernelGGL(head_integrate_kernel<true>, dim3(1), dim3(64), 0, st, v, prog, hc, status, scheme, c0, c1, c2, w, stride);
     else hipLaunchKernelGGL(head_integrate_kernel<false>, dim3(1), dim3(64), 0, st, v, prog, hc, status, scheme, c0, c1, c2, w, stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_head_implicit_midpoint(const View& v, const Program& prog, HeadConsts* hc, unsigned* status, double dt, double* w, long long stride, int* out,
+                                         bool exact, hipStream_t st) {
+    if (exact) hipLaunchKernelGGL(head_implicit_midpoint_kernel<true>, dim3(1), dim3(64), 0, st, v, prog, hc, status, dt, w, stride, out);
+    else hipLaunchKernelGGL(head_implicit_midpoint_kernel<false>, dim3(1), dim3(64), 0, st, v, prog, hc, status, dt, w, stride, out);
     return hipGetLastError();
 }
 
