@@ -116,6 +116,44 @@ def test_update_carried_by_one_pass_equals_separate_passes(ctx, n, planets, forc
         assert (np.abs(a1 - a2) / np.where(big == 0., 1., big)[None, :]).max() <= TOL
 
 
+@pytest.mark.parametrize("mode", [EXACT, FAST])
+@pytest.mark.parametrize("integrator", ["euler", "rk2", "rk4", "implicit_midpoint"])
+@pytest.mark.parametrize("n", [2, 3, 17, 64, 65])
+def test_small_systems_updated_in_one_launch_equal_the_separate_passes(ctx, n, integrator, mode):
+    """Up to 64 bodies, every one of them massive: all stages (or rounds) of the update run in one launch of one
+    wavefront; switched off (with the carried passes), every stage is a force pass plus an elementwise pass.  Same
+    functions in the same order: bit-equal velocities, left-over accelerations and round counts in reference-order
+    arithmetic, and the checker's velocities within the bar.  65 bodies take the separate passes either way."""
+    cols, pp, _ = synthetic.disk(n, min(3, n - 1), dust_mass=1e-7)
+    pp = dict(pp)
+    pp["primary"] = np.zeros(n, dtype=np.uint8)
+    pp["primary"][0] = 1
+    forces = [("modify_orbits_forces", {"coordinates": 2}), ("gr", {"c": C}), ("modify_orbits_forces", {}), ("radiation_forces", {"c": C}), ("tides_precession", {})]
+    ops = build_ops(forces, pp)
+    ref = oracle.Sim(cols)
+    n_ref = oracle.integrate_force(ref, integrator, 0.01, forces, pp)
+    out, rounds = [], []
+    for one_launch in (True, False):
+        dp = device_state(cols, pp, n_head=n, tail_massless=False)
+        try:
+            ctx.carried_steps(one_launch)
+            rounds.append(ctx.integrate_force(dp.view(), ops, integrator, 0.01, mode))
+        finally:
+            ctx.carried_steps(True)
+        out.append((vel(dp), np.array(dp.acc_host())))
+    (v1, a1), (v2, a2) = out
+    assert rounds[0] == rounds[1] == n_ref
+    v0 = np.array([cols[k] for k in ("vx", "vy", "vz")])
+    vr = np.array([ref.cols[k] for k in ("vx", "vy", "vz")])
+    assert dv_err(v0, vr, v1) <= TOL
+    if mode == EXACT:
+        assert np.array_equal(v1, v2) and np.array_equal(a1, a2)
+        if integrator != "implicit_midpoint":
+            assert ulp_diff(v1, vr).max() == 0
+    else:
+        assert dv_err(v0, v2, v1) <= TOL
+
+
 @pytest.mark.parametrize("integrator", ["euler", "rk4", "implicit_midpoint"])
 @pytest.mark.parametrize("odd", [("vx",), ("vy", "vz"), ("x", "vx", "ax")])
 def test_columns_at_odd_offsets_take_the_eight_byte_accesses(ctx, integrator, odd):
