@@ -1486,8 +1486,10 @@ extern "C" void rebx_integrate_force(struct reb_simulation* const sim, struct re
     Bridge* b = bridge_of(rebx, true);
     rebxamd_view v;
     double t[3];
-    // (implicit midpoint makes a pass per round over the columns: it keeps them in device memory; gr_full reads them all the time)
-    const bool in_place = in_place_wanted(b, N) && integrator != REBXAMD_INTEGRATOR_IMPLICIT_MIDPOINT && force->update_accelerations != rebx_gr_full;
+    // (implicit midpoint makes a pass per round over the columns: beyond a wavefront's worth of bodies it keeps them in device
+    // memory; gr_full reads them all the time)
+    const bool in_place = in_place_wanted(b, N) && (integrator != REBXAMD_INTEGRATOR_IMPLICIT_MIDPOINT || N <= REBXAMD_MAX_HEAD) &&
+                          force->update_accelerations != rebx_gr_full;
     if (!stage_in(sim, rebx, b, sim->particles, N, v, t, true, true, in_place)) return;
     const bool evaluated_in_place = in_place && v.x == b->hd_dyn[H_X];
     std::vector<rebxamd_op> ops;
