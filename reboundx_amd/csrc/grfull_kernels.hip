@@ -534,11 +534,11 @@ int grfull_small_limit() { return GB; }
 // ten sweeps they agree to rounding unless the system is strongly relativistic.
 struct __align__(16) TileH { double x, y, z, m, vx, vy, vz, pad; };
 
-__global__ __launch_bounds__(GB) void grfull_h_sweep_kernel(View v, double G, double C2, const double* vtx, const double* vty, const double* vtz,
-                                                          double* ox, double* oy, double* oz) {
+// (blk: the workgroup's index among those of the sweep; t: its tile in LDS)
+__device__ __forceinline__ void grfull_h_sweep_body(const View& v, double G, double C2, const double* vtx, const double* vty, const double* vtz,
+                                                    double* ox, double* oy, double* oz, TileH* t, long long blk) {
 #pragma clang fp contract(off)
-    __shared__ TileH t[GB];
-    const long long i = (long long)blockIdx.x * GB + threadIdx.x;
+    const long long i = blk * GB + threadIdx.x;
     const bool live = i < v.n;
     double xi = 0., yi = 0., zi = 0., vix = 0., viy = 0., viz = 0.;
     if (live) { xi = v.x[i]; yi = v.y[i]; zi = v.z[i]; vix = vtx[i]; viy = vty[i]; viz = vtz[i]; }
@@ -572,13 +572,17 @@ __global__ __launch_bounds__(GB) void grfull_h_sweep_kernel(View v, double G, do
         ox[i] = (v.vx[i] + dx) / A; oy[i] = (v.vy[i] + dy) / A; oz[i] = (v.vz[i] + dz) / A;
     }
 }
+__global__ __launch_bounds__(GB) void grfull_h_sweep_kernel(View v, double G, double C2, const double* vtx, const double* vty, const double* vtz,
+                                                          double* ox, double* oy, double* oz) {
+    __shared__ TileH t[GB];
+    grfull_h_sweep_body(v, G, C2, vtx, vty, vtz, ox, oy, oz, t, (long long)blockIdx.x);
+}
 
 // per-workgroup sums of (kinetic, Newtonian potential, post-Newtonian) -> partials[3*block + c]
-__global__ __launch_bounds__(GB) void grfull_h_energy_kernel(View v, double G, double C2, const double* vtx, const double* vty, const double* vtz, double* partials) {
+__device__ __forceinline__ void grfull_h_energy_body(const View& v, double G, double C2, const double* vtx, const double* vty, const double* vtz, double* partials,
+                                                     TileH* t, double (*red)[3], long long blk) {
 #pragma clang fp contract(off)
-    __shared__ TileH t[GB];
-    __shared__ double red[GB / 64][3];
-    const long long i = (long long)blockIdx.x * GB + threadIdx.x;
+    const long long i = blk * GB + threadIdx.x;
     const bool live = i < v.n;
     double xi = 0., yi = 0., zi = 0., mi = 0., vix = 0., viy = 0., viz = 0.;
     if (live) { xi = v.x[i]; yi = v.y[i]; zi = v.z[i]; mi = v.m[i]; vix = vtx[i]; viy = vty[i]; viz = vtz[i]; }
@@ -627,8 +631,34 @@ __global__ __launch_bounds__(GB) void grfull_h_energy_kernel(View v, double G, d
     if (threadIdx.x < 3) {
         double ssum = 0.;
         for (int w = 0; w < GB / 64; w++) ssum += red[w][threadIdx.x];
-        partials[3 * (long long)blockIdx.x + threadIdx.x] = ssum;
+        partials[3 * blk + threadIdx.x] = ssum;
     }
+}
+__global__ __launch_bounds__(GB) void grfull_h_energy_kernel(View v, double G, double C2, const double* vtx, const double* vty, const double* vtz, double* partials) {
+    __shared__ TileH t[GB];
+    __shared__ double red[GB / 64][3];
+    grfull_h_energy_body(v, G, C2, vtx, vty, vtz, partials, t, red, (long long)blockIdx.x);
+}
+
+// Up to 256 bodies: the ten sweeps, the energies and their sums in one launch of one workgroup (the bodies of the kernels
+// above, separated by workgroup barriers; with one workgroup the final sums are the workgroup's own).
+__global__ __launch_bounds__(GB) void grfull_h_small_kernel(View v, double G, double C2, double* ws, double* out) {
+    __shared__ TileH t[GB];
+    __shared__ double red[GB / 64][3];
+    const long long n = v.n;
+    double* a[3] = {ws, ws + n, ws + 2 * n};
+    double* b[3] = {ws + 3 * n, ws + 4 * n, ws + 5 * n};
+    double* part = ws + 6 * n;
+    if (threadIdx.x < n) { a[0][threadIdx.x] = v.vx[threadIdx.x]; a[1][threadIdx.x] = v.vy[threadIdx.x]; a[2][threadIdx.x] = v.vz[threadIdx.x]; }
+    for (int q = 0; q < 10; q++) {                  // the reference's loop bound (gr_full.c:279)
+        __syncthreads();
+        grfull_h_sweep_body(v, G, C2, a[0], a[1], a[2], b[0], b[1], b[2], t, 0);
+        for (int k = 0; k < 3; k++) { double* tmp = a[k]; a[k] = b[k]; b[k] = tmp; }
+    }
+    __syncthreads();
+    grfull_h_energy_body(v, G, C2, a[0], a[1], a[2], part, t, red, 0);
+    __syncthreads();
+    if (threadIdx.x < 3) out[threadIdx.x] = 0. + part[threadIdx.x];
 }
 
 __global__ __launch_bounds__(1024) void grfull_h_sum_kernel(const double* partials, long long nb, double* out) {
@@ -657,6 +687,10 @@ hipError_t launch_grfull_hamiltonian(const View& v, double G, double c, double* 
     double* b[3] = {ws + 3 * n, ws + 4 * n, ws + 5 * n};
     double* part = ws + 6 * n;
     *out = part + 3 * nb;
+    if (n <= GB) {
+        hipLaunchKernelGGL(grfull_h_small_kernel, dim3(1), dim3(GB), 0, st, v, G, c * c, ws, *out);
+        return hipGetLastError();
+    }
     const size_t bytes = (size_t)n * sizeof(double);
     const double* src[3] = {v.vx, v.vy, v.vz};
     for (int k = 0; k < 3; k++) {
